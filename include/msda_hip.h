@@ -1,0 +1,106 @@
+/*
+ * msda_hip.h — C ABI of libmsda_hip.so, the MI355X (gfx950) multi-scale deformable
+ * attention kernels.  Plain pointers and sizes only: no torch / HIP types in the
+ * signatures (the stream is passed as an opaque void* holding a hipStream_t).
+ *
+ * This is the drop-in boundary for the reference's L1 launcher pair (paths relative
+ * to the reference checkout, rziga/msda-triton @ 2025-08-24):
+ *
+ *   msda_fwd_<dtype>  replaces  triton_multi_scale_deformable_attention_fwd
+ *                                 src/msda_triton/kernels.py:351-379   (called from frontend.py:124-126)
+ *   msda_bwd_<dtype>  replaces  triton_multi_scale_deformable_attention_bwd
+ *                                 src/msda_triton/kernels.py:556-592   (called from frontend.py:139-141)
+ *
+ * Tensor conventions are the reference's (frontend.py:157-160, kernels.py:9-15); every
+ * buffer is device memory, dense row-major, and is never modified unless it is an output:
+ *
+ *   value      [B, I, H, D]        packed pyramid, level l occupies pixels
+ *                                  [start_l, start_l + h_l*w_l), row-major (y*w_l + x)
+ *   shapes     [L, 2]  int64       (height, width) per level, on the device; the level
+ *                                  start offsets are derived in-kernel (kernels.py:58-62)
+ *   loc        [B, Q, H, L, P, 2]  (x, y) normalised to [0,1]
+ *   attn       [B, Q, H, L, P]
+ *   out        [B, Q, H, D]
+ *   grad_out   [B, Q, H, D]
+ *   grad_value / grad_loc / grad_attn   shaped like value / loc / attn
+ *
+ * <dtype> in {f32, f16, bf16, f64} is the storage type of every floating-point buffer
+ * (one dtype per call, as in the reference).  Coordinates, bilinear weights and all
+ * accumulation are float (double for f64); results are rounded once on store.
+ *
+ * padding_mode: MSDA_PADDING_BORDER | MSDA_PADDING_ZEROS   (frontend.py:150,161)
+ * align_corners: 0 | 1                                      (frontend.py:151,162)
+ *
+ * Outputs are fully overwritten (no pre-zeroing required, no accumulation into them).
+ * msda_bwd_*: grad_value may be NULL (that gradient is skipped), and grad_loc / grad_attn may
+ * be NULL together (both skipped) — the autograd caller passes only what needs_input_grad asks.
+ * Calls are asynchronous on `stream`; there is no host synchronisation and no allocation
+ * inside, so a call sequence can be captured into a hipGraph.
+ *
+ * Return value: 0 on success; a negative MSDA_ERR_* for rejected arguments (nothing was
+ * launched); a positive hipError_t if a launch failed.  msda_last_error() describes the
+ * most recent failure on the calling thread.
+ */
+#ifndef MSDA_HIP_H
+#define MSDA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDA_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define MSDA_API __attribute__((visibility("default")))
+#else
+#define MSDA_API
+#endif
+
+#define MSDA_PADDING_BORDER 0
+#define MSDA_PADDING_ZEROS 1
+
+#define MSDA_MAX_LEVELS 32
+
+#define MSDA_ERR_BAD_ARG (-1)      /* null pointer, negative size, unknown padding mode */
+#define MSDA_ERR_TOO_MANY_LEVELS (-2) /* L > MSDA_MAX_LEVELS */
+#define MSDA_ERR_TOO_LARGE (-3)    /* I*H*D*sizeof(dtype) >= 2^31 bytes per batch element */
+#define MSDA_ERR_MISALIGNED (-4)   /* a buffer is not aligned to its element size */
+
+#define MSDA_DECLARE(SUF)                                                                          \
+    MSDA_API int msda_fwd_##SUF(const void *value, const int64_t *shapes, const void *loc,                  \
+                       const void *attn, void *out, int64_t B, int64_t I, int64_t H, int64_t D,    \
+                       int64_t Q, int64_t L, int64_t P, int padding_mode, int align_corners,       \
+                       void *stream);                                                              \
+    MSDA_API int msda_bwd_##SUF(const void *grad_out, const void *value, const int64_t *shapes,             \
+                       const void *loc, const void *attn, void *grad_value, void *grad_loc,        \
+                       void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,     \
+                       int64_t L, int64_t P, int padding_mode, int align_corners, void *stream);
+
+MSDA_DECLARE(f32)
+MSDA_DECLARE(f16)
+MSDA_DECLARE(bf16)
+MSDA_DECLARE(f64)
+#undef MSDA_DECLARE
+
+/* ABI version of the loaded library (== MSDA_ABI_VERSION it was built with). */
+MSDA_API int msda_abi_version(void);
+
+/* Human-readable description of the last non-zero return on this thread ("" if none). */
+MSDA_API const char *msda_last_error(void);
+
+/*
+ * Kernel-variant switches for A/B measurements (bench.py, profiling).  Not needed for
+ * normal use: the defaults are the fastest measured variants.  Unknown keys return
+ * MSDA_ERR_BAD_ARG.  Keys:
+ *   "xcd_map"   1 (default): blockIdx -> (batch, head) mapping keeps each (b,h) plane on one XCD's L2
+ *               0: plain linear mapping
+ */
+MSDA_API int msda_set_option(const char *key, int value);
+MSDA_API int msda_get_option(const char *key);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSDA_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of ``libmsda_hip.so`` — the C ABI declared in ``include/msda_hip.h``.
+
+The library is built in-tree by ``msda_triton_amd/csrc/Makefile`` (``__graft_entry__.build()``)
+and lives next to this file.  There is no fallback: if it is missing, every GPU call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libmsda_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+ABI_VERSION = 1
+PADDING_MODES = {"border": 0, "zeros": 1}
+DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64")
+
+# every symbol include/msda_hip.h declares
+EXPORTED_SYMBOLS = tuple(
+    [f"msda_{d}_{s}" for d in ("fwd", "bwd") for s in DTYPE_SUFFIXES]
+    + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option"]
+)
+
+_lib = None
+_lock = threading.Lock()
+
+
+class MSDALibraryError(RuntimeError):
+    """libmsda_hip.so is missing/unloadable, or a call into it failed."""
+
+
+def build(verbose: bool = False, jobs: int = 5) -> str:
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, f"-j{jobs}"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise MSDALibraryError(f"building {LIB_NAME} failed (exit {res.returncode})")
+    return LIB_PATH
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises MSDALibraryError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise MSDALibraryError(
+                f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` or `make -C {CSRC_DIR}`. "
+                "There is no CPU fallback for GPU tensors."
+            )
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # e.g. libamdhip64 missing
+            raise MSDALibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        i64, vp, ci = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int
+        for suf in DTYPE_SUFFIXES:
+            f = getattr(lib, f"msda_fwd_{suf}")
+            f.restype = ci
+            f.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, vp]
+            g = getattr(lib, f"msda_bwd_{suf}")
+            g.restype = ci
+            g.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, vp]
+        lib.msda_abi_version.restype = ci
+        lib.msda_last_error.restype = ctypes.c_char_p
+        lib.msda_set_option.restype = ci
+        lib.msda_set_option.argtypes = [ctypes.c_char_p, ci]
+        lib.msda_get_option.restype = ci
+        lib.msda_get_option.argtypes = [ctypes.c_char_p]
+        got = lib.msda_abi_version()
+        if got != ABI_VERSION:
+            raise MSDALibraryError(f"{LIB_NAME} has ABI version {got}, this package expects {ABI_VERSION}; rebuild it")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().msda_last_error().decode(errors="replace")
+        if rc < 0:
+            raise ValueError(f"{what}: rejected arguments ({rc}): {msg}")
+        raise MSDALibraryError(f"{what}: HIP error {rc}: {msg}")
+
+
+def set_option(key: str, value: int) -> None:
+    check(load().msda_set_option(key.encode(), int(value)), f"msda_set_option({key})")
+
+
+def get_option(key: str) -> int:
+    return int(load().msda_get_option(key.encode()))

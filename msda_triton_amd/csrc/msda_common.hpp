@@ -1,0 +1,220 @@
+// msda_common.hpp — device-side building blocks shared by the forward and backward kernels.
+// gfx950 (MI355X / CDNA4) only: wave64, buffer loads with hardware range checking, DPP lane moves.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/msda_hip.h"
+
+namespace msda {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;          // threads per workgroup of the gather kernels
+constexpr int kMaxLevels = MSDA_MAX_LEVELS;
+constexpr uint32_t kMaskedOffset = 0x80000000u;  // >= any buffer size we accept -> buffer_load returns 0
+
+// ------------------------------------------------------------------------------------------
+// storage type traits: how many bytes, what we accumulate in, how to convert
+// ------------------------------------------------------------------------------------------
+template <typename T> struct Traits;
+template <> struct Traits<float> {
+    using acc = float;
+    static __device__ __forceinline__ float to_acc(float v) { return v; }
+    static __device__ __forceinline__ float from_acc(float v) { return v; }
+};
+template <> struct Traits<double> {
+    using acc = double;
+    static __device__ __forceinline__ double to_acc(double v) { return v; }
+    static __device__ __forceinline__ double from_acc(double v) { return v; }
+};
+template <> struct Traits<_Float16> {
+    using acc = float;
+    static __device__ __forceinline__ float to_acc(_Float16 v) { return (float)v; }
+    static __device__ __forceinline__ _Float16 from_acc(float v) { return (_Float16)v; }
+};
+template <> struct Traits<__bf16> {
+    using acc = float;
+    static __device__ __forceinline__ float to_acc(__bf16 v) { return (float)v; }
+    static __device__ __forceinline__ __bf16 from_acc(float v) { return (__bf16)v; }  // v_cvt_pk_bf16_f32, RNE
+};
+
+// N elements of T with the natural alignment of the whole pack (so one load/store instruction).
+template <typename T, int N> struct alignas(sizeof(T) * N) Pack {
+    T v[N];
+};
+
+// ------------------------------------------------------------------------------------------
+// buffer resource + range-checked raw loads.  A masked bilinear corner carries kMaskedOffset,
+// which is out of range for every descriptor we build, so the hardware returns zeros for it:
+// this is the reference's tl.where(mask, img, 0) (kernels.py:220-231) at no instruction cost.
+// ------------------------------------------------------------------------------------------
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    // base/bytes must be wave-uniform (T20): callers derive them from kernargs and blockIdx only.
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), /*stride*/ 0, (int)bytes, 0x00020000);
+}
+
+template <int BYTES> struct RawLoad;
+template <> struct RawLoad<16> {
+    using type = __attribute__((ext_vector_type(4))) uint32_t;
+    static __device__ __forceinline__ type load(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+};
+template <> struct RawLoad<8> {
+    using type = __attribute__((ext_vector_type(2))) uint32_t;
+    static __device__ __forceinline__ type load(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
+};
+template <> struct RawLoad<4> {
+    using type = uint32_t;
+    static __device__ __forceinline__ type load(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
+};
+template <> struct RawLoad<2> {
+    using type = uint16_t;
+    static __device__ __forceinline__ type load(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0); }
+};
+
+// Load VEC consecutive elements of T at byte offset `off` and widen them to the accumulate type.
+template <typename T, int VEC>
+__device__ __forceinline__ void load_row(rsrc_t r, uint32_t off, typename Traits<T>::acc (&dst)[VEC])
+{
+    using RL = RawLoad<sizeof(T) * VEC>;
+    typename RL::type raw = RL::load(r, off);
+    Pack<T, VEC> p = __builtin_bit_cast(Pack<T, VEC>, raw);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dst[i] = Traits<T>::to_acc(p.v[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// level table in LDS: (h, w) from the device-resident shapes tensor, start = exclusive cumsum
+// of h*w (reference: load_shapes_and_level_offsets, kernels.py:44-64).  No host sync.
+// ------------------------------------------------------------------------------------------
+struct LevelTab {
+    int h[kMaxLevels];
+    int w[kMaxLevels];
+    int start[kMaxLevels];
+};
+
+__device__ __forceinline__ void load_level_table(LevelTab *tab, const int64_t *shapes, int L)
+{
+    const int t = threadIdx.x;
+    if (t < L) {
+        int start = 0;
+        for (int l = 0; l < t; ++l) start += (int)shapes[2 * l] * (int)shapes[2 * l + 1];
+        tab->h[t] = (int)shapes[2 * t];
+        tab->w[t] = (int)shapes[2 * t + 1];
+        tab->start[t] = start;
+    }
+}
+
+// n / d for 0 <= n < 2^22, using a precomputed float reciprocal (exact after the fix-up steps).
+__device__ __forceinline__ int div_small(int n, int d, float inv_d)
+{
+    int q = (int)((float)n * inv_d);
+    if (q * d > n) --q;
+    if ((q + 1) * d <= n) ++q;
+    return q;
+}
+
+// ------------------------------------------------------------------------------------------
+// one sample's bilinear taps (reference: sample_bilinear, kernels.py:120-252; semantics §9.1
+// of SURVEY.md).  Offsets are byte offsets of the four corner rows relative to the (b, h) plane
+// base; a corner that "zeros" padding masks out gets kMaskedOffset.
+// ------------------------------------------------------------------------------------------
+template <typename A> struct Taps {
+    uint32_t off[4];  // 00 (y0,x0), 01 (y0,x1), 10 (y1,x0), 11 (y1,x1)
+    A dx, dy;
+    bool gx_on, gy_on;  // location gradient alive (grid_sample border clipping zeroes it)
+};
+
+template <typename A>
+__device__ __forceinline__ void make_taps(A x, A y, int h, int w, int start, bool zeros, bool align,
+                                          uint32_t row_bytes, Taps<A> &t)
+{
+    const A W = (A)w, Hh = (A)h;
+    A px, py;
+    if (align) {
+        px = x * (W - (A)1);
+        py = y * (Hh - (A)1);
+    } else {
+        px = x * W - (A)0.5;
+        py = y * Hh - (A)0.5;
+    }
+    const A x0 = __builtin_floor(px), y0 = __builtin_floor(py);
+    const A x1 = x0 + (A)1, y1 = y0 + (A)1;
+    // clamp in floating point before the int conversion: far-OOB / NaN coordinates cannot overflow
+    const A xm = W - (A)1, ym = Hh - (A)1;
+    const int x0c = (int)__builtin_fmin(__builtin_fmax(x0, (A)0), xm);
+    const int x1c = (int)__builtin_fmin(__builtin_fmax(x1, (A)0), xm);
+    const int y0c = (int)__builtin_fmin(__builtin_fmax(y0, (A)0), ym);
+    const int y1c = (int)__builtin_fmin(__builtin_fmax(y1, (A)0), ym);
+    const uint32_t r0 = (uint32_t)(start + y0c * w), r1 = (uint32_t)(start + y1c * w);
+    t.off[0] = (r0 + (uint32_t)x0c) * row_bytes;
+    t.off[1] = (r0 + (uint32_t)x1c) * row_bytes;
+    t.off[2] = (r1 + (uint32_t)x0c) * row_bytes;
+    t.off[3] = (r1 + (uint32_t)x1c) * row_bytes;
+    if (zeros) {
+        const bool mx0 = (x0 >= (A)0) && (x0 <= xm), mx1 = (x1 >= (A)0) && (x1 <= xm);
+        const bool my0 = (y0 >= (A)0) && (y0 <= ym), my1 = (y1 >= (A)0) && (y1 <= ym);
+        if (!(my0 && mx0)) t.off[0] = kMaskedOffset;
+        if (!(my0 && mx1)) t.off[1] = kMaskedOffset;
+        if (!(my1 && mx0)) t.off[2] = kMaskedOffset;
+        if (!(my1 && mx1)) t.off[3] = kMaskedOffset;
+        t.gx_on = true;
+        t.gy_on = true;
+    } else {
+        t.gx_on = (px > (A)0) && (px < xm);
+        t.gy_on = (py > (A)0) && (py < ym);
+    }
+    t.dx = px - x0;
+    t.dy = py - y0;
+}
+
+// ------------------------------------------------------------------------------------------
+// sum over the G lanes of a unit (G a power of two, groups are G-aligned inside the wave).
+// Stages 1,2 are quad permutes, 4 is row_half_mirror, 8 is row_mirror (valid because after
+// the lower stages every lane of an aligned sub-group already holds that sub-group's sum);
+// 16 and 32 go through ds_bpermute.  All lanes of the group end with the same bits.
+// ------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+template <int G> __device__ __forceinline__ float group_sum(float v)
+{
+    if constexpr (G >= 2) v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+    if constexpr (G >= 4) v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += dpp_f32<0x141>(v);  // row_half_mirror
+    if constexpr (G >= 16) v += dpp_f32<0x140>(v); // row_mirror
+    if constexpr (G >= 32) v += __shfl_xor(v, 16, kWave);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+
+template <int G> __device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+// blockIdx -> (pair = b*H + h, slot).  With xcd_map, workgroups whose ids are congruent mod 8
+// (they share an XCD and therefore an L2 under round-robin dispatch) work on the same (b, h)
+// planes, and each XCD walks its planes one after another, so a plane is pulled into exactly
+// one L2.  Pure speed: any placement gives the same results.  Returns false for padding blocks.
+__device__ __forceinline__ bool decode_block(int bid, int npairs, int slots, bool xcd_map, int &pair, int &slot)
+{
+    if (xcd_map) {
+        const int x = bid & 7, t = bid >> 3;
+        slot = t % slots;
+        pair = (t / slots) * 8 + x;
+    } else {
+        pair = bid / slots;
+        slot = bid - pair * slots;
+    }
+    return pair < npairs;
+}
+
+}  // namespace msda

@@ -1,0 +1,286 @@
+// msda_launch.hpp — host side of the C ABI: argument checks, variant selection, launches.
+// One translation unit per storage dtype instantiates run_fwd<T> / run_bwd<T> (msda_<dtype>.hip).
+#pragma once
+
+#include <stdio.h>
+
+#include "msda_kernels.hpp"
+
+namespace msda {
+
+// ---- process-wide options and per-thread error text (defined in msda_api.hip) ----
+int option_xcd_map();
+void set_error(const char *fmt, ...);
+
+constexpr int kGatherLdsBudget = 60 * 1024;                // per workgroup, gather kernels
+constexpr int kValueLdsBudget = 160 * 1024 - 2048;         // per workgroup, grad_value tiles
+constexpr int kMaxDynLds = 160 * 1024;
+
+inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+template <typename K> inline void allow_big_lds(K kernel)
+{
+    // one attribute call per kernel instantiation (thread-safe enough: idempotent)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kMaxDynLds);
+}
+
+struct Dims {
+    int64_t B, I, H, D, Q, L, P;
+};
+
+template <typename T>
+inline int check_common(const Dims &d, int padding_mode, const void *const *ptrs, int nptrs)
+{
+    if (d.B < 0 || d.I < 0 || d.H < 0 || d.D < 0 || d.Q < 0 || d.L < 0 || d.P < 0) {
+        set_error("negative dimension");
+        return MSDA_ERR_BAD_ARG;
+    }
+    if (padding_mode != MSDA_PADDING_BORDER && padding_mode != MSDA_PADDING_ZEROS) {
+        set_error("unknown padding_mode %d", padding_mode);
+        return MSDA_ERR_BAD_ARG;
+    }
+    if (d.L > MSDA_MAX_LEVELS) {
+        set_error("L=%lld exceeds MSDA_MAX_LEVELS=%d", (long long)d.L, MSDA_MAX_LEVELS);
+        return MSDA_ERR_TOO_MANY_LEVELS;
+    }
+    const int64_t lim = (int64_t)1 << 31;
+    if (d.I * d.H * d.D * (int64_t)sizeof(T) >= lim || d.B >= lim || d.Q >= lim || d.L * d.P >= (1 << 22) ||
+        d.B * d.H >= (1 << 28)) {
+        set_error("tensor too large for 32-bit plane offsets (I*H*D*sizeof = %lld bytes)",
+                  (long long)(d.I * d.H * d.D * (int64_t)sizeof(T)));
+        return MSDA_ERR_TOO_LARGE;
+    }
+    for (int i = 0; i < nptrs; ++i) {
+        if (ptrs[i] == nullptr) {
+            set_error("null buffer (argument %d)", i);
+            return MSDA_ERR_BAD_ARG;
+        }
+    }
+    return 0;
+}
+
+inline int pick_group(int lanes_needed)
+{
+    if (lanes_needed <= 4) return 4;
+    if (lanes_needed <= 8) return 8;
+    if (lanes_needed <= 16) return 16;
+    if (lanes_needed <= 32) return 32;
+    return 64;
+}
+
+// samples of a unit parked in LDS at a time, and the resulting dynamic LDS size
+inline void plan_gather(int G, int LP, size_t acc_bytes, int &sc, size_t &lds)
+{
+    const int NU = kBlock / G;
+    const size_t rec = 16 + 4 * acc_bytes;
+    const size_t room = kGatherLdsBudget - sizeof(LevelTab);
+    int cap = (int)(room / (NU * rec)) - 1;
+    if (cap < 1) cap = 1;
+    sc = LP < cap ? LP : cap;
+    lds = sizeof(LevelTab) + (size_t)NU * (sc + 1) * rec;
+}
+
+template <typename T, int VEC, int G, bool BWD> inline int launch_gather(Params &p, hipStream_t stream)
+{
+    using A = typename Traits<T>::acc;
+    constexpr int NU = kBlock / G;
+    size_t lds;
+    plan_gather(G, p.LP, sizeof(A), p.sc, lds);
+    p.nqc = (p.Q + NU - 1) / NU;
+    const int npairs = p.B * p.H;
+    const int64_t blocks = (int64_t)(p.xcd_map ? ((npairs + 7) / 8) * 8 : npairs) * p.nqc;
+    if (blocks >= ((int64_t)1 << 31)) {
+        set_error("grid too large");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    auto kernel = BWD ? msda_bwd_sample_kernel<T, VEC, G> : msda_fwd_kernel<T, VEC, G>;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int VEC, bool BWD> inline int dispatch_group(Params &p, hipStream_t stream)
+{
+    const int lanes = (p.D + VEC - 1) / VEC;
+    switch (pick_group(lanes)) {
+    case 4: return launch_gather<T, VEC, 4, BWD>(p, stream);
+    case 8: return launch_gather<T, VEC, 8, BWD>(p, stream);
+    case 16: return launch_gather<T, VEC, 16, BWD>(p, stream);
+    case 32: return launch_gather<T, VEC, 32, BWD>(p, stream);
+    default: return launch_gather<T, VEC, 64, BWD>(p, stream);
+    }
+}
+
+template <typename T, bool BWD> inline int dispatch_gather(Params &p, bool vec_ok, hipStream_t stream)
+{
+    constexpr int VECF = 16 / sizeof(T);
+    if (vec_ok && (p.D % VECF) == 0) return dispatch_group<T, VECF, BWD>(p, stream);
+    return dispatch_group<T, 1, BWD>(p, stream);
+}
+
+template <typename T, int CH> inline int launch_value(Params &p, hipStream_t stream)
+{
+    using A = typename Traits<T>::acc;
+    const size_t px_bytes = (size_t)CH * sizeof(A);
+    const size_t room = kValueLdsBudget - sizeof(LevelTab);
+    p.nchunks = p.D / CH;
+    p.nranges = (int)(((size_t)p.I * px_bytes + room - 1) / room);
+    if (p.nranges < 1) p.nranges = 1;
+    p.range_px = (p.I + p.nranges - 1) / p.nranges;
+    const size_t lds = sizeof(LevelTab) + (size_t)p.range_px * px_bytes;
+    const int npairs = p.B * p.H;
+    const int64_t blocks = (int64_t)(p.xcd_map ? ((npairs + 7) / 8) * 8 : npairs) * p.nchunks * p.nranges;
+    if (blocks >= ((int64_t)1 << 31)) {
+        set_error("grid too large");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    static bool big_lds_ok = false;
+    if (!big_lds_ok) {
+        allow_big_lds(msda_bwd_value_kernel<T, CH>);
+        big_lds_ok = true;
+    }
+    hipLaunchKernelGGL((msda_bwd_value_kernel<T, CH>), dim3((unsigned)blocks), dim3(kValueBlock), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <typename T> inline int dispatch_value(Params &p, hipStream_t stream)
+{
+    using A = typename Traits<T>::acc;
+    const size_t room = kValueLdsBudget - sizeof(LevelTab);
+    auto fits = [&](int ch) {
+        return (p.D % ch) == 0 && aligned_to(p.grad_out, ch * sizeof(T)) && aligned_to(p.grad_value, ch * sizeof(T)) &&
+               (size_t)p.I * ch * sizeof(A) <= room;
+    };
+    if (fits(4)) return launch_value<T, 4>(p, stream);
+    if (fits(2)) return launch_value<T, 2>(p, stream);
+    return launch_value<T, 1>(p, stream);
+}
+
+inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_corners)
+{
+    p.B = (int)d.B;
+    p.I = (int)d.I;
+    p.H = (int)d.H;
+    p.D = (int)d.D;
+    p.Q = (int)d.Q;
+    p.L = (int)d.L;
+    p.P = (int)d.P;
+    p.LP = (int)(d.L * d.P);
+    p.zeros = padding_mode == MSDA_PADDING_ZEROS;
+    p.align = align_corners != 0;
+    p.xcd_map = option_xcd_map();
+    p.nqc = p.sc = p.nchunks = p.nranges = p.range_px = 0;
+}
+
+template <typename T>
+int run_fwd(const void *value, const int64_t *shapes, const void *loc, const void *attn, void *out, int64_t B,
+            int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int padding_mode, int align_corners,
+            void *stream_)
+{
+    const Dims d{B, I, H, D, Q, L, P};
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t out_bytes = (size_t)(B * Q * H * D) * sizeof(T);
+    if (out_bytes == 0) return 0;  // nothing to produce
+    const void *ptrs[] = {out};
+    int rc = check_common<T>(d, padding_mode, ptrs, 1);
+    if (rc) return rc;
+    if (L * P == 0 || I == 0) {  // empty sum
+        return (int)hipMemsetAsync(out, 0, out_bytes, stream);
+    }
+    const void *ptrs2[] = {value, shapes, loc, attn};
+    rc = check_common<T>(d, padding_mode, ptrs2, 4);
+    if (rc) return rc;
+    if (!aligned_to(value, sizeof(T)) || !aligned_to(out, sizeof(T)) || !aligned_to(loc, 2 * sizeof(T)) ||
+        !aligned_to(attn, sizeof(T)) || !aligned_to(shapes, 8)) {
+        set_error("misaligned buffer");
+        return MSDA_ERR_MISALIGNED;
+    }
+    Params p{};
+    p.value = value;
+    p.shapes = shapes;
+    p.loc = loc;
+    p.attn = attn;
+    p.out = out;
+    fill_params(p, d, padding_mode, align_corners);
+    const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
+    rc = dispatch_gather<T, false>(p, vec_ok, stream);
+    if (rc) set_error("forward launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
+template <typename T>
+int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, const void *loc, const void *attn,
+            void *grad_value, void *grad_loc, void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,
+            int64_t L, int64_t P, int padding_mode, int align_corners, void *stream_)
+{
+    const Dims d{B, I, H, D, Q, L, P};
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = check_common<T>(d, padding_mode, nullptr, 0);
+    if (rc) return rc;
+    const size_t gv_bytes = (size_t)(B * I * H * D) * sizeof(T);
+    const size_t ns = (size_t)(B * Q * H * L * P);
+    if (B * Q * H * D == 0 || L * P == 0 || I == 0) {  // no sample touches anything: all gradients are zero
+        hipError_t e = hipSuccess;
+        if (gv_bytes && grad_value) e = hipMemsetAsync(grad_value, 0, gv_bytes, stream);
+        if (e == hipSuccess && ns && grad_loc) e = hipMemsetAsync(grad_loc, 0, ns * 2 * sizeof(T), stream);
+        if (e == hipSuccess && ns && grad_attn) e = hipMemsetAsync(grad_attn, 0, ns * sizeof(T), stream);
+        return (int)e;
+    }
+    const bool want_value = grad_value != nullptr;
+    const bool want_sample = grad_loc != nullptr || grad_attn != nullptr;
+    if (want_sample && (grad_loc == nullptr || grad_attn == nullptr)) {
+        set_error("grad_loc and grad_attn must be both null or both non-null");
+        return MSDA_ERR_BAD_ARG;
+    }
+    const void *ptrs[] = {grad_out, value, shapes, loc, attn};
+    rc = check_common<T>(d, padding_mode, ptrs, 5);
+    if (rc) return rc;
+    if (!aligned_to(value, sizeof(T)) || !aligned_to(grad_out, sizeof(T)) || !aligned_to(grad_value, sizeof(T)) ||
+        !aligned_to(loc, 2 * sizeof(T)) || !aligned_to(grad_loc, 2 * sizeof(T)) || !aligned_to(attn, sizeof(T)) ||
+        !aligned_to(grad_attn, sizeof(T)) || !aligned_to(shapes, 8)) {
+        set_error("misaligned buffer");
+        return MSDA_ERR_MISALIGNED;
+    }
+    Params p{};
+    p.value = value;
+    p.shapes = shapes;
+    p.loc = loc;
+    p.attn = attn;
+    p.grad_out = grad_out;
+    p.grad_value = grad_value;
+    p.grad_loc = grad_loc;
+    p.grad_attn = grad_attn;
+    fill_params(p, d, padding_mode, align_corners);
+    if (want_sample) {
+        const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
+        rc = dispatch_gather<T, true>(p, vec_ok, stream);
+        if (rc) {
+            set_error("backward (grad_loc/grad_attn) launch failed: %s", hipGetErrorString((hipError_t)rc));
+            return rc;
+        }
+    }
+    if (want_value) {
+        rc = dispatch_value<T>(p, stream);
+        if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
+    }
+    return rc;
+}
+
+}  // namespace msda
+
+#define MSDA_DEFINE_ENTRY_POINTS(SUF, T)                                                                         \
+    extern "C" int msda_fwd_##SUF(const void *value, const int64_t *shapes, const void *loc, const void *attn,  \
+                                  void *out, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,  \
+                                  int64_t P, int padding_mode, int align_corners, void *stream)                 \
+    {                                                                                                            \
+        return msda::run_fwd<T>(value, shapes, loc, attn, out, B, I, H, D, Q, L, P, padding_mode,               \
+                                align_corners, stream);                                                          \
+    }                                                                                                            \
+    extern "C" int msda_bwd_##SUF(const void *grad_out, const void *value, const int64_t *shapes,               \
+                                  const void *loc, const void *attn, void *grad_value, void *grad_loc,          \
+                                  void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,       \
+                                  int64_t L, int64_t P, int padding_mode, int align_corners, void *stream)      \
+    {                                                                                                            \
+        return msda::run_bwd<T>(grad_out, value, shapes, loc, attn, grad_value, grad_loc, grad_attn, B, I, H,   \
+                                D, Q, L, P, padding_mode, align_corners, stream);                                \
+    }

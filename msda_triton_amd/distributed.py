@@ -1,0 +1,133 @@
+"""Query-sharded multi-GPU execution: one process per GPU, ``torch.distributed`` (RCCL over xGMI).
+
+The reference has no multi-device code; every (b, q, h) of the operator is independent
+(/root/reference/src/msda_triton/kernels.py:18-21), so the queries shard trivially:
+
+  forward   each rank runs the HIP kernels on its contiguous slice of the query axis against the
+            (replicated) value pyramid, then ONE all-gather assembles ``[B, Q, H, D]`` on every rank;
+  backward  grad_sampling_points / grad_attention_weights are shard-local (no communication);
+            grad_value is a sum over all queries, so it is all-reduced across the ranks.
+
+With 8 GPUs on one node the all-gather moves ``B*Q*H*D*s/8`` bytes per peer over point-to-point
+xGMI links; the collectives are issued once per call on whole tensors (no bucketing needed at
+these sizes: c4 0.9 MB, c5 51 MB per rank).
+"""
+from __future__ import annotations
+
+from typing import Literal, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch.autograd.function import Function
+
+from .functional import multiscale_deformable_attention
+
+
+def shard_bounds(num_queries: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous slice [begin, end) of the query axis owned by ``rank`` (equal ceil-sized shards,
+    the last ones may be short or empty)."""
+    per = -(-num_queries // world_size)
+    begin = min(num_queries, rank * per)
+    return begin, min(num_queries, begin + per)
+
+
+def _all_gather_into(buf: torch.Tensor, local: torch.Tensor, group) -> None:
+    try:
+        dist.all_gather_into_tensor(buf, local, group=group)
+    except (RuntimeError, NotImplementedError):  # backend without the fused form
+        dist.all_gather(list(buf.unbind(0)), local, group=group)
+
+
+class _GatherQueryShards(Function):
+    """local [B, per, H, D] on every rank  ->  full [B, Q, H, D] on every rank.
+
+    Backward takes this rank's slice of the incoming gradient: correct when every rank evaluates
+    the same downstream computation on the gathered output (replicated consumers, the
+    Grounding-DINO decoder case); use ``grad_sync="reduce_scatter"`` when consumers differ per rank.
+    """
+
+    @staticmethod
+    def forward(ctx, local: torch.Tensor, num_queries: int, group, grad_sync: str):
+        world = dist.get_world_size(group)
+        ctx.group, ctx.world, ctx.rank = group, world, dist.get_rank(group)
+        ctx.num_queries, ctx.grad_sync = num_queries, grad_sync
+        B, per, H, D = local.shape
+        ctx.per = per
+        buf = local.new_empty((world, B, per, H, D))
+        _all_gather_into(buf, local.contiguous(), group)
+        full = buf.permute(1, 0, 2, 3, 4).reshape(B, world * per, H, D)
+        return full[:, :num_queries].contiguous()
+
+    @staticmethod
+    def backward(ctx, grad_full: torch.Tensor):
+        B, Q, H, D = grad_full.shape
+        per, world = ctx.per, ctx.world
+        if Q < world * per:
+            grad_full = torch.nn.functional.pad(grad_full, (0, 0, 0, 0, 0, world * per - Q))
+        if ctx.grad_sync == "reduce_scatter":
+            shards = grad_full.reshape(B, world, per, H, D).permute(1, 0, 2, 3, 4).contiguous()
+            mine = torch.empty_like(shards[0])
+            dist.reduce_scatter_tensor(mine, shards, group=ctx.group)
+        else:
+            mine = grad_full[:, ctx.rank * per:(ctx.rank + 1) * per].contiguous()
+        return mine, None, None, None
+
+
+class _ReplicatedValue(Function):
+    """Identity in forward; sums the gradient over the ranks in backward (value is shared by all
+    query shards, so its gradient is the sum of the per-shard scatter results)."""
+
+    @staticmethod
+    def forward(ctx, value: torch.Tensor, group):
+        ctx.group = group
+        return value.view_as(value)
+
+    @staticmethod
+    def backward(ctx, grad: torch.Tensor):
+        grad = grad.contiguous()
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=ctx.group)
+        return grad, None
+
+
+def sharded_multiscale_deformable_attention(
+    img: torch.Tensor,
+    img_shapes: torch.Tensor,
+    sampling_points: torch.Tensor,
+    attention_weights: torch.Tensor,
+    padding_mode: Literal["border", "zeros"],
+    align_corners: bool,
+    group: Optional[dist.ProcessGroup] = None,
+    inputs_are_sharded: bool = False,
+    num_queries: Optional[int] = None,
+    grad_sync: Literal["slice", "reduce_scatter"] = "slice",
+) -> torch.Tensor:
+    """Query-sharded operator; returns the full ``[B, Q, H, D]`` output on every rank.
+
+    ``inputs_are_sharded=False``: ``sampling_points`` / ``attention_weights`` hold all Q queries
+    (replicated) and each rank computes its ``shard_bounds`` slice.
+    ``inputs_are_sharded=True``: they already hold only this rank's slice (``num_queries`` = global
+    Q is then required, and every rank's slice must have the ceil-sized shard length except that
+    trailing ranks may be shorter).
+    ``img`` is the full value pyramid on every rank.
+    """
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("torch.distributed is not initialised; call init_process_group first")
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if inputs_are_sharded:
+        if num_queries is None:
+            raise ValueError("num_queries (global) is required when inputs_are_sharded=True")
+        Q = int(num_queries)
+        pts, att = sampling_points, attention_weights
+    else:
+        Q = sampling_points.shape[1]
+        begin, end = shard_bounds(Q, world, rank)
+        pts, att = sampling_points[:, begin:end], attention_weights[:, begin:end]
+    per = -(-Q // world)
+    if img.requires_grad and world > 1:
+        img = _ReplicatedValue.apply(img, group)
+    local = multiscale_deformable_attention(img, img_shapes, pts, att, padding_mode, align_corners)
+    if local.shape[1] < per:  # short / empty trailing shard: pad so the all-gather is regular
+        local = torch.nn.functional.pad(local, (0, 0, 0, 0, 0, per - local.shape[1]))
+    if world == 1:
+        return local[:, :Q]
+    return _GatherQueryShards.apply(local, Q, group, grad_sync)

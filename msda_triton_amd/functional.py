@@ -1,0 +1,260 @@
+"""Functional API: the reference's operator interface over the MI355X HIP kernels.
+
+Mirrors /root/reference/src/msda_triton/frontend.py (same names, argument meaning and errors):
+
+  multiscale_deformable_attention          frontend.py:145-172   public entry
+  hip_multiscale_deformable_attention      frontend.py:71-105    GPU path (there: triton_multiscale_…)
+  native_multiscale_deformable_attention   frontend.py:15-68     host-tensor path
+  msda_hip_fwd / msda_hip_bwd              kernels.py:351-379 / 556-592   launcher pair (the native seam)
+
+Deliberate differences from the reference:
+  * GPU tensors never fall back to a CPU/eager path.  The reference wraps its GPU path in
+    ``try/except Exception`` (frontend.py:167-172); here a missing extension or a failed launch
+    raises.  Host (CPU) tensors use the native formulation, as the reference documents
+    (README.md:127 "cpu uses fallback native torch version").
+  * bfloat16 runs natively on the GPU (the reference rejects it, frontend.py:84).
+  * an unknown ``padding_mode`` raises ``ValueError`` instead of reaching ``grid_sample``.
+"""
+from __future__ import annotations
+
+from typing import Literal, Optional, Tuple
+
+import torch
+from torch.amp import custom_bwd, custom_fwd
+from torch.autograd.function import Function, once_differentiable
+
+from . import _lib
+
+_SUFFIX = {
+    torch.float32: "f32",
+    torch.float16: "f16",
+    torch.bfloat16: "bf16",
+    torch.float64: "f64",
+}
+VALID_DTYPES = tuple(_SUFFIX)
+
+
+def _padding_code(padding_mode: str) -> int:
+    try:
+        return _lib.PADDING_MODES[padding_mode]
+    except KeyError:
+        raise ValueError(f"`padding_mode` should be 'border' or 'zeros', but got {padding_mode!r}.") from None
+
+
+def _dims(img: torch.Tensor, sampling_points: torch.Tensor, attention_weights: torch.Tensor, img_shapes: torch.Tensor):
+    if img.dim() != 4 or sampling_points.dim() != 6 or attention_weights.dim() != 5:
+        raise ValueError(
+            "expected img [B,I,H,C], sampling_points [B,N,H,L,P,2], attention_weights [B,N,H,L,P]; got "
+            f"{tuple(img.shape)}, {tuple(sampling_points.shape)}, {tuple(attention_weights.shape)}")
+    B, I, H, D = img.shape
+    B2, Q, H2, L, P, two = sampling_points.shape
+    if (B2, H2, two) != (B, H, 2) or tuple(attention_weights.shape) != (B, Q, H, L, P):
+        raise ValueError(
+            f"inconsistent shapes: img {tuple(img.shape)}, sampling_points {tuple(sampling_points.shape)}, "
+            f"attention_weights {tuple(attention_weights.shape)}")
+    if tuple(img_shapes.shape) != (L, 2):
+        raise ValueError(f"`img_shapes` should be [{L}, 2], but got {tuple(img_shapes.shape)}.")
+    return B, I, H, D, Q, L, P
+
+
+def _shapes_i64(img_shapes: torch.Tensor) -> torch.Tensor:
+    if img_shapes.dtype not in (torch.int64, torch.int32, torch.int16, torch.int8, torch.uint8):
+        raise ValueError(f"`img_shapes` should be an integer tensor, but got {img_shapes.dtype}.")
+    return img_shapes.to(torch.int64).contiguous()  # stays on the device: no host sync
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+# ------------------------------------------------------------------------------------------
+# launcher pair — the native seam (reference: kernels.py:351-379, 556-592)
+# ------------------------------------------------------------------------------------------
+def msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners) -> torch.Tensor:
+    """Allocate ``out`` and enqueue the forward kernel on the current stream (no host sync)."""
+    B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
+    pad = _padding_code(padding_mode)
+    suf = _SUFFIX[img.dtype]
+    img, sampling_points, attention_weights = img.contiguous(), sampling_points.contiguous(), attention_weights.contiguous()
+    shapes = _shapes_i64(img_shapes)
+    out = torch.empty((B, Q, H, D), dtype=img.dtype, device=img.device)
+    lib = _lib.load()
+    with torch.cuda.device(img.device):
+        rc = getattr(lib, f"msda_fwd_{suf}")(
+            img.data_ptr(), shapes.data_ptr(), sampling_points.data_ptr(), attention_weights.data_ptr(),
+            out.data_ptr(), B, I, H, D, Q, L, P, pad, int(bool(align_corners)), _stream_ptr(img.device))
+    _lib.check(rc, f"msda_fwd_{suf}")
+    return out
+
+
+def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners,
+                 needs: Tuple[bool, bool, bool] = (True, True, True)
+                 ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """Returns ``(img_grad, sampling_points_grad, attention_weights_grad)``; entries not in ``needs`` are None.
+
+    Gradients are allocated contiguous (the reference's ``zeros_like(...).contiguous()`` would write
+    into a temporary for permuted inputs, kernels.py:570-578) and are fully written by the kernels,
+    so they are not pre-zeroed.
+    """
+    B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
+    pad = _padding_code(padding_mode)
+    suf = _SUFFIX[img.dtype]
+    img, sampling_points, attention_weights = img.contiguous(), sampling_points.contiguous(), attention_weights.contiguous()
+    out_grad = out_grad.contiguous()
+    if out_grad.dtype != img.dtype:
+        out_grad = out_grad.to(img.dtype)
+    shapes = _shapes_i64(img_shapes)
+    want_value = bool(needs[0])
+    want_sample = bool(needs[1] or needs[2])
+    kw = dict(dtype=img.dtype, device=img.device)
+    g_img = torch.empty((B, I, H, D), **kw) if want_value else None
+    g_pts = torch.empty((B, Q, H, L, P, 2), **kw) if want_sample else None
+    g_att = torch.empty((B, Q, H, L, P), **kw) if want_sample else None
+    if want_value or want_sample:
+        lib = _lib.load()
+        with torch.cuda.device(img.device):
+            rc = getattr(lib, f"msda_bwd_{suf}")(
+                out_grad.data_ptr(), img.data_ptr(), shapes.data_ptr(), sampling_points.data_ptr(),
+                attention_weights.data_ptr(),
+                g_img.data_ptr() if want_value else None,
+                g_pts.data_ptr() if want_sample else None,
+                g_att.data_ptr() if want_sample else None,
+                B, I, H, D, Q, L, P, pad, int(bool(align_corners)), _stream_ptr(img.device))
+        _lib.check(rc, f"msda_bwd_{suf}")
+    return g_img, (g_pts if needs[1] else None), (g_att if needs[2] else None)
+
+
+# ------------------------------------------------------------------------------------------
+# autograd boundary (reference: _TritonMultiscaleDeformableAttentionFunction, frontend.py:108-142)
+# ------------------------------------------------------------------------------------------
+class _HipMultiscaleDeformableAttentionFunction(Function):
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # under autocast the op runs in fp32 (frontend.py:111)
+    def forward(ctx, img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners):
+        ctx.save_for_backward(img, img_shapes, sampling_points, attention_weights)
+        ctx.padding_mode = padding_mode
+        ctx.align_corners = align_corners
+        return msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners)
+
+    @staticmethod
+    @once_differentiable
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, out_grad):
+        img, img_shapes, sampling_points, attention_weights = ctx.saved_tensors
+        needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        g_img, g_pts, g_att = msda_hip_bwd(
+            out_grad, img, img_shapes, sampling_points, attention_weights,
+            ctx.padding_mode, ctx.align_corners, needs)
+        return g_img, None, g_pts, g_att, None, None
+
+
+def hip_multiscale_deformable_attention(
+    img: torch.Tensor,
+    img_shapes: torch.Tensor,
+    sampling_points: torch.Tensor,
+    attention_weights: torch.Tensor,
+    padding_mode: Literal["border", "zeros"],
+    align_corners: bool,
+) -> torch.Tensor:
+    """GPU path.  Same contract as the reference's ``triton_multiscale_deformable_attention``
+    (frontend.py:71-105): ``ValueError`` on unsupported dtype or non-GPU inputs."""
+    for name, t in (("img", img), ("sampling_points", sampling_points), ("attention_weights", attention_weights)):
+        if t.dtype not in VALID_DTYPES:
+            raise ValueError(f"Dtype of `{name}` should be in {list(VALID_DTYPES)}, but got {t.dtype}.")
+    if not (img.dtype == sampling_points.dtype == attention_weights.dtype):
+        raise ValueError(
+            "`img`, `sampling_points` and `attention_weights` should share one dtype, but got "
+            f"{img.dtype}, {sampling_points.dtype}, {attention_weights.dtype}.")
+    devices = [t.device for t in (img, img_shapes, sampling_points, attention_weights)]
+    if any(d.type != "cuda" for d in devices) or any(d != devices[0] for d in devices):
+        raise ValueError(f"Expected all inputs to be on one gpu, but got {devices}.")
+    _padding_code(padding_mode)
+    return _HipMultiscaleDeformableAttentionFunction.apply(
+        img, img_shapes, sampling_points, attention_weights, padding_mode, bool(align_corners))
+
+
+# ------------------------------------------------------------------------------------------
+# host-tensor path (reference: native_multiscale_deformable_attention, frontend.py:15-68)
+# ------------------------------------------------------------------------------------------
+def _unnormalise(coord: torch.Tensor, size: int, padding_mode: str, align_corners: bool) -> torch.Tensor:
+    pix = coord * (size - 1) if align_corners else coord * size - 0.5
+    if padding_mode == "border":
+        # grid_sample clips the coordinate to [0, size-1] and kills its gradient at and beyond the border
+        inside = (pix > 0) & (pix < size - 1)
+        pix = torch.where(inside, pix, pix.detach().clamp(0, size - 1))
+    return pix
+
+
+def native_multiscale_deformable_attention(
+    img: torch.Tensor,
+    img_shapes: torch.Tensor,
+    sampling_points: torch.Tensor,
+    attention_weights: torch.Tensor,
+    padding_mode: Literal["border", "zeros"],
+    align_corners: bool,
+) -> torch.Tensor:
+    """Plain-PyTorch formulation for host tensors, differentiable through autograd.
+
+    An independent statement of the operator (index arithmetic + ``gather``; the reference loops
+    ``F.grid_sample`` over levels).  Like the reference's it reads ``img_shapes`` on the host.
+    """
+    _padding_code(padding_mode)
+    B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
+    planes = img.permute(0, 2, 1, 3)  # [B, H, I, D]
+    out = img.new_zeros((B, H, Q, D))
+    start = 0
+    for lvl, (h, w) in enumerate(img_shapes.tolist()):
+        plane = planes[:, :, start:start + h * w]                      # [B, H, h*w, D]
+        pts = sampling_points[:, :, :, lvl].permute(0, 2, 1, 3, 4)     # [B, H, Q, P, 2]
+        att = attention_weights[:, :, :, lvl].permute(0, 2, 1, 3)      # [B, H, Q, P]
+        px = _unnormalise(pts[..., 0], w, padding_mode, align_corners)
+        py = _unnormalise(pts[..., 1], h, padding_mode, align_corners)
+        x0, y0 = px.detach().floor(), py.detach().floor()
+        dx, dy = px - x0, py - y0
+        level_sample = 0
+        for yo, xo, wgt in ((0, 0, (1 - dy) * (1 - dx)), (0, 1, (1 - dy) * dx), (1, 0, dy * (1 - dx)), (1, 1, dy * dx)):
+            xi, yi = x0 + xo, y0 + yo
+            valid = (xi >= 0) & (xi <= w - 1) & (yi >= 0) & (yi <= h - 1)
+            idx = (yi.clamp(0, h - 1) * w + xi.clamp(0, w - 1)).long()            # [B, H, Q, P]
+            rows = plane.gather(2, idx.reshape(B, H, Q * P, 1).expand(-1, -1, -1, D)).reshape(B, H, Q, P, D)
+            level_sample = level_sample + rows * (wgt * valid.to(wgt.dtype)).unsqueeze(-1)
+        out = out + (level_sample * att.unsqueeze(-1)).sum(dim=3)
+        start += h * w
+    return out.permute(0, 2, 1, 3).contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+# public entry (reference: multiscale_deformable_attention, frontend.py:145-172)
+# ------------------------------------------------------------------------------------------
+def multiscale_deformable_attention(
+    img: torch.Tensor,
+    img_shapes: torch.Tensor,
+    sampling_points: torch.Tensor,
+    attention_weights: torch.Tensor,
+    padding_mode: Literal["border", "zeros"],
+    align_corners: bool,
+) -> torch.Tensor:
+    """Differentiable multiscale deformable attention.
+
+    Args:
+        img: flattened image pyramid ``[batch, num_image, num_heads, num_channels]`` with
+            ``num_image = sum(h*w)`` over the levels.
+        img_shapes: ``[num_levels, 2]`` integer tensor of (height, width).
+        sampling_points: ``[batch, num_queries, num_heads, num_levels, num_points, 2]`` in (x, y)
+            order, normalised to [0, 1] with (0, 0) the top-left corner.
+        attention_weights: ``[batch, num_queries, num_heads, num_levels, num_points]``.
+        padding_mode: ``"border"`` (clamp to the nearest pixel) or ``"zeros"``.
+        align_corners: grid alignment, as in ``torch.nn.functional.grid_sample``.
+
+    Returns:
+        ``[batch, num_queries, num_heads, num_channels]``.
+
+    Tensors on an AMD GPU ("cuda" device type on ROCm) run the hand-written gfx950 kernels and
+    never fall back; host tensors run the plain-PyTorch formulation.
+    """
+    if img.device.type == "cuda":
+        return hip_multiscale_deformable_attention(
+            img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners)
+    return native_multiscale_deformable_attention(
+        img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners)

@@ -1,0 +1,91 @@
+"""``MultiscaleDeformableAttention`` — the reference's nn.Module interface
+(/root/reference/src/msda_triton/frontend.py:175-292) over the HIP operator.
+
+Parameter names (``img_input_proj``, ``query_input_proj``, ``query_output_proj``) and shapes are
+the reference's, so state dicts interchange.  The projections are plain ``nn.Linear`` GEMMs
+(hipBLASLt through PyTorch); only the deformable-attention core is custom.
+"""
+from __future__ import annotations
+
+from typing import Literal
+
+import torch
+from torch import nn
+
+from .functional import multiscale_deformable_attention
+
+
+class MultiscaleDeformableAttention(nn.Module):
+    """Multiscale deformable attention with input/output projections (Deformable-DETR, fig. 2).
+
+    Args:
+        emb_dim: feature dimension of ``img`` and ``queries``.
+        hidden_dim: projected feature dimension; must be divisible by ``num_heads``.
+        num_levels: number of pyramid levels.
+        num_heads: number of attention heads.
+        num_points: sampling points per level.
+        padding_mode: ``"border"`` or ``"zeros"``.
+        align_corners: grid alignment.
+
+    Raises:
+        ValueError: if ``hidden_dim`` is not divisible by ``num_heads`` (frontend.py:211-212).
+    """
+
+    def __init__(self, emb_dim: int, hidden_dim: int, num_levels: int, num_heads: int, num_points: int,
+                 padding_mode: Literal["border", "zeros"], align_corners: bool):
+        super().__init__()
+        if hidden_dim % num_heads != 0:
+            raise ValueError(
+                f"Hidden dimension ({hidden_dim=}) should be divisible by number of heads ({num_heads=}).")
+        self.num_levels = num_levels
+        self.num_heads = num_heads
+        self.num_points = num_points
+        self.hidden_dim = hidden_dim
+        self.padding_mode = padding_mode
+        self.align_corners = align_corners
+        # one fused query projection: (x offset, y offset, attention logit) per (head, level, point)
+        self.img_input_proj = nn.Linear(emb_dim, hidden_dim)
+        self.query_input_proj = nn.Linear(emb_dim, num_heads * num_levels * num_points * 3)
+        self.query_output_proj = nn.Linear(hidden_dim, emb_dim)
+
+    def sampling_inputs(self, img_shapes: torch.Tensor, queries: torch.Tensor, reference_points: torch.Tensor):
+        """Query projection -> (sampling_points [B,N,H,L,P,2], attention_weights [B,N,H,L,P])."""
+        B, N, _ = queries.shape
+        H, L, P = self.num_heads, self.num_levels, self.num_points
+        proj = self.query_input_proj(queries).reshape(B, N, H, L, P, 3)
+        offsets, logits = proj[..., :2], proj[..., 2]
+        attention_weights = logits.reshape(B, N, H, L * P).softmax(dim=-1).reshape(B, N, H, L, P)
+
+        ref = reference_points[:, :, None, None, None, :]
+        coords = reference_points.shape[-1]
+        if coords == 2:
+            # NB: the reference divides the (x, y) offsets by img_shapes in its stored (h, w) order
+            # (frontend.py:275); reproduced for parity — it only matters for non-square levels.
+            sampling_points = ref + offsets / img_shapes[:, None, :]
+        elif coords == 4:
+            sampling_points = ref[..., :2] + offsets * ref[..., 2:] / (2 * P)
+        else:
+            raise ValueError(f"`reference_points` should have the last dim either 2 or 4, but got {coords}.")
+        return sampling_points, attention_weights
+
+    def forward(self, img: torch.Tensor, img_shapes: torch.Tensor, queries: torch.Tensor,
+                reference_points: torch.Tensor) -> torch.Tensor:
+        """
+        Args:
+            img: flattened pyramid ``[batch, num_image, emb_dim]``.
+            img_shapes: ``[num_levels, 2]`` (height, width).
+            queries: ``[batch, num_queries, emb_dim]``.
+            reference_points: ``[batch, num_queries, 2]`` (x, y) or ``[batch, num_queries, 4]``
+                (cx, cy, w, h), normalised to [0, 1].
+
+        Returns:
+            ``[batch, num_queries, emb_dim]``.
+        """
+        B, I, _ = img.shape  # noqa: E741
+        N = queries.shape[1]
+        H = self.num_heads
+        sampling_points, attention_weights = self.sampling_inputs(img_shapes, queries, reference_points)
+        value = self.img_input_proj(img).reshape(B, I, H, self.hidden_dim // H)
+        attended = multiscale_deformable_attention(
+            value, img_shapes, sampling_points, attention_weights, self.padding_mode, self.align_corners)
+        return self.query_output_proj(attended.reshape(B, N, self.hidden_dim))

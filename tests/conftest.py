@@ -1,0 +1,56 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+MODES = [("zeros", False), ("zeros", True), ("border", False), ("border", True)]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def mode_key(pm, ac):
+    return f"{pm}_{int(ac)}"
+
+
+def golden_cases(dtype_tag=None):
+    files = sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if "digest_" not in os.path.basename(f))
+    if dtype_tag:
+        files = [f for f in files if f.endswith(f"_{dtype_tag}.npz")]
+    return files
+
+
+def digest_cases():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "digest_*.npz")))
+
+
+def case_id(path):
+    return os.path.basename(path)[:-4]
+
+
+def kink_mask(loc, shapes, align_corners, tol=1e-4):
+    """True where a sample's pixel-space x (resp. y) coordinate is within ``tol`` of an integer: there
+    the location gradient is discontinuous and float round-off legitimately picks either side.
+    Returns a bool array shaped like loc ([..., L, P, 2])."""
+    loc = np.asarray(loc, dtype=np.float64)
+    shapes = np.asarray(shapes)
+    L = shapes.shape[0]
+    size = np.stack([shapes[:, 1], shapes[:, 0]], -1).astype(np.float64)  # (w, h) per level -> x, y
+    size = size.reshape((1,) * (loc.ndim - 3) + (L, 1, 2))
+    pix = loc * (size - 1) if align_corners else loc * size - 0.5
+    return np.abs(pix - np.round(pix)) < tol
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import msda_oracle
+    msda_oracle.build()
+    return msda_oracle

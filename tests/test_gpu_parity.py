@@ -1,0 +1,470 @@
+"""GPU parity tests proper: the HIP path (through the C ABI in libmsda_hip.so) against the CPU
+oracle, the reference's golden vectors and size-independent properties.  Run with ``-m gpu``.
+
+Tolerances follow the reference's tests (/root/reference/tests/test_msda.py:15-27):
+fp32 fwd atol 1e-4 rtol 1e-3, bwd atol 1e-3 rtol 1e-2; fp64 1e-8; fp16 1e-1.  The north-star
+bar (1e-4 fp32 vs the native CPU fallback) is what the fp32 forward checks use.
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import MODES, case_id, digest_cases, golden_cases, kink_mask, mode_key
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+FWD_TOL = {torch.float32: dict(atol=1e-4, rtol=1e-3), torch.float64: dict(atol=1e-8, rtol=1e-8)}
+BWD_TOL = {torch.float32: dict(atol=1e-3, rtol=1e-2), torch.float64: dict(atol=1e-8, rtol=1e-8)}
+
+
+def _ops():
+    import msda_triton_amd
+    return msda_triton_amd
+
+
+def run_hip(value, shapes, loc, attn, grad_out, pm, ac, dtype=None, needs_grad=True):
+    """numpy in -> numpy out through the public API (autograd -> ctypes -> C ABI -> HIP)."""
+    ops = _ops()
+    td = dtype or torch.from_numpy(np.asarray(value)).dtype
+    v = torch.from_numpy(np.asarray(value)).to(DEV, td).requires_grad_(needs_grad)
+    l = torch.from_numpy(np.asarray(loc)).to(DEV, td).requires_grad_(needs_grad)
+    a = torch.from_numpy(np.asarray(attn)).to(DEV, td).requires_grad_(needs_grad)
+    s = torch.from_numpy(np.asarray(shapes)).to(DEV)
+    out = ops.multiscale_deformable_attention(v, s, l, a, pm, ac)
+    if not needs_grad:
+        return out.detach().float().cpu().numpy() if td in (torch.float16, torch.bfloat16) else out.detach().cpu().numpy()
+    out.backward(torch.from_numpy(np.asarray(grad_out)).to(DEV, td))
+    conv = (lambda t: t.detach().float().cpu().numpy()) if td in (torch.float16, torch.bfloat16) else (
+        lambda t: t.detach().cpu().numpy())
+    return conv(out), conv(v.grad), conv(l.grad), conv(a.grad)
+
+
+def rand_case(rng, B, Q, H, D, levels, P, lo=-0.3, hi=1.3, dtype=np.float32):
+    I = sum(h * w for h, w in levels)  # noqa: E741
+    L = len(levels)
+    return dict(
+        value=rng.standard_normal((B, I, H, D)).astype(dtype),
+        shapes=np.asarray(levels, dtype=np.int64),
+        loc=rng.uniform(lo, hi, size=(B, Q, H, L, P, 2)).astype(dtype),
+        attn=rng.uniform(0, 1, size=(B, Q, H, L, P)).astype(dtype),
+        grad_out=rng.uniform(0, 1, size=(B, Q, H, D)).astype(dtype),
+    )
+
+
+def check_against_oracle(oracle, c, pm, ac, fwd_tol, bwd_tol, mask_kinks=True):
+    out, gv, gl, ga = run_hip(c["value"], c["shapes"], c["loc"], c["attn"], c["grad_out"], pm, ac)
+    r_out = oracle.forward(c["value"], c["shapes"], c["loc"], c["attn"], pm, ac)
+    r_gv, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], pm, ac)
+    np.testing.assert_allclose(out, r_out, err_msg="out", **fwd_tol)
+    np.testing.assert_allclose(gv, r_gv, err_msg="grad_value", **bwd_tol)
+    np.testing.assert_allclose(ga, r_ga, err_msg="grad_attn", **bwd_tol)
+    if mask_kinks:
+        keep = ~kink_mask(c["loc"], c["shapes"], ac)
+        gl, r_gl = np.where(keep, gl, 0), np.where(keep, r_gl, 0)
+    np.testing.assert_allclose(gl, r_gl, err_msg="grad_loc", **bwd_tol)
+
+
+# ------------------------------------------------------------------------------------------
+# golden vectors produced by the reference itself
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", golden_cases(), ids=case_id)
+def test_hip_matches_reference_golden(path):
+    z = np.load(path)
+    td = torch.float32 if path.endswith("_f32.npz") else torch.float64
+    for pm, ac in MODES:
+        k = mode_key(pm, ac)
+        out, gv, gl, ga = run_hip(z["value"], z["shapes"], z["loc"], z["attn"], z["grad_out"], pm, ac)
+        np.testing.assert_allclose(out, z[f"out_{k}"], err_msg=f"out {k}", **FWD_TOL[td])
+        np.testing.assert_allclose(gv, z[f"grad_value_{k}"], err_msg=f"grad_value {k}", **BWD_TOL[td])
+        np.testing.assert_allclose(ga, z[f"grad_attn_{k}"], err_msg=f"grad_attn {k}", **BWD_TOL[td])
+        r_gl = z[f"grad_loc_{k}"]
+        if td == torch.float32:
+            keep = ~kink_mask(z["loc"], z["shapes"], ac)
+            gl, r_gl = np.where(keep, gl, 0), np.where(keep, r_gl, 0)
+        np.testing.assert_allclose(gl, r_gl, err_msg=f"grad_loc {k}", **BWD_TOL[td])
+
+
+@pytest.mark.parametrize("path", digest_cases(), ids=case_id)
+def test_hip_matches_reference_digest_fullsize(path):
+    from msda_triton_amd import synth
+    z = np.load(path)
+    wl = synth.WORKLOADS[str(z["workload"])]
+    d = synth.make_inputs_numpy(wl, seed=int(z["seed"]), loc_lo=float(z["loc_lo"]), loc_hi=float(z["loc_hi"]))
+    f32 = {k: (v if k == "shapes" else v.astype(np.float32)) for k, v in d.items()}
+    for pm, ac in MODES:
+        k = mode_key(pm, ac)
+        res = run_hip(f32["value"], f32["shapes"], f32["loc"], f32["attn"], f32["grad_out"], pm, ac)
+        for nm, arr in zip(("out", "grad_value", "grad_loc", "grad_attn"), res):
+            dg = synth.digest(arr)
+            np.testing.assert_allclose(dg["samples"], z[f"{nm}_{k}_samples"],
+                                       atol=2e-3 if nm == "grad_value" else 5e-4, rtol=1e-3, err_msg=f"{nm} {k}")
+            scale = max(1.0, float(z[f"{nm}_{k}_abs_sum"]))
+            assert abs(dg["sum"] - float(z[f"{nm}_{k}_sum"])) <= 1e-4 * scale, (nm, k)
+            assert abs(dg["abs_sum"] - float(z[f"{nm}_{k}_abs_sum"])) <= 1e-4 * scale, (nm, k)
+
+
+# ------------------------------------------------------------------------------------------
+# oracle on seeded random inputs: shape / dtype / mode matrix, incl. every kernel variant
+# ------------------------------------------------------------------------------------------
+SHAPE_MATRIX = {
+    # name: (B, Q, H, D, levels, P)
+    "d32_vec_g8": (2, 70, 8, 32, [(16, 16), (8, 8), (4, 4), (2, 2)], 4),
+    "d64_vec_g16": (1, 33, 4, 64, [(9, 7), (5, 4)], 3),
+    "d128_vec_g32": (1, 9, 2, 128, [(6, 6)], 2),
+    "d256_vec_g64": (1, 5, 1, 256, [(4, 5), (2, 3)], 2),
+    "d512_two_channel_chunks": (1, 3, 1, 512, [(3, 3)], 2),
+    "d8_vec_g4": (2, 19, 3, 8, [(7, 9), (3, 4)], 5),
+    "d5_scalar": (2, 13, 3, 5, [(6, 4), (3, 2), (2, 5)], 3),
+    "d36_scalar_g64": (1, 7, 2, 36, [(5, 5), (2, 2)], 2),
+    "d1": (1, 11, 2, 1, [(5, 6)], 3),
+    "pairs_not_multiple_of_8": (3, 21, 5, 16, [(8, 8), (4, 4)], 2),
+    "many_samples_chunked": (1, 6, 2, 8, [(6, 6), (3, 3), (2, 2), (1, 1), (4, 2), (2, 4), (5, 1), (1, 5)], 64),
+    "one_query": (1, 1, 1, 32, [(4, 4)], 1),
+    "big_level_pixel_ranges": (1, 50, 1, 3, [(210, 200), (10, 10)], 2),
+}
+
+
+@pytest.mark.parametrize("name", list(SHAPE_MATRIX), ids=list(SHAPE_MATRIX))
+@pytest.mark.parametrize("pm,ac", MODES, ids=[mode_key(*m) for m in MODES])
+def test_hip_vs_oracle_f32(oracle, name, pm, ac):
+    B, Q, H, D, levels, P = SHAPE_MATRIX[name]
+    c = rand_case(np.random.default_rng(zlib.crc32(name.encode())), B, Q, H, D, levels, P)
+    check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float32], BWD_TOL[torch.float32])
+
+
+@pytest.mark.parametrize("name", ["d32_vec_g8", "d5_scalar", "d8_vec_g4", "big_level_pixel_ranges", "d512_two_channel_chunks"])
+@pytest.mark.parametrize("pm,ac", MODES, ids=[mode_key(*m) for m in MODES])
+def test_hip_vs_oracle_f64(oracle, name, pm, ac):
+    B, Q, H, D, levels, P = SHAPE_MATRIX[name]
+    c = rand_case(np.random.default_rng(7), B, Q, H, D, levels, P, dtype=np.float64)
+    check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float64], BWD_TOL[torch.float64], mask_kinks=False)
+
+
+@pytest.mark.parametrize("td,atol,rtol", [(torch.float16, 2e-2, 2e-2), (torch.bfloat16, 1e-1, 5e-2)],
+                         ids=["fp16", "bf16"])
+@pytest.mark.parametrize("name", ["d32_vec_g8", "d64_vec_g16", "d5_scalar", "d8_vec_g4"])
+@pytest.mark.parametrize("pm,ac", [("zeros", False), ("border", True)], ids=["zeros_0", "border_1"])
+def test_hip_low_precision_vs_fp32_oracle_on_rounded_inputs(oracle, td, atol, rtol, name, pm, ac):
+    """fp16/bf16 oracle = fp32 math on inputs rounded to the low dtype; the reference's
+    own fp16 tolerance is (1e-1, 1e-1) (tests/test_msda.py:16-18)."""
+    B, Q, H, D, levels, P = SHAPE_MATRIX[name]
+    c = rand_case(np.random.default_rng(11), B, Q, H, D, levels, P, lo=-0.1, hi=1.1)
+    rounded = {k: (v if k == "shapes" else torch.from_numpy(v).to(td).float().numpy()) for k, v in c.items()}
+    out, gv, gl, ga = run_hip(rounded["value"], rounded["shapes"], rounded["loc"], rounded["attn"],
+                              rounded["grad_out"], pm, ac, dtype=td)
+    r_out = oracle.forward(rounded["value"], rounded["shapes"], rounded["loc"], rounded["attn"], pm, ac)
+    r_gv, r_gl, r_ga = oracle.backward(rounded["grad_out"], rounded["value"], rounded["shapes"], rounded["loc"],
+                                       rounded["attn"], pm, ac)
+    np.testing.assert_allclose(out, r_out, atol=atol, rtol=rtol, err_msg="out")
+    np.testing.assert_allclose(ga, r_ga, atol=atol * 4, rtol=rtol, err_msg="grad_attn")
+    np.testing.assert_allclose(gv, r_gv, atol=atol * 4, rtol=rtol, err_msg="grad_value")
+    keep = ~kink_mask(rounded["loc"], rounded["shapes"], ac, tol=2e-2)
+    scale = max(1.0, float(np.abs(r_gl).max()))
+    np.testing.assert_allclose(np.where(keep, gl, 0), np.where(keep, r_gl, 0), atol=atol * scale, rtol=rtol * 2,
+                               err_msg="grad_loc")
+
+
+def test_far_oob_and_nonfinite_free(oracle):
+    rng = np.random.default_rng(3)
+    c = rand_case(rng, 1, 40, 2, 32, [(8, 8), (3, 5)], 4, lo=-50.0, hi=50.0)
+    c["loc"].reshape(-1)[::9] = 1e30
+    c["loc"].reshape(-1)[1::13] = -1e30
+    for pm, ac in MODES:
+        check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float32], BWD_TOL[torch.float32])
+        out = run_hip(c["value"], c["shapes"], c["loc"], c["attn"], None, pm, ac, needs_grad=False)
+        assert np.isfinite(out).all()
+
+
+def test_zeros_padding_never_reads_masked_corners():
+    """tl.where semantics (kernels.py:220-231): a masked corner contributes exactly 0 even when the
+    clamped pixel it would alias holds nan (a weight-zero multiply would give nan)."""
+    ops = _ops()
+    shapes = torch.tensor([(4, 4)], device=DEV)
+    att = torch.ones(1, 2, 1, 1, 1, device=DEV, requires_grad=True)
+    value = torch.full((1, 16, 1, 32), float("nan"), device=DEV)
+    value[:, 15] = 3.0
+    # align_corners=True on 4x4: loc 1.2 -> pixel coordinate 3.6 (x0 = 3 valid, x1 = 4 masked)
+    #   query 0: (3.6, 3.6): only corner (3,3) is valid, weight 0.4*0.4
+    #   query 1: (3.6, 9.0): every corner is masked (y0 = 9) but all of them clamp onto nan pixels' row 3
+    loc = torch.tensor([[1.2, 1.2], [1.2, 3.0]], device=DEV).reshape(1, 2, 1, 1, 1, 2).requires_grad_(True)
+    out = ops.multiscale_deformable_attention(value, shapes, loc, att, "zeros", True)
+    assert torch.allclose(out[0, 0], torch.full_like(out[0, 0], 3.0 * 0.16), atol=1e-6)
+    assert torch.count_nonzero(out[0, 1]) == 0 and torch.isfinite(out).all()
+    value[:, 15] = float("nan")
+    value[:, 11] = float("nan")
+    out = ops.multiscale_deformable_attention(value, shapes, loc[:, 1:], att[:, 1:], "zeros", True)
+    assert torch.count_nonzero(out) == 0
+    out.sum().backward()
+    assert torch.count_nonzero(loc.grad[:, 1]) == 0 and torch.count_nonzero(att.grad[:, 1]) == 0
+
+
+# ------------------------------------------------------------------------------------------
+# properties at BASELINE.json's full sizes
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wl_name", ["c2_q10k", "c4_gdino_dec"])
+def test_fullsize_properties(wl_name):
+    """Linearity in value and in the attention weights, query-permutation equivariance, and
+    sum(grad_value) == sum_q attn-weighted grad_out mass (border mode: bilinear weights sum to 1)."""
+    from msda_triton_amd import synth
+    ops = _ops()
+    wl = synth.WORKLOADS[wl_name]
+    d = synth.make_inputs_torch(wl, DEV, seed=0)
+    v, s, l, a, g = d["value"], d["shapes"], d["loc"], d["attn"], d["grad_out"]
+    pm, ac = wl.padding_mode, wl.align_corners
+    f = lambda vv, aa, ll=l: ops.multiscale_deformable_attention(vv, s, ll, aa, pm, ac)  # noqa: E731
+    out = f(v, a)
+    assert out.shape == (wl.B, wl.Q, wl.H, wl.D) and torch.isfinite(out).all()
+    v2 = torch.randn_like(v)
+    torch.testing.assert_close(f(v + 2 * v2, a), out + 2 * f(v2, a), atol=2e-4, rtol=1e-4)
+    torch.testing.assert_close(f(v, 3 * a), 3 * out, atol=2e-4, rtol=1e-4)
+    perm = torch.randperm(wl.Q, device=DEV)
+    torch.testing.assert_close(f(v, a[:, perm], l[:, perm]), out[:, perm], atol=0, rtol=0)
+    # mass conservation of the scatter in border mode (every sample's 4 weights sum to 1)
+    vb = v.clone().requires_grad_(True)
+    ob = ops.multiscale_deformable_attention(vb, s, l, a, "border", True)
+    ob.backward(g)
+    expect = torch.einsum("bqhd,bqh->bhd", g.double(), a.double().sum((-1, -2)))
+    got = vb.grad.double().sum(1)
+    torch.testing.assert_close(got, expect, atol=1e-2, rtol=1e-4)
+
+
+def test_c3_encoder_shape_bf16_and_c5_slice_fp16(oracle):
+    """BASELINE configs[2] at full size in bf16 and a query slice of configs[4] in fp16, each against
+    the fp32 oracle on a strided subset of queries."""
+    from msda_triton_amd import synth
+    ops = _ops()
+    for wl_name, q_take, td, atol in (("c3_ddetr_enc", 17821, torch.bfloat16, 6e-2), ("c5_stress", 2000, torch.float16, 2e-2)):
+        wl = synth.WORKLOADS[wl_name]
+        d = synth.make_inputs_torch(wl, "cpu", seed=0, q_end=q_take, loc_lo=-0.05, loc_hi=1.05)
+        dd = {k: t.to(DEV) for k, t in d.items()}
+        out = ops.multiscale_deformable_attention(dd["value"], dd["shapes"], dd["loc"], dd["attn"],
+                                                  wl.padding_mode, wl.align_corners)
+        sel = slice(0, q_take, max(1, q_take // 64))
+        r = oracle.forward(d["value"].float().numpy(), d["shapes"].numpy(), d["loc"][:, sel].float().numpy(),
+                           d["attn"][:, sel].float().numpy(), wl.padding_mode, wl.align_corners)
+        np.testing.assert_allclose(out[:, sel].float().cpu().numpy(), r, atol=atol, rtol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------
+# API behaviour on the GPU
+# ------------------------------------------------------------------------------------------
+def test_gradcheck_fp64():
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    levels = [(5, 4), (3, 2)]
+    c = rand_case(rng, 1, 3, 2, 4, levels, 2, lo=-0.4, hi=1.4, dtype=np.float64)
+    # keep samples away from the pixel-grid kinks so finite differences are valid
+    shapes = torch.tensor(levels, device=DEV)
+    for pm, ac in MODES:
+        k = kink_mask(c["loc"], c["shapes"], ac, tol=5e-3)
+        loc = np.where(k, c["loc"] + 0.031, c["loc"])
+        v = torch.from_numpy(c["value"]).to(DEV).requires_grad_(True)
+        l = torch.from_numpy(loc).to(DEV).requires_grad_(True)
+        a = torch.from_numpy(c["attn"]).to(DEV).requires_grad_(True)
+        assert torch.autograd.gradcheck(
+            lambda vv, ll, aa: ops.multiscale_deformable_attention(vv, shapes, ll, aa, pm, ac),
+            (v, l, a), eps=1e-6, atol=1e-5, rtol=1e-4, nondet_tol=1e-12)
+
+
+def test_noncontiguous_inputs_and_int32_shapes(oracle):
+    ops = _ops()
+    rng = np.random.default_rng(9)
+    c = rand_case(rng, 2, 17, 4, 32, [(6, 6), (3, 3)], 2)
+    v = torch.from_numpy(c["value"]).to(DEV).permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)  # dense, permuted
+    l = torch.from_numpy(c["loc"]).to(DEV)
+    l_big = torch.zeros(2, 17, 4, 2, 2, 4, device=DEV)
+    l_big[..., :2] = l
+    a = torch.from_numpy(c["attn"]).to(DEV)
+    s32 = torch.from_numpy(c["shapes"]).to(DEV, torch.int32)
+    assert not v.is_contiguous() and not l_big[..., :2].is_contiguous()
+    v.requires_grad_(True)
+    out = ops.multiscale_deformable_attention(v, s32, l_big[..., :2], a, "zeros", False)
+    out.backward(torch.from_numpy(c["grad_out"]).to(DEV))
+    r = oracle.forward(c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
+    r_gv, _, _ = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), r, **FWD_TOL[torch.float32])
+    np.testing.assert_allclose(v.grad.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
+
+
+def test_unaligned_views_take_the_scalar_path(oracle):
+    """A storage offset that breaks 16-byte alignment must still give right answers."""
+    ops = _ops()
+    rng = np.random.default_rng(10)
+    c = rand_case(rng, 1, 9, 2, 32, [(4, 4)], 2)
+    flat = torch.zeros(c["value"].size + 1, device=DEV)
+    flat[1:] = torch.from_numpy(c["value"]).to(DEV).reshape(-1)
+    v = flat[1:].reshape(c["value"].shape)  # contiguous but only 4-byte aligned
+    assert v.data_ptr() % 16 != 0 and v.is_contiguous()
+    out = ops.multiscale_deformable_attention(v, torch.from_numpy(c["shapes"]).to(DEV), torch.from_numpy(c["loc"]).to(DEV),
+                                              torch.from_numpy(c["attn"]).to(DEV), "border", False)
+    r = oracle.forward(c["value"], c["shapes"], c["loc"], c["attn"], "border", False)
+    np.testing.assert_allclose(out.cpu().numpy(), r, **FWD_TOL[torch.float32])
+
+
+def test_partial_needs_input_grad(oracle):
+    ops = _ops()
+    c = rand_case(np.random.default_rng(12), 1, 10, 2, 32, [(5, 5)], 3)
+    s = torch.from_numpy(c["shapes"]).to(DEV)
+    g = torch.from_numpy(c["grad_out"]).to(DEV)
+    r_gv, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", True)
+    for which in ((True, False, False), (False, True, False), (False, False, True), (False, True, True)):
+        v, l, a = (torch.from_numpy(c[k]).to(DEV).requires_grad_(w) for k, w in zip(("value", "loc", "attn"), which))
+        ops.multiscale_deformable_attention(v, s, l, a, "zeros", True).backward(g)
+        for t, w, r in ((v, which[0], r_gv), (l, which[1], r_gl), (a, which[2], r_ga)):
+            assert (t.grad is not None) == w
+            if w:
+                np.testing.assert_allclose(t.grad.cpu().numpy(), r, **BWD_TOL[torch.float32])
+
+
+def test_forward_is_bitwise_deterministic_and_backward_stable():
+    from msda_triton_amd import synth
+    ops = _ops()
+    d = synth.make_inputs_torch(synth.WORKLOADS["c1_readme"], DEV, seed=3)
+    outs, gvs, gls = [], [], []
+    for _ in range(2):
+        v, l, a = (d[k].clone().requires_grad_(True) for k in ("value", "loc", "attn"))
+        o = ops.multiscale_deformable_attention(v, d["shapes"], l, a, "zeros", False)
+        o.backward(d["grad_out"])
+        outs.append(o.detach()); gvs.append(v.grad); gls.append((l.grad, a.grad))
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(gls[0][0], gls[1][0]) and torch.equal(gls[0][1], gls[1][1])  # private per sample: exact
+    torch.testing.assert_close(gvs[0], gvs[1], atol=1e-4, rtol=1e-4)  # LDS float adds: order may vary
+
+
+def test_xcd_map_on_off_same_results():
+    from msda_triton_amd import _lib, synth
+    ops = _ops()
+    d = synth.make_inputs_torch(synth.WORKLOADS["c1_readme"], DEV, seed=4)
+    res = []
+    try:
+        for flag in (1, 0):
+            _lib.set_option("xcd_map", flag)
+            v = d["value"].clone().requires_grad_(True)
+            o = ops.multiscale_deformable_attention(v, d["shapes"], d["loc"], d["attn"], "border", True)
+            o.backward(d["grad_out"])
+            res.append((o.detach(), v.grad))
+    finally:
+        _lib.set_option("xcd_map", 1)
+    assert torch.equal(res[0][0], res[1][0])
+    torch.testing.assert_close(res[0][1], res[1][1], atol=1e-4, rtol=1e-4)
+
+
+def test_empty_and_degenerate_inputs():
+    ops = _ops()
+    s = torch.tensor([[3, 3]], device=DEV)
+    v = torch.randn(2, 9, 2, 8, device=DEV, requires_grad=True)
+    out = ops.multiscale_deformable_attention(v, s, torch.rand(2, 0, 2, 1, 2, 2, device=DEV),
+                                              torch.rand(2, 0, 2, 1, 2, device=DEV), "zeros", False)
+    assert out.shape == (2, 0, 2, 8)
+    out.sum().backward()
+    assert torch.count_nonzero(v.grad) == 0
+    # zero points per level: empty sum -> zeros
+    out = ops.multiscale_deformable_attention(v.detach(), s, torch.rand(2, 5, 2, 1, 0, 2, device=DEV),
+                                              torch.rand(2, 5, 2, 1, 0, device=DEV), "border", True)
+    assert out.shape == (2, 5, 2, 8) and torch.count_nonzero(out) == 0
+
+
+def test_errors_match_reference_contract():
+    ops = _ops()
+    s = torch.tensor([[2, 2]], device=DEV)
+    v = torch.randn(1, 4, 1, 4, device=DEV)
+    l = torch.rand(1, 1, 1, 1, 1, 2, device=DEV)
+    a = torch.rand(1, 1, 1, 1, 1, device=DEV)
+    with pytest.raises(ValueError):  # unsupported dtype (frontend.py:84-90)
+        ops.hip_multiscale_deformable_attention(v.to(torch.int32), s, l, a, "zeros", False)
+    with pytest.raises(ValueError):  # inputs not on the gpu (frontend.py:93-95)
+        ops.hip_multiscale_deformable_attention(v.cpu(), s, l, a, "zeros", False)
+    with pytest.raises(ValueError):  # shapes tensor on the host while the rest is on the gpu
+        ops.multiscale_deformable_attention(v, s.cpu(), l, a, "zeros", False)
+    with pytest.raises(ValueError):
+        ops.multiscale_deformable_attention(v, s, l, a, "reflection", False)
+    with pytest.raises(ValueError):  # mixed dtypes
+        ops.multiscale_deformable_attention(v, s, l.double(), a, "zeros", False)
+    with pytest.raises(ValueError):  # too many levels for the C ABI (MSDA_ERR_TOO_MANY_LEVELS)
+        L = 33
+        ops.multiscale_deformable_attention(torch.randn(1, L, 1, 4, device=DEV), torch.ones(L, 2, dtype=torch.int64, device=DEV),
+                                            torch.rand(1, 1, 1, L, 1, 2, device=DEV), torch.rand(1, 1, 1, L, 1, device=DEV),
+                                            "zeros", False)
+
+
+@pytest.mark.parametrize("td", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_autocast_runs_in_fp32(td):
+    """Reference: custom_fwd(cast_inputs=float32) (frontend.py:111) and tests/test_msda.py:171-182."""
+    ops = _ops()
+    c = rand_case(np.random.default_rng(2), 1, 12, 2, 32, [(4, 4), (2, 2)], 2)
+    v, l, a = (torch.from_numpy(c[k]).to(DEV, torch.float16) for k in ("value", "loc", "attn"))
+    s = torch.from_numpy(c["shapes"]).to(DEV)
+    with torch.amp.autocast(device_type="cuda", dtype=td):
+        out = ops.multiscale_deformable_attention(v, s, l, a, "zeros", False)
+    assert out.dtype == torch.float32
+    ref = ops.multiscale_deformable_attention(v.float(), s, l.float(), a.float(), "zeros", False)
+    torch.testing.assert_close(out, ref, atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("coords", [2, 4])
+def test_module_gpu_matches_cpu_native(coords):
+    """Reference smoke test tests/test_msda.py:154-168, plus a numeric check against the host path."""
+    ops = _ops()
+    torch.manual_seed(0)
+    emb, heads, levels, points = 256, 8, 4, 8
+    shapes = [(64 // 2**i, 64 // 2**i) for i in range(levels)]
+    I = sum(h * w for h, w in shapes)  # noqa: E741
+    m = ops.MultiscaleDeformableAttention(emb, emb // heads, levels, heads, points, "border", True)
+    img, q, ref = torch.randn(2, I, emb), torch.randn(2, 100, emb), torch.randn(2, 100, coords)
+    s = torch.tensor(shapes)
+    out_cpu = m(img, s, q, ref)
+    m_gpu = m.to(DEV)
+    out_gpu = m_gpu(img.to(DEV), s.to(DEV), q.to(DEV), ref.to(DEV))
+    assert out_gpu.shape == (2, 100, emb)
+    torch.testing.assert_close(out_gpu.cpu(), out_cpu, atol=2e-3, rtol=1e-3)
+    out_gpu.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m_gpu.parameters())
+
+
+def test_reference_import_path_shim_on_gpu():
+    import msda_triton
+    from msda_triton.frontend import triton_multiscale_deformable_attention
+    s = torch.tensor([[4, 4]], device=DEV)
+    v = torch.randn(1, 16, 2, 32, device=DEV)
+    l = torch.rand(1, 3, 2, 1, 2, 2, device=DEV)
+    a = torch.rand(1, 3, 2, 1, 2, device=DEV)
+    o1 = msda_triton.multiscale_deformable_attention(v, s, l, a, "zeros", False)
+    o2 = triton_multiscale_deformable_attention(v, s, l, a, "zeros", False)
+    assert torch.equal(o1, o2)
+
+
+def test_native_library_is_loaded_in_process():
+    """The HIP path must be the one that ran: libmsda_hip.so is mapped into this process."""
+    from msda_triton_amd import _lib
+    _lib.load()
+    with open("/proc/self/maps") as f:
+        assert _lib.LIB_NAME in f.read()
+
+
+def test_graph_capture_replays():
+    """No allocation / sync inside the C ABI calls: a fwd+bwd pair captures into a hipGraph."""
+    ops = _ops()
+    c = rand_case(np.random.default_rng(21), 2, 64, 8, 32, [(8, 8), (4, 4)], 4)
+    v, l, a, g = (torch.from_numpy(c[k]).to(DEV) for k in ("value", "loc", "attn", "grad_out"))
+    s = torch.from_numpy(c["shapes"]).to(DEV)
+    eager = ops.msda_hip_fwd(v, s, l, a, "zeros", False)
+    eager_g = ops.msda_hip_bwd(g, v, s, l, a, "zeros", False)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.msda_hip_fwd(v, s, l, a, "zeros", False)  # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = ops.msda_hip_fwd(v, s, l, a, "zeros", False)
+        grads = ops.msda_hip_bwd(g, v, s, l, a, "zeros", False)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    torch.testing.assert_close(grads[0], eager_g[0], atol=1e-4, rtol=1e-4)
+    assert torch.equal(grads[1], eager_g[1]) and torch.equal(grads[2], eager_g[2])
