@@ -293,6 +293,7 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
 // stores; every element of grad_value is written exactly once, so no memset is needed either.
 // ==========================================================================================
 constexpr int kValueBlock = 1024;
+using TileAcc = double;
 
 template <typename T, int CH>
 __global__ __launch_bounds__(kValueBlock) void msda_bwd_value_kernel(const Params p)
@@ -310,11 +311,15 @@ __global__ __launch_bounds__(kValueBlock) void msda_bwd_value_kernel(const Param
     if (npx <= 0) return;
 
     LevelTab *tab = reinterpret_cast<LevelTab *>(msda_smem);
-    A *s_acc = reinterpret_cast<A *>(msda_smem + sizeof(LevelTab));
+    // Tile sums are double whatever the storage type: on gfx950 ds_add_f64 retires a wave-instruction
+    // in ~21 cycles while ds_add_f32 takes ~193 (measured, tools/lds_atomic_bench.hip) — and the
+    // wider sums make the scatter order irrelevant at fp32 output precision.  Layout [CH][npx]
+    // (channel-major) spreads a wave's pixels over all LDS banks.
+    TileAcc *s_acc = reinterpret_cast<TileAcc *>(msda_smem + sizeof(LevelTab));
 
     load_level_table(tab, p.shapes, p.L);
     const int tid = threadIdx.x;
-    for (int i = tid; i < npx * CH; i += kValueBlock) s_acc[i] = (A)0;
+    for (int i = tid; i < npx * CH; i += kValueBlock) s_acc[i] = (TileAcc)0;
     __syncthreads();
 
     // levels intersecting [p0, p1) form an interval [la, lb)
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(kValueBlock) void msda_bwd_value_kernel(const Param
                 const uint32_t rel = t.off[k] - (uint32_t)p0;  // masked / out-of-range wrap to huge values
                 if (rel < (uint32_t)npx) {
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) atomicAdd(&s_acc[rel * CH + c], w[k] * g[c]);
+                    for (int c = 0; c < CH; ++c) atomicAdd(&s_acc[c * npx + rel], (TileAcc)(w[k] * g[c]));
                 }
             }
             q += dq;
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(kValueBlock) void msda_bwd_value_kernel(const Param
     for (int i = tid; i < npx; i += kValueBlock) {
         Pack<T, CH> o;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) o.v[c] = TR::from_acc(s_acc[i * CH + c]);
+        for (int c = 0; c < CH; ++c) o.v[c] = TR::from_acc((A)s_acc[c * npx + i]);
         *reinterpret_cast<Pack<T, CH> *>(gv + (size_t)(p0 + i) * p.H * p.D) = o;
     }
 }

@@ -120,8 +120,7 @@ template <typename T, bool BWD> inline int dispatch_gather(Params &p, bool vec_o
 
 template <typename T, int CH> inline int launch_value(Params &p, hipStream_t stream)
 {
-    using A = typename Traits<T>::acc;
-    const size_t px_bytes = (size_t)CH * sizeof(A);
+    const size_t px_bytes = (size_t)CH * sizeof(TileAcc);
     const size_t room = kValueLdsBudget - sizeof(LevelTab);
     p.nchunks = p.D / CH;
     p.nranges = (int)(((size_t)p.I * px_bytes + room - 1) / room);
@@ -145,11 +144,10 @@ template <typename T, int CH> inline int launch_value(Params &p, hipStream_t str
 
 template <typename T> inline int dispatch_value(Params &p, hipStream_t stream)
 {
-    using A = typename Traits<T>::acc;
     const size_t room = kValueLdsBudget - sizeof(LevelTab);
     auto fits = [&](int ch) {
         return (p.D % ch) == 0 && aligned_to(p.grad_out, ch * sizeof(T)) && aligned_to(p.grad_value, ch * sizeof(T)) &&
-               (size_t)p.I * ch * sizeof(A) <= room;
+               (size_t)p.I * ch * sizeof(TileAcc) <= room;
     };
     if (fits(4)) return launch_value<T, 4>(p, stream);
     if (fits(2)) return launch_value<T, 2>(p, stream);

@@ -67,6 +67,45 @@ def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class KernelTimer:
+    """Per-kernel HIP-event timing for measurements (``bench.py``).
+
+    While active (``with KernelTimer() as kt:``) every launcher brackets each kernel launch with
+    events recorded on the stream the kernel is launched on, and the backward is issued as two C-ABI
+    calls so its two kernels are timed separately.  ``kt.summary()`` (after a device sync) gives
+    ``{kernel: (launches, mean_ms)}``.  Off by default: zero cost on the normal path.
+    """
+
+    active: Optional["KernelTimer"] = None
+
+    def __init__(self):
+        self.records = []  # (name, start_event, end_event)
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+        return False
+
+    def launch(self, name: str, device: torch.device, call):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        stream = torch.cuda.current_stream(device)
+        start.record(stream)
+        rc = call()
+        end.record(stream)
+        self.records.append((name, start, end))
+        return rc
+
+    def summary(self):
+        acc = {}
+        for name, start, end in self.records:
+            n, total = acc.get(name, (0, 0.0))
+            acc[name] = (n + 1, total + start.elapsed_time(end))
+        return {k: (n, total / n) for k, (n, total) in acc.items()}
+
+
 # ------------------------------------------------------------------------------------------
 # launcher pair — the native seam (reference: kernels.py:351-379, 556-592)
 # ------------------------------------------------------------------------------------------
@@ -79,10 +118,15 @@ def msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mo
     shapes = _shapes_i64(img_shapes)
     out = torch.empty((B, Q, H, D), dtype=img.dtype, device=img.device)
     lib = _lib.load()
+    fn = getattr(lib, f"msda_fwd_{suf}")
+
+    def call():
+        return fn(img.data_ptr(), shapes.data_ptr(), sampling_points.data_ptr(), attention_weights.data_ptr(),
+                  out.data_ptr(), B, I, H, D, Q, L, P, pad, int(bool(align_corners)), _stream_ptr(img.device))
+
     with torch.cuda.device(img.device):
-        rc = getattr(lib, f"msda_fwd_{suf}")(
-            img.data_ptr(), shapes.data_ptr(), sampling_points.data_ptr(), attention_weights.data_ptr(),
-            out.data_ptr(), B, I, H, D, Q, L, P, pad, int(bool(align_corners)), _stream_ptr(img.device))
+        timer = KernelTimer.active
+        rc = timer.launch("msda_fwd", img.device, call) if timer else call()
     _lib.check(rc, f"msda_fwd_{suf}")
     return out
 
@@ -112,14 +156,26 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
     g_att = torch.empty((B, Q, H, L, P), **kw) if want_sample else None
     if want_value or want_sample:
         lib = _lib.load()
+        fn = getattr(lib, f"msda_bwd_{suf}")
+
+        def call(value_part: bool, sample_part: bool):
+            return fn(out_grad.data_ptr(), img.data_ptr(), shapes.data_ptr(), sampling_points.data_ptr(),
+                      attention_weights.data_ptr(),
+                      g_img.data_ptr() if value_part else None,
+                      g_pts.data_ptr() if sample_part else None,
+                      g_att.data_ptr() if sample_part else None,
+                      B, I, H, D, Q, L, P, pad, int(bool(align_corners)), _stream_ptr(img.device))
+
         with torch.cuda.device(img.device):
-            rc = getattr(lib, f"msda_bwd_{suf}")(
-                out_grad.data_ptr(), img.data_ptr(), shapes.data_ptr(), sampling_points.data_ptr(),
-                attention_weights.data_ptr(),
-                g_img.data_ptr() if want_value else None,
-                g_pts.data_ptr() if want_sample else None,
-                g_att.data_ptr() if want_sample else None,
-                B, I, H, D, Q, L, P, pad, int(bool(align_corners)), _stream_ptr(img.device))
+            timer = KernelTimer.active
+            if timer is None:
+                rc = call(want_value, want_sample)
+            else:  # one C-ABI call per kernel so each gets its own event pair
+                rc = 0
+                if want_sample:
+                    rc = timer.launch("msda_bwd_sample", img.device, lambda: call(False, True))
+                if rc == 0 and want_value:
+                    rc = timer.launch("msda_bwd_value", img.device, lambda: call(True, False))
         _lib.check(rc, f"msda_bwd_{suf}")
     return g_img, (g_pts if needs[1] else None), (g_att if needs[2] else None)
 
