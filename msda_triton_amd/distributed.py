@@ -67,7 +67,7 @@ class _GatherQueryShards(Function):
         if ctx.grad_sync == "reduce_scatter":
             shards = grad_full.reshape(B, world, per, H, D).permute(1, 0, 2, 3, 4).contiguous()
             mine = torch.empty_like(shards[0])
-            dist.reduce_scatter_tensor(mine, shards, group=ctx.group)
+            dist.reduce_scatter_tensor(mine, shards.reshape(world * B, per, H, D), group=ctx.group)
         else:
             mine = grad_full[:, ctx.rank * per:(ctx.rank + 1) * per].contiguous()
         return mine, None, None, None

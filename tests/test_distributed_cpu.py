@@ -1,0 +1,75 @@
+"""CPU-only, world_size 2 over gloo: the query-shard path (all-gather forward, all-reduce of
+grad_value) equals the unsharded operator."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q_total, sharded_inputs, grad_sync, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from msda_triton_amd import multiscale_deformable_attention, synth
+        from msda_triton_amd.distributed import shard_bounds, sharded_multiscale_deformable_attention
+        wl = synth.Workload("t", 2, q_total, 3, 8, ((6, 5), (3, 3)), 2, "float64", "zeros", False)
+        d = synth.make_inputs_torch(wl, "cpu", seed=2, loc_lo=-0.2, loc_hi=1.2)
+        v = d["value"].clone().requires_grad_(True)
+        l = d["loc"].clone().requires_grad_(True)
+        a = d["attn"].clone().requires_grad_(True)
+        b, e = shard_bounds(q_total, world, rank)
+        if sharded_inputs:
+            l_in = d["loc"][:, b:e].clone().requires_grad_(True)
+            a_in = d["attn"][:, b:e].clone().requires_grad_(True)
+            out = sharded_multiscale_deformable_attention(v, d["shapes"], l_in, a_in, "zeros", False,
+                                                          inputs_are_sharded=True, num_queries=q_total, grad_sync=grad_sync)
+        else:
+            l_in, a_in = l, a
+            out = sharded_multiscale_deformable_attention(v, d["shapes"], l_in, a_in, "zeros", False, grad_sync=grad_sync)
+        g = d["grad_out"] if grad_sync == "slice" else d["grad_out"] / world  # reduce_scatter sums the replicas
+        out.backward(g)
+        # unsharded reference on the same inputs
+        v2, l2, a2 = (t.detach().clone().requires_grad_(True) for t in (d["value"], d["loc"], d["attn"]))
+        ref = multiscale_deformable_attention(v2, d["shapes"], l2, a2, "zeros", False)
+        ref.backward(d["grad_out"])
+        ok = torch.allclose(out, ref, atol=1e-12)
+        ok &= torch.allclose(v.grad, v2.grad, atol=1e-10)
+        lg = l_in.grad if sharded_inputs else l_in.grad[:, b:e]
+        ag = a_in.grad if sharded_inputs else a_in.grad[:, b:e]
+        ok &= torch.allclose(lg, l2.grad[:, b:e], atol=1e-10) and torch.allclose(ag, a2.grad[:, b:e], atol=1e-10)
+        if not sharded_inputs:  # gradients outside this rank's shard stay zero
+            mask = torch.ones(q_total, dtype=torch.bool)
+            mask[b:e] = False
+            ok &= float(l_in.grad[:, mask].abs().sum()) == 0.0
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("q_total,sharded_inputs,grad_sync", [(10, False, "slice"), (9, True, "slice"), (8, False, "reduce_scatter")])
+def test_query_shard_gloo_world2(q_total, sharded_inputs, grad_sync):
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), q_total, sharded_inputs, grad_sync, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_shard_bounds_cover_and_partition():
+    from msda_triton_amd.distributed import shard_bounds
+    for q in (0, 1, 7, 8, 9, 900, 10000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(q, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == q
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert len({e - b for b, e in spans if e - b == -(-q // world)}) <= 1

@@ -1,0 +1,165 @@
+"""CPU-only: the host-side mirror of the reference interface, the synthetic-workload generator and
+the C-ABI library's export table (no compute calls into the library without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import MODES, ROOT, case_id, golden_cases, mode_key
+
+
+# ---------------------------------------------------------------- C ABI -----------------------
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "msda_hip.h")).read()
+    names = set(re.findall(r"MSDA_API\s+(?:const\s+)?\w+\s*\*?\s*(msda_\w+)\s*\(", text))
+    names = {n for n in names if "##" not in n}
+    for suf in re.findall(r"MSDA_DECLARE\((\w+)\)", text):
+        if suf != "SUF":
+            names |= {f"msda_fwd_{suf}", f"msda_bwd_{suf}"}
+    return names
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from msda_triton_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert _lib.load().msda_abi_version() == _lib.ABI_VERSION
+    # argument validation happens before anything touches a device
+    assert _lib.load().msda_set_option(b"no_such_option", 1) < 0
+    assert b"no_such_option" in _lib.load().msda_last_error()
+    assert _lib.get_option("xcd_map") in (0, 1)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from msda_triton_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libmsda_hip.so"))
+    with pytest.raises(_lib.MSDALibraryError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "msda_triton_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "msda_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+# ---------------------------------------------------------------- functional API --------------
+@pytest.mark.parametrize("path", golden_cases(), ids=case_id)
+def test_native_host_path_matches_reference_golden(path):
+    from msda_triton_amd import multiscale_deformable_attention
+    z = np.load(path)
+    f64 = path.endswith("_f64.npz")
+    tol = dict(atol=1e-10, rtol=1e-9) if f64 else dict(atol=2e-5, rtol=1e-4)
+    for pm, ac in MODES:
+        k = mode_key(pm, ac)
+        v = torch.from_numpy(z["value"]).requires_grad_(True)
+        l = torch.from_numpy(z["loc"]).requires_grad_(True)
+        a = torch.from_numpy(z["attn"]).requires_grad_(True)
+        out = multiscale_deformable_attention(v, torch.from_numpy(z["shapes"]), l, a, pm, ac)  # CPU tensors -> native
+        np.testing.assert_allclose(out.detach().numpy(), z[f"out_{k}"], **tol)
+        if f64:  # float32 kinks are covered by the oracle tests
+            out.backward(torch.from_numpy(z["grad_out"]))
+            np.testing.assert_allclose(v.grad.numpy(), z[f"grad_value_{k}"], **tol)
+            np.testing.assert_allclose(l.grad.numpy(), z[f"grad_loc_{k}"], **tol)
+            np.testing.assert_allclose(a.grad.numpy(), z[f"grad_attn_{k}"], **tol)
+
+
+def test_readme_functional_example_on_cpu():
+    """/root/reference/README.md:121-147 with device='cpu', through the reference's import path."""
+    from msda_triton import multiscale_deformable_attention
+    batch, head_dim, num_queries, num_heads, num_points = 2, 32, 900, 8, 4
+    img_shapes = [(64, 64), (32, 32), (16, 16), (8, 8)]
+    num_pixels = sum(h * w for h, w in img_shapes)
+    img = torch.randn(batch, num_pixels, num_heads, head_dim)
+    out = multiscale_deformable_attention(
+        img, torch.tensor(img_shapes), torch.rand(batch, num_queries, num_heads, len(img_shapes), num_points, 2),
+        torch.rand(batch, num_queries, num_heads, len(img_shapes), num_points), "zeros", False)
+    assert out.shape == (batch, num_queries, num_heads, head_dim)
+
+
+def test_gpu_entry_point_rejects_host_tensors_and_bad_dtypes():
+    from msda_triton.frontend import triton_multiscale_deformable_attention as gpu_only
+    from msda_triton_amd import multiscale_deformable_attention
+    v, s = torch.randn(1, 4, 1, 4), torch.tensor([[2, 2]])
+    l, a = torch.rand(1, 1, 1, 1, 1, 2), torch.rand(1, 1, 1, 1, 1)
+    with pytest.raises(ValueError, match="gpu"):
+        gpu_only(v, s, l, a, "zeros", False)
+    with pytest.raises(ValueError, match="Dtype"):
+        gpu_only(v.to(torch.int32), s, l, a, "zeros", False)
+    with pytest.raises(ValueError, match="padding_mode"):
+        multiscale_deformable_attention(v, s, l, a, "reflection", False)
+    with pytest.raises(ValueError):
+        multiscale_deformable_attention(v, torch.tensor([[2, 2], [1, 1]]), l, a, "zeros", False)
+
+
+def test_shim_exposes_reference_names():
+    import msda_triton
+    import msda_triton.frontend as fe
+    import msda_triton.kernels as ke
+    assert set(msda_triton.__all__) == {"multiscale_deformable_attention", "MultiscaleDeformableAttention"}
+    for name in ("triton_multiscale_deformable_attention", "native_multiscale_deformable_attention",
+                 "MultiscaleDeformableAttention", "multiscale_deformable_attention"):
+        assert hasattr(fe, name)
+    for name in ("triton_multi_scale_deformable_attention_fwd", "triton_multi_scale_deformable_attention_bwd"):
+        assert hasattr(ke, name)
+
+
+# ---------------------------------------------------------------- nn.Module -------------------
+@pytest.mark.parametrize("coords", [2, 4])
+def test_module_cpu(coords):
+    """Reference smoke test tests/test_msda.py:154-168 (cpu leg) + state-dict contract."""
+    from msda_triton_amd import MultiscaleDeformableAttention
+    channels, heads, levels, points = 64, 8, 4, 8
+    shapes = [(16 // 2**i, 16 // 2**i) for i in range(levels)]
+    I = sum(h * w for h, w in shapes)  # noqa: E741
+    m = MultiscaleDeformableAttention(channels, channels // heads * heads, levels, heads, points, "border", True)
+    assert set(m.state_dict()) == {f"{n}.{p}" for n in ("img_input_proj", "query_input_proj", "query_output_proj")
+                                   for p in ("weight", "bias")}
+    assert m.query_input_proj.weight.shape == (heads * levels * points * 3, channels)
+    out = m(torch.randn(2, I, channels), torch.tensor(shapes), torch.randn(2, 10, channels), torch.randn(2, 10, coords))
+    assert out.shape == (2, 10, channels) and torch.isfinite(out).all()
+    out.sum().backward()
+    assert all(p.grad is not None for p in m.parameters())
+
+
+def test_module_errors_and_q6_normaliser_order():
+    from msda_triton_amd import MultiscaleDeformableAttention
+    with pytest.raises(ValueError, match="divisible"):
+        MultiscaleDeformableAttention(32, 30, 2, 4, 2, "zeros", False)
+    m = MultiscaleDeformableAttention(8, 8, 1, 1, 1, "zeros", False)
+    with pytest.raises(ValueError, match="2 or 4"):
+        m(torch.randn(1, 16, 8), torch.tensor([[2, 8]]), torch.randn(1, 1, 8), torch.randn(1, 1, 3))
+    # reference quirk (frontend.py:275): (x, y) offsets are divided by img_shapes in (h, w) order
+    with torch.no_grad():
+        m.query_input_proj.weight.zero_()
+        m.query_input_proj.bias.copy_(torch.tensor([1.0, 1.0, 0.0]))
+    pts, _ = m.sampling_inputs(torch.tensor([[2, 8]]), torch.zeros(1, 1, 8), torch.zeros(1, 1, 2))
+    assert torch.allclose(pts.flatten(), torch.tensor([0.5, 0.125]))
+
+
+# ---------------------------------------------------------------- synth -----------------------
+def test_synth_shards_are_slices_of_the_whole_and_bytes_match_baseline_md():
+    from msda_triton_amd import synth
+    wl = synth.Workload("t", 2, 24, 2, 4, ((4, 4), (2, 2)), 3)
+    full = synth.make_inputs_numpy(wl, seed=5)
+    part = synth.make_inputs_numpy(wl, seed=5, q_begin=7, q_end=19)
+    for k in ("loc", "attn", "grad_out"):
+        assert np.array_equal(part[k], full[k][:, 7:19])
+    assert np.array_equal(part["value"], full["value"])
+    assert abs(full["attn"].sum(-1) - 1).max() < 1e-12
+    c2 = synth.WORKLOADS["c2_q10k"]
+    assert (c2.alg_fwd_bytes, c2.alg_fwd_bytes + c2.alg_bwd_bytes) == (124_682_304, 333_086_784)  # 124.68 / 333.09 MB
+    assert c2.gather_fwd_bytes == 2_621_440_000
+    assert synth.WORKLOADS["c3_ddetr_enc"].I == 17821 and synth.WORKLOADS["c5_stress"].I == 21824
