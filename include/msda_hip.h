@@ -34,6 +34,13 @@
  * Outputs are fully overwritten (no pre-zeroing required, no accumulation into them).
  * msda_bwd_*: grad_value may be NULL (that gradient is skipped), and grad_loc / grad_attn may
  * be NULL together (both skipped) — the autograd caller passes only what needs_input_grad asks.
+ *
+ * Backward workspace: grad_value is computed as a gather over a per-call inverted index (sample
+ * records sorted by bilinear cell), which lives in caller-provided device memory so that the
+ * library never allocates: pass `workspace` (256-byte aligned) of at least
+ * msda_bwd_workspace_bytes(...) bytes; its contents are scratch and need no initialisation.
+ * With workspace == NULL (or too small) grad_value falls back to an LDS-tile kernel that needs no
+ * workspace but is slower and scales worse with pyramid size.
  * Calls are asynchronous on `stream`; there is no host synchronisation and no allocation
  * inside, so a call sequence can be captured into a hipGraph.
  *
@@ -50,7 +57,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 1
+#define MSDA_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define MSDA_API __attribute__((visibility("default")))
@@ -76,13 +83,18 @@ extern "C" {
     MSDA_API int msda_bwd_##SUF(const void *grad_out, const void *value, const int64_t *shapes,             \
                        const void *loc, const void *attn, void *grad_value, void *grad_loc,        \
                        void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,     \
-                       int64_t L, int64_t P, int padding_mode, int align_corners, void *stream);
+                       int64_t L, int64_t P, int padding_mode, int align_corners, void *workspace, \
+                       int64_t workspace_bytes, void *stream);
 
 MSDA_DECLARE(f32)
 MSDA_DECLARE(f16)
 MSDA_DECLARE(bf16)
 MSDA_DECLARE(f64)
 #undef MSDA_DECLARE
+
+/* Bytes of device workspace msda_bwd_<dtype> wants for these sizes; elem_size = sizeof(dtype). */
+MSDA_API int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
+                                          int64_t P, int elem_size);
 
 /* ABI version of the loaded library (== MSDA_ABI_VERSION it was built with). */
 MSDA_API int msda_abi_version(void);
@@ -94,8 +106,10 @@ MSDA_API const char *msda_last_error(void);
  * Kernel-variant switches for A/B measurements (bench.py, profiling).  Not needed for
  * normal use: the defaults are the fastest measured variants.  Unknown keys return
  * MSDA_ERR_BAD_ARG.  Keys:
- *   "xcd_map"   1 (default): blockIdx -> (batch, head) mapping keeps each (b,h) plane on one XCD's L2
- *               0: plain linear mapping
+ *   "xcd_map"    1 (default): blockIdx -> (batch, head) mapping keeps each (b,h) plane on one XCD's L2
+ *                0: plain linear mapping
+ *   "value_path" 0 (default): grad_value by sorted gather when a workspace is supplied
+ *                1: always the LDS-tile kernel
  */
 MSDA_API int msda_set_option(const char *key, int value);
 MSDA_API int msda_get_option(const char *key);

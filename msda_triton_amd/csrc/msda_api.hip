@@ -10,9 +10,11 @@
 namespace msda {
 
 static std::atomic<int> g_xcd_map{1};
+static std::atomic<int> g_value_path{0};
 static thread_local char g_err[256] = "";
 
 int option_xcd_map() { return g_xcd_map.load(std::memory_order_relaxed); }
+int option_value_path() { return g_value_path.load(std::memory_order_relaxed); }
 
 void set_error(const char *fmt, ...)
 {
@@ -26,12 +28,26 @@ void set_error(const char *fmt, ...)
 
 extern "C" int msda_abi_version(void) { return MSDA_ABI_VERSION; }
 
+// the layout lives in a device header (msda_value_sorted.hpp); msda_f32.hip exposes its size formula
+extern "C" int64_t msda_bwd_workspace_bytes_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
+
+extern "C" int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
+                                            int64_t P, int elem_size)
+{
+    if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0) return 0;
+    return msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
+}
+
 extern "C" const char *msda_last_error(void) { return msda::g_err; }
 
 extern "C" int msda_set_option(const char *key, int value)
 {
     if (key && strcmp(key, "xcd_map") == 0) {
         msda::g_xcd_map.store(value ? 1 : 0, std::memory_order_relaxed);
+        return 0;
+    }
+    if (key && strcmp(key, "value_path") == 0) {
+        msda::g_value_path.store(value ? 1 : 0, std::memory_order_relaxed);
         return 0;
     }
     msda::set_error("unknown option '%s'", key ? key : "(null)");
@@ -41,6 +57,7 @@ extern "C" int msda_set_option(const char *key, int value)
 extern "C" int msda_get_option(const char *key)
 {
     if (key && strcmp(key, "xcd_map") == 0) return msda::option_xcd_map();
+    if (key && strcmp(key, "value_path") == 0) return msda::option_value_path();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

@@ -94,17 +94,23 @@ struct LevelTab {
     int h[kMaxLevels];
     int w[kMaxLevels];
     int start[kMaxLevels];
+    int cstart[kMaxLevels];  // exclusive cumsum of (h+1)*(w+1): the level's first bilinear *cell* (backward)
 };
 
 __device__ __forceinline__ void load_level_table(LevelTab *tab, const int64_t *shapes, int L)
 {
     const int t = threadIdx.x;
     if (t < L) {
-        int start = 0;
-        for (int l = 0; l < t; ++l) start += (int)shapes[2 * l] * (int)shapes[2 * l + 1];
+        int start = 0, cstart = 0;
+        for (int l = 0; l < t; ++l) {
+            const int lh = (int)shapes[2 * l], lw = (int)shapes[2 * l + 1];
+            start += lh * lw;
+            cstart += (lh + 1) * (lw + 1);
+        }
         tab->h[t] = (int)shapes[2 * t];
         tab->w[t] = (int)shapes[2 * t + 1];
         tab->start[t] = start;
+        tab->cstart[t] = cstart;
     }
 }
 

@@ -38,6 +38,17 @@ struct Params {
     int nchunks;   // channel chunks (D / CH)
     int nranges;   // pixel ranges
     int range_px;  // pixels per range
+    // sorted (gather-formulated) grad_value path: caller-provided workspace, see msda_value_sorted.hpp
+    int *ws_part;       // [pairs][nsplit][nc_cap]  per-slice cell counts, then each slice's first slot per cell
+    int *ws_off;        // [pairs][nc_cap+1]  exclusive offsets of the cell lists
+    int4 *ws_pixrec;    // [pairs][I][3]      per pixel: list starts, list lengths, (first item, chunks, -, -)
+    int *ws_itemcnt;    // [pairs]            work items of the plane
+    int4 *ws_items;     // [pairs][it_cap]    (pixel, chunk, chunks of the pixel, -)
+    void *ws_entries;   // [pairs][Q*L*P]     Entry<acc>: sample records sorted by cell
+    void *ws_scratch;   // [pairs][it_cap][D] acc-typed partial rows of multi-chunk pixels
+    int nc_cap, it_cap;
+    int nsplit;         // query slices per plane in the count / place passes
+    int cell_cap;       // cells a count / place workgroup holds in LDS at a time
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char msda_smem[];

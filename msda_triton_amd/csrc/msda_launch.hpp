@@ -4,25 +4,27 @@
 
 #include <stdio.h>
 
-#include "msda_kernels.hpp"
+#include "msda_value_sorted.hpp"
 
 namespace msda {
 
 // ---- process-wide options and per-thread error text (defined in msda_api.hip) ----
 int option_xcd_map();
+int option_value_path();  // 0: sorted gather when a workspace is supplied (default), 1: always LDS tiles
 void set_error(const char *fmt, ...);
 
 constexpr int kGatherLdsBudget = 60 * 1024;                // per workgroup, gather kernels
 constexpr int kValueLdsBudget = 160 * 1024 - 2048;         // per workgroup, grad_value tiles
-constexpr int kMaxDynLds = 160 * 1024;
+constexpr int kMaxDynLds = 160 * 1024 - 2048;  // leaves room for small static __shared__ objects
 
 inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 template <typename K> inline void allow_big_lds(K kernel)
 {
     // one attribute call per kernel instantiation (thread-safe enough: idempotent)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kMaxDynLds);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kMaxDynLds) != hipSuccess)
+        (void)hipGetLastError();  // do not let a refused attribute poison the next launch check
 }
 
 struct Dims {
@@ -154,6 +156,86 @@ template <typename T> inline int dispatch_value(Params &p, hipStream_t stream)
     return launch_value<T, 1>(p, stream);
 }
 
+// ---- sorted (gather-formulated) grad_value: K1..K5 of msda_value_sorted.hpp ----
+template <typename T, int VEC, int G> inline int launch_value_gather(Params &p, hipStream_t stream)
+{
+    constexpr int NU = kBlock / G;
+    const int npairs = p.B * p.H;
+    const int64_t ppairs = p.xcd_map ? ((npairs + 7) / 8) * 8 : npairs;
+    const int64_t b4 = ppairs * ((p.it_cap + NU - 1) / NU), b5 = ppairs * ((p.I + NU - 1) / NU);
+    if (b4 >= ((int64_t)1 << 31) || b5 >= ((int64_t)1 << 31)) {
+        set_error("grid too large");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G>), dim3((unsigned)b4), dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((msda_value_finish_kernel<T, VEC, G>), dim3((unsigned)b5), dim3(kBlock), 0, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int VEC> inline int dispatch_value_gather_group(Params &p, hipStream_t stream)
+{
+    const int lanes = (p.D + VEC - 1) / VEC;
+    switch (pick_group(lanes)) {
+    case 4: return launch_value_gather<T, VEC, 4>(p, stream);
+    case 8: return launch_value_gather<T, VEC, 8>(p, stream);
+    case 16: return launch_value_gather<T, VEC, 16>(p, stream);
+    case 32: return launch_value_gather<T, VEC, 32>(p, stream);
+    default: return launch_value_gather<T, VEC, 64>(p, stream);
+    }
+}
+
+template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void *workspace, hipStream_t stream)
+{
+    using A = typename Traits<T>::acc;
+    const SortedWsLayout w = sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A));
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    p.ws_part = reinterpret_cast<int *>(ws + w.off_part);
+    p.ws_off = reinterpret_cast<int *>(ws + w.off_off);
+    p.ws_pixrec = reinterpret_cast<int4 *>(ws + w.off_pixrec);
+    p.ws_itemcnt = reinterpret_cast<int *>(ws + w.off_itemcnt);
+    p.ws_items = reinterpret_cast<int4 *>(ws + w.off_items);
+    p.ws_entries = ws + w.off_entries;
+    p.ws_scratch = ws + w.off_scratch;
+    p.nc_cap = w.nc_cap;
+    p.it_cap = w.it_cap;
+    p.nsplit = w.nsplit;
+    p.cell_cap = w.nc_cap < kCellLdsInts ? w.nc_cap : kCellLdsInts;
+    const int npairs = p.B * p.H;
+    const int64_t ppairs = p.xcd_map ? ((npairs + 7) / 8) * 8 : npairs;
+    const int64_t bcell = ppairs * p.nsplit;
+    if (bcell >= ((int64_t)1 << 31)) {
+        set_error("grid too large");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    const size_t cell_lds = sizeof(LevelTab) + (size_t)p.cell_cap * sizeof(int);
+    static bool big_lds_ok = false;
+    if (!big_lds_ok) {
+        allow_big_lds(msda_cell_pass_kernel<T, false>);
+        allow_big_lds(msda_cell_pass_kernel<T, true>);
+        big_lds_ok = true;
+    }
+    hipLaunchKernelGGL((msda_cell_pass_kernel<T, false>), dim3((unsigned)bcell), dim3(kCellBlock), cell_lds, stream, p);
+    const int64_t tot_blocks = (int64_t)((p.nc_cap + kBlock - 1) / kBlock) * npairs;
+    if (tot_blocks >= ((int64_t)1 << 31)) {
+        set_error("grid too large");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    hipLaunchKernelGGL((msda_cell_total_kernel<T>), dim3((unsigned)tot_blocks), dim3(kBlock), 0, stream, p);
+    const size_t scan_lds = (size_t)(p.cell_cap + 1) * sizeof(int);
+    static bool scan_lds_ok = false;
+    if (!scan_lds_ok) {
+        allow_big_lds(msda_cell_scan_kernel<T>);
+        scan_lds_ok = true;
+    }
+    hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)npairs), dim3(kCellBlock), scan_lds, stream, p);
+    hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), dim3((unsigned)bcell), dim3(kCellBlock), cell_lds, stream, p);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    constexpr int VECF = 16 / sizeof(T);
+    const bool vec_ok = aligned_to(p.grad_out, 16) && aligned_to(p.grad_value, 16) && (p.D % VECF) == 0;
+    return vec_ok ? dispatch_value_gather_group<T, VECF>(p, stream) : dispatch_value_gather_group<T, 1>(p, stream);
+}
+
 inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_corners)
 {
     p.B = (int)d.B;
@@ -209,7 +291,8 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
 template <typename T>
 int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, const void *loc, const void *attn,
             void *grad_value, void *grad_loc, void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,
-            int64_t L, int64_t P, int padding_mode, int align_corners, void *stream_)
+            int64_t L, int64_t P, int padding_mode, int align_corners, void *workspace, int64_t workspace_bytes,
+            void *stream_)
 {
     const Dims d{B, I, H, D, Q, L, P};
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -258,7 +341,10 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
         }
     }
     if (want_value) {
-        rc = dispatch_value<T>(p, stream);
+        using A = typename Traits<T>::acc;
+        const bool sorted = option_value_path() == 0 && workspace != nullptr && aligned_to(workspace, 256) &&
+                            (uint64_t)workspace_bytes >= sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A)).total;
+        rc = sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
         if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
     return rc;
@@ -277,8 +363,9 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     extern "C" int msda_bwd_##SUF(const void *grad_out, const void *value, const int64_t *shapes,               \
                                   const void *loc, const void *attn, void *grad_value, void *grad_loc,          \
                                   void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,       \
-                                  int64_t L, int64_t P, int padding_mode, int align_corners, void *stream)      \
+                                  int64_t L, int64_t P, int padding_mode, int align_corners, void *workspace,   \
+                                  int64_t workspace_bytes, void *stream)                                         \
     {                                                                                                            \
         return msda::run_bwd<T>(grad_out, value, shapes, loc, attn, grad_value, grad_loc, grad_attn, B, I, H,   \
-                                D, Q, L, P, padding_mode, align_corners, stream);                                \
+                                D, Q, L, P, padding_mode, align_corners, workspace, workspace_bytes, stream);    \
     }

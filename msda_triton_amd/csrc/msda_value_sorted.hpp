@@ -1,0 +1,470 @@
+// msda_value_sorted.hpp — grad_value as a GATHER: no atomics on floating-point data, no global atomics.
+//
+// The reference scatter-adds four corner tiles per sample with global atomics (kernels.py:543-553).
+// Here the scatter is inverted once per call:
+//
+//   a bilinear *cell* of level l is the unit square whose top-left corner is pixel (x0, y0),
+//   x0 in [-1, W-1], y0 in [-1, H-1]  ->  (W+1)*(H+1) cells per level, cell id = cstart_l + (y0+1)*(W+1) + (x0+1).
+//   A sample lives in exactly one cell and touches only that cell's (up to) four corner pixels.
+//
+//   K1 count    (plane, query slice j): histogram of the slice's samples over the plane's cells, kept in LDS
+//               (ds_add_u32), written out as part[plane][j][cell]
+//   K2a total   off[cell] = sum_j part[j][cell]                       (all cells of all planes in parallel)
+//   K2b scan    per plane, in LDS: off = exclusive_scan(off); per pixel: the four incident cell lists
+//               (start, length), chunks = max(1, ceil(n / kChunk)); work items (pixel, chunk) by a second scan
+//   K3 place    (plane, j): cursor[cell] = off[cell] + sum_{j'<j} part[j'][cell] in LDS; every sample ->
+//               entries[cursor[cell]++] = {q, dx, dy, a}
+//   K4 gather   one G-lane group per work item: walk its window of the pixel's four cell lists (as one
+//               virtual list), G entries at a time: each lane fetches one record and turns it into
+//               (q, a*fx*fy); the group passes these lane to lane, issues the grad_out row loads (16 bytes per
+//               lane, the forward's gather shape) back to back and FMAs into registers; single-chunk pixels
+//               store their grad_value row directly, multi-chunk pixels park a partial row in scratch
+//   K5 finish   pixels with several chunks: sum their partial rows in chunk order, store
+//
+// Every grad_value row is written exactly once by plain stores (no memset); hot pixels of coarse
+// levels are split into kChunk-entry work items so the load stays balanced whatever the sampling
+// distribution.  Padding semantics: "zeros" drops samples/corners outside the image; "border" clips
+// the pixel coordinate to [0, size-1] first (grid_sample), which puts the whole weight on the edge
+// pixel exactly as the reference's clamped corners do.
+#pragma once
+
+#include "msda_kernels.hpp"
+
+namespace msda {
+
+constexpr int kChunk = 64;           // entries per work item
+constexpr int kCellBlock = 1024;     // threads of K1 / K2b / K3
+constexpr int kCellLdsInts = 36864;  // cells a workgroup keeps in LDS at a time (144 KiB)
+
+template <typename A> struct alignas(16) Entry {
+    uint32_t q;
+    A dx, dy, a;
+};
+
+// sample -> (cell id inside the plane, fractional offsets).  false: the sample touches no pixel.
+template <typename A>
+__device__ __forceinline__ bool sample_cell(A x, A y, int h, int w, int cstart, bool zeros, bool align, int &cell,
+                                            A &dx, A &dy)
+{
+    const A W = (A)w, Hh = (A)h;
+    A px, py;
+    if (align) {
+        px = x * (W - (A)1);
+        py = y * (Hh - (A)1);
+    } else {
+        px = x * W - (A)0.5;
+        py = y * Hh - (A)0.5;
+    }
+    A x0, y0;
+    if (zeros) {
+        x0 = __builtin_floor(px);
+        y0 = __builtin_floor(py);
+        if (!(x0 >= (A)-1 && x0 <= W - (A)1 && y0 >= (A)-1 && y0 <= Hh - (A)1)) return false;  // also NaN
+    } else {
+        px = __builtin_fmin(__builtin_fmax(px, (A)0), W - (A)1);
+        py = __builtin_fmin(__builtin_fmax(py, (A)0), Hh - (A)1);
+        x0 = __builtin_floor(px);
+        y0 = __builtin_floor(py);
+    }
+    dx = px - x0;
+    dy = py - y0;
+    cell = cstart + ((int)y0 + 1) * (w + 1) + ((int)x0 + 1);
+    return true;
+}
+
+__device__ __forceinline__ int plane_cells(const LevelTab &tab, int L)
+{
+    return tab.cstart[L - 1] + (tab.h[L - 1] + 1) * (tab.w[L - 1] + 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 / K3: one pass over the samples of a (plane, query slice).  PLACE=false counts, true places.
+// ------------------------------------------------------------------------------------------
+template <typename T, bool PLACE>
+__global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params p)
+{
+    using A = typename Traits<T>::acc;
+    using TR = Traits<T>;
+    int pair, slice;
+    if (!decode_block(blockIdx.x, p.B * p.H, p.nsplit, p.xcd_map, pair, slice)) return;
+    const int b = pair / p.H, h = pair - b * p.H;
+    const int qper = (p.Q + p.nsplit - 1) / p.nsplit;
+    const int qa = min(p.Q, slice * qper), qb = min(p.Q, qa + qper);
+
+    LevelTab *tab = reinterpret_cast<LevelTab *>(msda_smem);
+    int *s_cell = reinterpret_cast<int *>(msda_smem + sizeof(LevelTab));
+    load_level_table(tab, p.shapes, p.L);
+    __syncthreads();
+    const int ncells = plane_cells(*tab, p.L);
+    const int cap = p.cell_cap;
+
+    int *part = p.ws_part + (size_t)pair * p.nsplit * p.nc_cap;  // [slice][cell]
+    const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
+    Entry<A> *entries = static_cast<Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
+    const T *loc = static_cast<const T *>(p.loc);
+    const T *attn = static_cast<const T *>(p.attn);
+    const float inv_P = 1.0f / (float)p.P;
+    const int tid = threadIdx.x;
+    const int dq = kCellBlock / p.LP, dr = kCellBlock - dq * p.LP;
+
+    for (int c0 = 0; c0 < ncells; c0 += cap) {  // one trip unless the plane has more cells than fit in LDS
+        const int n = min(cap, ncells - c0);
+        for (int i = tid; i < n; i += kCellBlock) {
+            int v = 0;
+            if constexpr (PLACE) {  // this slice's first slot in every cell list
+                v = off[c0 + i];
+                for (int jj = 0; jj < slice; ++jj) v += part[(size_t)jj * p.nc_cap + c0 + i];
+            }
+            s_cell[i] = v;
+        }
+        __syncthreads();
+        int q = qa + tid / p.LP, sl = tid % p.LP;
+        while (q < qb) {
+            const int l = div_small(sl, p.P, inv_P);
+            const size_t sidx = ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.LP + sl;
+            const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+            int cell;
+            A dx, dy;
+            if (sample_cell<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], tab->cstart[l], p.zeros,
+                               p.align, cell, dx, dy)) {
+                const unsigned rel = (unsigned)(cell - c0);
+                if (rel < (unsigned)n) {
+                    if constexpr (!PLACE) {
+                        atomicAdd(&s_cell[rel], 1);
+                    } else {
+                        const int pos = atomicAdd(&s_cell[rel], 1);
+                        Entry<A> e;
+                        e.q = (uint32_t)q;
+                        e.dx = dx;
+                        e.dy = dy;
+                        e.a = TR::to_acc(attn[sidx]);
+                        entries[pos] = e;
+                    }
+                }
+            }
+            q += dq;
+            sl += dr;
+            if (sl >= p.LP) {
+                sl -= p.LP;
+                ++q;
+            }
+        }
+        __syncthreads();
+        if constexpr (!PLACE) {
+            for (int i = tid; i < n; i += kCellBlock) part[(size_t)slice * p.nc_cap + c0 + i] = s_cell[i];
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2a: off[cell] = number of samples in the cell (sum over the query slices); grid (cell blocks, planes)
+// ------------------------------------------------------------------------------------------
+template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_total_kernel(const Params p)
+{
+    const int per_plane = (p.nc_cap + kBlock - 1) / kBlock;
+    const int pair = blockIdx.x / per_plane;
+    const int c = (blockIdx.x - pair * per_plane) * kBlock + threadIdx.x;
+    if (c >= p.nc_cap) return;  // cells beyond the plane's real count hold garbage that nobody reads
+    const int *part = p.ws_part + (size_t)pair * p.nsplit * p.nc_cap;
+    int tot = 0;
+    for (int j = 0; j < p.nsplit; ++j) tot += part[(size_t)j * p.nc_cap + c];
+    p.ws_off[(size_t)pair * (p.nc_cap + 1) + c] = tot;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2b: per-plane scans (one 1024-thread workgroup per plane), cell offsets staged in LDS when they fit
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_exclusive_scan(int v, int *s_wave, int &total)
+{
+    // inclusive scan inside the wave, then across the 16 waves through LDS
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int n = __shfl_up(inc, d, kWave);
+        if (lane >= d) inc += n;
+    }
+    __syncthreads();  // s_wave may still be in use by a previous scan
+    if (lane == kWave - 1) s_wave[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kCellBlock / kWave; ++i) {
+        const int s = s_wave[i];
+        if (i < wid) base += s;
+        tot += s;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
+template <typename Tag> __global__ __launch_bounds__(kCellBlock) void msda_cell_scan_kernel(const Params p)
+{
+    const int pair = blockIdx.x;
+    __shared__ LevelTab tab;
+    __shared__ int s_wave[kCellBlock / kWave];
+    int *s_off = reinterpret_cast<int *>(msda_smem);
+    load_level_table(&tab, p.shapes, p.L);
+    __syncthreads();
+    const int t = threadIdx.x;
+    const int last = p.L - 1;
+    const int nc = plane_cells(tab, p.L);
+    int *goff = p.ws_off + (size_t)pair * (p.nc_cap + 1);
+    const bool in_lds = nc + 1 <= p.cell_cap + 1;  // the launch sized the dynamic LDS for cell_cap + 1 ints
+    int *off = in_lds ? s_off : goff;
+
+    if (in_lds) {
+        for (int c = t; c < nc; c += kCellBlock) s_off[c] = goff[c];
+        __syncthreads();
+    }
+    // ---- A: exclusive scan of the per-cell totals ----
+    {
+        const int seg = (nc + kCellBlock - 1) / kCellBlock;
+        const int lo = min(nc, t * seg), hi = min(nc, lo + seg);
+        int sum = 0;
+        for (int i = lo; i < hi; ++i) sum += off[i];
+        int total;
+        int run = block_exclusive_scan(sum, s_wave, total);
+        for (int i = lo; i < hi; ++i) {
+            const int c = off[i];
+            off[i] = run;
+            run += c;
+        }
+        if (t == 0) off[nc] = total;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (in_lds)
+        for (int c = t; c <= nc; c += kCellBlock) goff[c] = s_off[c];
+
+    // ---- B: per-pixel list records and work items ----
+    {
+        const int seg = (p.I + kCellBlock - 1) / kCellBlock;
+        const int lo = min(p.I, t * seg), hi = min(p.I, lo + seg);
+        int4 *pixrec = p.ws_pixrec + (size_t)pair * p.I * 3;
+        int4 *items = p.ws_items + (size_t)pair * p.it_cap;
+        // pass 1: lists of every pixel of this thread's segment -> pixrec, count chunks
+        int sum = 0, l = 0;
+        for (int pix = lo; pix < hi; ++pix) {
+            while (l < last && pix >= tab.start[l + 1]) ++l;
+            const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
+            const int y = rel / w, x = rel - y * w;
+            const int c11 = tab.cstart[l] + y * cw + x;  // cell (x0 = x-1, y0 = y-1): this pixel is its corner 11
+            // list i = samples for which the pixel is corner i: 00 -> cell (x, y), 01 -> (x-1, y), 10 -> (x, y-1), 11
+            const int cells[4] = {c11 + cw + 1, c11 + cw, c11 + 1, c11};
+            int4 beg, len;
+            beg.x = off[cells[0]];
+            len.x = off[cells[0] + 1] - beg.x;
+            beg.y = off[cells[1]];
+            len.y = off[cells[1] + 1] - beg.y;
+            beg.z = off[cells[2]];
+            len.z = off[cells[2] + 1] - beg.z;
+            beg.w = off[cells[3]];
+            len.w = off[cells[3] + 1] - beg.w;
+            const int n = len.x + len.y + len.z + len.w;
+            const int chunks = max(1, (n + kChunk - 1) / kChunk);
+            pixrec[(size_t)pix * 3 + 0] = beg;
+            pixrec[(size_t)pix * 3 + 1] = len;
+            pixrec[(size_t)pix * 3 + 2] = make_int4(0, chunks, 0, 0);
+            sum += chunks;
+        }
+        int total;
+        int run = block_exclusive_scan(sum, s_wave, total);
+        // pass 2: item table (each thread re-reads the chunk counts it just wrote)
+        for (int pix = lo; pix < hi; ++pix) {
+            const int chunks = pixrec[(size_t)pix * 3 + 2].y;
+            pixrec[(size_t)pix * 3 + 2] = make_int4(run, chunks, 0, 0);
+            for (int k = 0; k < chunks; ++k) items[run + k] = make_int4(pix, k, chunks, 0);
+            run += chunks;
+        }
+        if (t == 0) p.ws_itemcnt[pair] = total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: gather.  G lanes per work item, VEC channels per lane (same shape as the forward gather).
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int G>
+__global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params p)
+{
+    using A = typename Traits<T>::acc;
+    using TR = Traits<T>;
+    constexpr int NU = kBlock / G;
+    constexpr int UB = G < 8 ? G : 8;  // row loads in flight per lane
+    const int slots = (p.it_cap + NU - 1) / NU;
+    int pair, slot;
+    if (!decode_block(blockIdx.x, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
+    const int nitems = p.ws_itemcnt[pair];
+    const int tid = threadIdx.x;
+    const int unit = tid / G, j = tid % G;
+    const int item = slot * NU + unit;
+    if (item >= nitems) return;
+    const int b = pair / p.H, h = pair - b * p.H;
+    const int lane_base = (tid & (kWave - 1)) & ~(G - 1);
+
+    const int4 it = p.ws_items[(size_t)pair * p.it_cap + item];
+    const int pix = it.x, chunk = it.y, nchunks = it.z;
+    const int4 *rec = p.ws_pixrec + ((size_t)pair * p.I + pix) * 3;
+    const int4 beg = rec[0], len = rec[1];
+    const int c1 = len.x, c2 = c1 + len.y, c3 = c2 + len.z, n = c3 + len.w;
+    const int w0 = chunk * kChunk, w1 = min(n, w0 + kChunk);  // this item's window of the virtual list
+
+    const Entry<A> *entries = static_cast<const Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
+    const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;
+    const size_t q_stride = (size_t)p.H * p.D;
+    const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
+
+    // position v of the pixel's virtual list (lists 0..3 back to back) -> (query, a * fx * fy)
+    auto fetch = [&](int v, uint32_t &q, A &wgt) {
+        q = 0;
+        wgt = (A)0;
+        if (v < w1) {
+            const int i = (v >= c1) + (v >= c2) + (v >= c3);
+            const int base = i == 0 ? beg.x : i == 1 ? beg.y - c1 : i == 2 ? beg.z - c2 : beg.w - c3;
+            const Entry<A> e = entries[base + v];
+            const A fx = (i & 1) ? e.dx : (A)1 - e.dx;
+            const A fy = (i & 2) ? e.dy : (A)1 - e.dy;
+            q = e.q;
+            wgt = e.a * (fy * fx);
+        }
+    };
+
+    for (int cc = 0; cc < nchan_chunks; ++cc) {
+        const int c0 = (cc * G + j) * VEC;
+        const bool lane_ok = c0 < p.D;
+        const T *grow = gout + (lane_ok ? c0 : 0);
+        A acc[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = (A)0;
+
+        uint32_t cur_q, nxt_q;
+        A cur_w, nxt_w;
+        fetch(w0 + j, cur_q, cur_w);
+        for (int v0 = w0; v0 < w1; v0 += G) {
+            fetch(v0 + G + j, nxt_q, nxt_w);  // next batch's records are in flight while this one is consumed
+            const int cnt = min(G, w1 - v0);
+            int jj = 0;
+            for (; jj + UB <= cnt; jj += UB) {  // UB row loads issued back to back, then consumed
+                A wgt[UB];
+                Pack<T, VEC> g[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj + u, kWave);
+                    wgt[u] = __shfl(cur_w, lane_base + jj + u, kWave);
+                    g[u] = *reinterpret_cast<const Pack<T, VEC> *>(grow + q * q_stride);
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] += wgt[u] * TR::to_acc(g[u].v[v]);
+            }
+            for (; jj < cnt; ++jj) {
+                const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj, kWave);
+                const A wg = __shfl(cur_w, lane_base + jj, kWave);
+                const Pack<T, VEC> g = *reinterpret_cast<const Pack<T, VEC> *>(grow + q * q_stride);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] += wg * TR::to_acc(g.v[v]);
+            }
+            cur_q = nxt_q;
+            cur_w = nxt_w;
+        }
+        if (lane_ok) {
+            if (nchunks == 1) {
+                Pack<T, VEC> o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
+                T *dst = static_cast<T *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
+                *reinterpret_cast<Pack<T, VEC> *>(dst) = o;
+            } else {
+                Pack<A, VEC> o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o.v[v] = acc[v];
+                A *dst = static_cast<A *>(p.ws_scratch) + ((size_t)pair * p.it_cap + item) * p.D + c0;
+                *reinterpret_cast<Pack<A, VEC> *>(dst) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: pixels that were split into several work items: sum the partial rows in chunk order
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC, int G>
+__global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params p)
+{
+    using A = typename Traits<T>::acc;
+    using TR = Traits<T>;
+    constexpr int NU = kBlock / G;
+    const int slots = (p.I + NU - 1) / NU;
+    int pair, slot;
+    if (!decode_block(blockIdx.x, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
+    const int b = pair / p.H, h = pair - b * p.H;
+    const int unit = threadIdx.x / G, j = threadIdx.x % G;
+    const int pix = slot * NU + unit;
+    if (pix >= p.I) return;
+    const int4 info = p.ws_pixrec[((size_t)pair * p.I + pix) * 3 + 2];
+    const int item0 = info.x, nchunks = info.y;
+    if (nchunks <= 1) return;
+    const A *src = static_cast<const A *>(p.ws_scratch) + ((size_t)pair * p.it_cap + item0) * p.D;
+    const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
+    for (int cc = 0; cc < nchan_chunks; ++cc) {
+        const int c0 = (cc * G + j) * VEC;
+        if (c0 >= p.D) continue;
+        A acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = (A)0;
+#pragma unroll 8
+        for (int k = 0; k < nchunks; ++k) {
+            const Pack<A, VEC> r = *reinterpret_cast<const Pack<A, VEC> *>(src + (size_t)k * p.D + c0);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += r.v[v];
+        }
+        Pack<T, VEC> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
+        T *dst = static_cast<T *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
+        *reinterpret_cast<Pack<T, VEC> *>(dst) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace layout (host + device agree through these helpers)
+// ------------------------------------------------------------------------------------------
+struct SortedWsLayout {
+    int nc_cap, it_cap, nsplit;
+    size_t off_part, off_off, off_pixrec, off_itemcnt, off_items, off_entries, off_scratch, total;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P,
+                                       size_t acc_bytes)
+{
+    SortedWsLayout w;
+    const size_t pairs = (size_t)(B * H);
+    const size_t samples = (size_t)(Q * L * P);  // per plane
+    w.nc_cap = (int)(2 * I + 2 * L);             // (w+1)(h+1) <= 2wh + 2 per level
+    w.it_cap = (int)(I + (4 * samples + kChunk - 1) / kChunk + 1);
+    // query slices per plane: enough workgroups to fill the chip, at least ~2k samples each
+    int64_t ns = pairs ? (int64_t)((512 + pairs - 1) / pairs) : 1;
+    const int64_t by_work = (int64_t)((samples + 2047) / 2048);
+    if (ns > by_work) ns = by_work;
+    if (ns > 64) ns = 64;
+    if (ns > Q) ns = Q;
+    if (ns < 1) ns = 1;
+    w.nsplit = (int)ns;
+    const size_t entry_bytes = acc_bytes == 8 ? 32 : 16;
+    size_t o = 0;
+    w.off_part = o;     o = align_up(o + pairs * w.nsplit * (size_t)w.nc_cap * 4, 256);
+    w.off_off = o;      o = align_up(o + pairs * ((size_t)w.nc_cap + 1) * 4, 256);
+    w.off_pixrec = o;   o = align_up(o + pairs * (size_t)I * 48, 256);
+    w.off_itemcnt = o;  o = align_up(o + pairs * 4, 256);
+    w.off_items = o;    o = align_up(o + pairs * (size_t)w.it_cap * 16, 256);
+    w.off_entries = o;  o = align_up(o + pairs * samples * entry_bytes, 256);
+    w.off_scratch = o;  o = align_up(o + pairs * (size_t)w.it_cap * (size_t)D * acc_bytes, 256);
+    w.total = o;
+    return w;
+}
+
+}  // namespace msda

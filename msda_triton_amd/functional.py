@@ -157,6 +157,10 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
     if want_value or want_sample:
         lib = _lib.load()
         fn = getattr(lib, f"msda_bwd_{suf}")
+        ws, ws_bytes = None, 0
+        if want_value:  # scratch for the inverted index; the caching allocator makes this cheap
+            ws_bytes = int(lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, img.element_size()))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
         def call(value_part: bool, sample_part: bool):
             return fn(out_grad.data_ptr(), img.data_ptr(), shapes.data_ptr(), sampling_points.data_ptr(),
@@ -164,7 +168,9 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
                       g_img.data_ptr() if value_part else None,
                       g_pts.data_ptr() if sample_part else None,
                       g_att.data_ptr() if sample_part else None,
-                      B, I, H, D, Q, L, P, pad, int(bool(align_corners)), _stream_ptr(img.device))
+                      B, I, H, D, Q, L, P, pad, int(bool(align_corners)),
+                      ws.data_ptr() if (ws is not None and value_part) else None, ws_bytes,
+                      _stream_ptr(img.device))
 
         with torch.cuda.device(img.device):
             timer = KernelTimer.active
