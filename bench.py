@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--workload", default="c2_q10k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--xcd-map", type=int, default=None, help="override the blockIdx->(b,h) mapping (A/B runs)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
+                    help="msda_set_option override for A/B runs, e.g. --opt stage_kb=0 --opt value_path=1")
     args = ap.parse_args()
 
     import torch
@@ -116,6 +118,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
     if args.xcd_map is not None:
         _lib.set_option("xcd_map", args.xcd_map)
+    for kv in args.opt:
+        key, val = kv.split("=")
+        _lib.set_option(key, int(val))
 
     wl = synth.WORKLOADS[args.workload]
     pm, ac = wl.padding_mode, wl.align_corners
@@ -215,7 +220,7 @@ def main():
                          "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic,
                          "timing": "HIP events around every launch inside the timed region"},
             "kernels": kernels,
-            "options": {"xcd_map": _lib.get_option("xcd_map")},
+            "options": {k: _lib.get_option(k) for k in ("xcd_map", "value_path", "stage_kb")},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wl)

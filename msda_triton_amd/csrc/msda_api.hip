@@ -11,10 +11,16 @@ namespace msda {
 
 static std::atomic<int> g_xcd_map{1};
 static std::atomic<int> g_value_path{0};
+static std::atomic<int> g_stage_kb{0};
+static std::atomic<int> g_gather_block{1024};
+static std::atomic<int> g_wg_target{1 << 30};
 static thread_local char g_err[256] = "";
 
 int option_xcd_map() { return g_xcd_map.load(std::memory_order_relaxed); }
 int option_value_path() { return g_value_path.load(std::memory_order_relaxed); }
+int option_stage_kb() { return g_stage_kb.load(std::memory_order_relaxed); }
+int option_gather_block() { return g_gather_block.load(std::memory_order_relaxed); }
+int option_wg_target() { return g_wg_target.load(std::memory_order_relaxed); }
 
 void set_error(const char *fmt, ...)
 {
@@ -50,6 +56,18 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_value_path.store(value ? 1 : 0, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "stage_kb") == 0 && value >= 0 && value <= 156) {
+        msda::g_stage_kb.store(value, std::memory_order_relaxed);
+        return 0;
+    }
+    if (key && strcmp(key, "gather_block") == 0 && (value == 256 || value == 512 || value == 1024)) {
+        msda::g_gather_block.store(value, std::memory_order_relaxed);
+        return 0;
+    }
+    if (key && strcmp(key, "wg_target") == 0 && value >= 1) {
+        msda::g_wg_target.store(value, std::memory_order_relaxed);
+        return 0;
+    }
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }
@@ -58,6 +76,9 @@ extern "C" int msda_get_option(const char *key)
 {
     if (key && strcmp(key, "xcd_map") == 0) return msda::option_xcd_map();
     if (key && strcmp(key, "value_path") == 0) return msda::option_value_path();
+    if (key && strcmp(key, "stage_kb") == 0) return msda::option_stage_kb();
+    if (key && strcmp(key, "gather_block") == 0) return msda::option_gather_block();
+    if (key && strcmp(key, "wg_target") == 0) return msda::option_wg_target();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

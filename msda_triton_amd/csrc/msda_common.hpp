@@ -39,6 +39,16 @@ template <> struct Traits<__bf16> {
     static __device__ __forceinline__ __bf16 from_acc(float v) { return (__bf16)v; }  // v_cvt_pk_bf16_f32, RNE
 };
 
+// a*b + c in the accumulate type (one v_fma_f32 / v_fma_f64, never a silent promotion to double)
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float floor_t(float a) { return __builtin_floorf(a); }
+__device__ __forceinline__ double floor_t(double a) { return __builtin_floor(a); }
+__device__ __forceinline__ float fmin_t(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double fmin_t(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float fmax_t(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double fmax_t(double a, double b) { return __builtin_fmax(a, b); }
+
 // N elements of T with the natural alignment of the whole pack (so one load/store instruction).
 template <typename T, int N> struct alignas(sizeof(T) * N) Pack {
     T v[N];
@@ -147,14 +157,14 @@ __device__ __forceinline__ void make_taps(A x, A y, int h, int w, int start, boo
         px = x * W - (A)0.5;
         py = y * Hh - (A)0.5;
     }
-    const A x0 = __builtin_floor(px), y0 = __builtin_floor(py);
+    const A x0 = floor_t(px), y0 = floor_t(py);
     const A x1 = x0 + (A)1, y1 = y0 + (A)1;
     // clamp in floating point before the int conversion: far-OOB / NaN coordinates cannot overflow
     const A xm = W - (A)1, ym = Hh - (A)1;
-    const int x0c = (int)__builtin_fmin(__builtin_fmax(x0, (A)0), xm);
-    const int x1c = (int)__builtin_fmin(__builtin_fmax(x1, (A)0), xm);
-    const int y0c = (int)__builtin_fmin(__builtin_fmax(y0, (A)0), ym);
-    const int y1c = (int)__builtin_fmin(__builtin_fmax(y1, (A)0), ym);
+    const int x0c = (int)fmin_t(fmax_t(x0, (A)0), xm);
+    const int x1c = (int)fmin_t(fmax_t(x1, (A)0), xm);
+    const int y0c = (int)fmin_t(fmax_t(y0, (A)0), ym);
+    const int y1c = (int)fmin_t(fmax_t(y1, (A)0), ym);
     const uint32_t r0 = (uint32_t)(start + y0c * w), r1 = (uint32_t)(start + y1c * w);
     t.off[0] = (r0 + (uint32_t)x0c) * row_bytes;
     t.off[1] = (r0 + (uint32_t)x1c) * row_bytes;
@@ -206,19 +216,43 @@ template <int G> __device__ __forceinline__ double group_sum(double v)
     return v;
 }
 
-// blockIdx -> (pair = b*H + h, slot).  With xcd_map, workgroups whose ids are congruent mod 8
+// n / d for any 32-bit n with a host-made (magic, shift) pair (round-up method, branch-free core).
+struct FastDiv {
+    uint32_t magic, shift;  // shift == 0: d is 1
+};
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv fd)
+{
+    if (fd.shift == 0) return n;
+    const uint32_t t = __umulhi(n, fd.magic);
+    return (((n - t) >> 1) + t) >> (fd.shift - 1);
+}
+
+// blockIdx -> (pair = b*H + h, slot).  With xcd_map, workgroups whose linear ids are congruent mod 8
 // (they share an XCD and therefore an L2 under round-robin dispatch) work on the same (b, h)
 // planes, and each XCD walks its planes one after another, so a plane is pulled into exactly
 // one L2.  Pure speed: any placement gives the same results.  Returns false for padding blocks.
-__device__ __forceinline__ bool decode_block(int bid, int npairs, int slots, bool xcd_map, int &pair, int &slot)
+// grid3d: the launch used dim3(8, slots, ceil(pairs/8)) (xcd_map) or dim3(slots, pairs), whose
+// linear dispatch order equals the 1-D formula below, so no integer division is needed.
+__device__ __forceinline__ bool decode_block(int grid3d, int npairs, int slots, bool xcd_map, int &pair, int &slot)
 {
-    if (xcd_map) {
-        const int x = bid & 7, t = bid >> 3;
-        slot = t % slots;
-        pair = (t / slots) * 8 + x;
+    if (grid3d) {
+        if (xcd_map) {
+            pair = (int)(blockIdx.z * 8 + blockIdx.x);
+            slot = (int)blockIdx.y;
+        } else {
+            pair = (int)blockIdx.y;
+            slot = (int)blockIdx.x;
+        }
     } else {
-        pair = bid / slots;
-        slot = bid - pair * slots;
+        const int bid = (int)blockIdx.x;
+        if (xcd_map) {
+            const int x = bid & 7, t = bid >> 3;
+            slot = t % slots;
+            pair = (t / slots) * 8 + x;
+        } else {
+            pair = bid / slots;
+            slot = bid - pair * slots;
+        }
     }
     return pair < npairs;
 }

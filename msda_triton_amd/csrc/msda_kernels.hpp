@@ -1,19 +1,24 @@
-// msda_kernels.hpp — the three gfx950 kernels and their host-side launch logic.
+// msda_kernels.hpp — kernel parameters and the two gather kernels.
 //
 //   msda_fwd_kernel         out = sum_{l,p} attn * bilinear(value_l, loc)        (kernels.py:259-348)
 //   msda_bwd_sample_kernel  grad_loc, grad_attn (private per sample, no atomics)  (kernels.py:494-537)
-//   msda_bwd_value_kernel   grad_value, owner-computes tiles accumulated in LDS   (kernels.py:543-553)
+//   (grad_value lives in msda_value_sorted.hpp / msda_value_tile.hpp)
 //
-// Work decomposition (all three): a workgroup owns ONE (batch, head) plane of `value` and a slice
-// of the queries, so every row it gathers comes from one 2-D plane that the XCD-aware block map
-// keeps resident in a single L2.  Inside the gather kernels a *unit* = one (b, q, h); a unit is
+// Work decomposition: a workgroup owns ONE (batch, head) plane of `value` and a run of query
+// chunks, so every row it gathers comes from one 2-D plane.  A *unit* = one (b, q, h); a unit is
 // served by G lanes (G * VEC >= D channels, VEC elements = one 16-byte load per lane), i.e.
 // 64/G units per wavefront and 256/G per workgroup.
 //
+// Stage (once per workgroup): the small pyramid levels of the plane — as many, smallest first, as fit
+//   the staging budget — are copied into LDS.  With the usual 2x pyramid the two coarsest levels are
+//   1/16 of the pixels but half of the samples, so half of the row gathers never touch the vector
+//   memory path (L2 -> L1 at 64 B/clk/CU is what bounds these kernels, not HBM).
 // Phase 1 (all 256 threads, one sample each): read (x, y, a), do the coordinate math ONCE per
 //   sample, park {4 row offsets, 4 weights} in LDS.  Loads are coalesced along (l, p).
-// Phase 2 (per unit, G lanes): walk the unit's samples, broadcast-read the parked record, issue
-//   the four row gathers as 16-byte range-checked buffer loads, FMA into per-lane accumulators.
+// Phase 2 (per unit, G lanes): walk the unit's samples level by level (the level of sample s is the
+//   same for every unit, so the LDS-or-global choice is wave-uniform), broadcast-read the parked
+//   record, fetch the four rows (ds_read_b128 from the staged copy, or range-checked 16-byte buffer
+//   loads), FMA into per-lane accumulators.
 #pragma once
 
 #include "msda_common.hpp"
@@ -32,9 +37,13 @@ struct Params {
     void *grad_attn;
     int B, I, H, D, Q, L, P, LP;
     int nqc;       // query chunks per (b,h) plane (gather kernels)
+    int qw;        // query chunks handled by one workgroup (amortises the level staging)
     int sc;        // samples of a unit parked in LDS at a time (<= LP)
+    int stage_bytes;  // LDS bytes available for staged levels (0: no staging)
     int zeros, align, xcd_map;
-    // grad_value kernel tiling
+    int grid3d;       // this launch uses the division-free 3-D grid (see decode_block)
+    FastDiv div_h;    // pair -> (b, h)
+    // grad_value tile kernel
     int nchunks;   // channel chunks (D / CH)
     int nranges;   // pixel ranges
     int range_px;  // pixels per range
@@ -57,105 +66,256 @@ template <typename A> struct alignas(16) Rec4 {
     A v[4];
 };
 
+// ------------------------------------------------------------------------------------------
+// level staging
+// ------------------------------------------------------------------------------------------
+struct StagePlan {
+    int off[kMaxLevels];  // byte offset of the level's copy inside the stage area, or -1 (not staged)
+    int zero_off;         // a row of zeros: where masked corners of staged levels point
+};
+
+// Decide (thread 0) which levels are staged, then copy them (all threads).  Levels are taken from the
+// last to the first (coarse to fine in the usual ordering) while they fit.  Caller syncs before and after.
+template <typename T, int BLOCK>
+__device__ __forceinline__ void stage_levels(const LevelTab *tab, StagePlan *plan, unsigned char *stage, rsrc_t rs,
+                                             uint32_t row_bytes, int row_b, int budget, int L)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int used = row_b;  // slot 0 is the zero row
+        plan->zero_off = 0;
+        for (int l = L - 1; l >= 0; --l) {
+            const long long bytes = (long long)tab->h[l] * tab->w[l] * row_b;
+            if (budget > 0 && used + bytes <= (long long)budget) {
+                plan->off[l] = used;
+                used += (int)bytes;
+            } else {
+                plan->off[l] = -1;
+            }
+        }
+    }
+    __syncthreads();
+    if (budget <= 0) return;
+    const int cpr = row_b / 16;  // 16-byte pieces per row
+    for (int i = tid; i < cpr; i += BLOCK) reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0, 0, 0, 0);
+    const float inv_cpr = 1.0f / (float)cpr;
+    for (int l = 0; l < L; ++l) {
+        const int so = plan->off[l];
+        if (so < 0) continue;  // uniform
+        const int pieces = tab->h[l] * tab->w[l] * cpr;
+        const uint32_t src0 = (uint32_t)tab->start[l] * row_bytes;
+        for (int c = tid; c < pieces; c += BLOCK) {
+            const int r = div_small(c, cpr, inv_cpr), part = c - r * cpr;
+            const auto v = RawLoad<16>::load(rs, src0 + (uint32_t)r * row_bytes + (uint32_t)part * 16u);
+            *reinterpret_cast<RawLoad<16>::type *>(stage + so + c * 16) = v;
+        }
+    }
+}
+
+// record offsets of one sample: staged level -> byte offset inside the stage area, else global plane offset
+template <typename A>
+__device__ __forceinline__ uint4 record_offsets(const Taps<A> &t, int stage_off, int zero_off, int row_b, int start,
+                                                uint32_t row_bytes)
+{
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t rel = t.off[k];  // pixel index inside the level, or kMaskedOffset
+        if (stage_off >= 0)
+            o[k] = rel == kMaskedOffset ? (uint32_t)zero_off : (uint32_t)stage_off + rel * (uint32_t)row_b;
+        else
+            o[k] = rel == kMaskedOffset ? kMaskedOffset : ((uint32_t)start + rel) * row_bytes;
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void lds_row(const unsigned char *stage, uint32_t off, typename Traits<T>::acc (&dst)[VEC])
+{
+    const Pack<T, VEC> p = *reinterpret_cast<const Pack<T, VEC> *>(stage + off);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dst[i] = Traits<T>::to_acc(p.v[i]);
+}
+
+// Records parked by a wave are read back only by that same wave: DS operations of one wave execute
+// in order, so no s_barrier is needed — only a compiler fence so the accesses are not reordered.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// shared LDS carve-up of the two gather kernels
+template <typename A> struct GatherLds {
+    LevelTab *tab;
+    StagePlan *plan;
+    uint4 *s_off;
+    Rec4<A> *s_rec;
+    unsigned char *stage;
+    __device__ __forceinline__ GatherLds(int units, int scp)
+    {
+        unsigned char *p = msda_smem;
+        tab = reinterpret_cast<LevelTab *>(p);
+        p += sizeof(LevelTab);
+        plan = reinterpret_cast<StagePlan *>(p);
+        p += (sizeof(StagePlan) + 15) / 16 * 16;
+        s_off = reinterpret_cast<uint4 *>(p);
+        p += (size_t)units * scp * sizeof(uint4);
+        s_rec = reinterpret_cast<Rec4<A> *>(p);
+        p += (size_t)units * scp * sizeof(Rec4<A>);
+        stage = p;
+    }
+};
+constexpr size_t kGatherLdsFixed = sizeof(LevelTab) + (sizeof(StagePlan) + 15) / 16 * 16;
+
 // ==========================================================================================
-// forward
+// forward.  After the one-time staging barrier every wave runs on its own: it parks the records of
+// ITS 64/G units, gathers, stores, and moves to its next query chunk without any block barrier.
 // ==========================================================================================
-template <typename T, int VEC, int G>
-__global__ __launch_bounds__(kBlock) void msda_fwd_kernel(const Params p)
+template <typename T, int VEC, int G, int BLOCK, bool STAGE>
+__global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
-    constexpr int NU = kBlock / G;
+    constexpr int NU = BLOCK / G;      // units per workgroup and query chunk
+    constexpr int UPW = kWave / G;     // units per wave
 
-    int pair, qc;
-    if (!decode_block(blockIdx.x, p.B * p.H, p.nqc, p.xcd_map, pair, qc)) return;
-    const int b = pair / p.H, h = pair - b * p.H;
-    const int q0 = qc * NU;
+    const int slots = (p.nqc + p.qw - 1) / p.qw;
+    int pair, slot;
+    if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
+    const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
 
-    LevelTab *tab = reinterpret_cast<LevelTab *>(msda_smem);
     const int scp = p.sc + 1;  // +1 record of padding: units land on different LDS banks
-    uint4 *s_off = reinterpret_cast<uint4 *>(msda_smem + sizeof(LevelTab));
-    Rec4<A> *s_wt = reinterpret_cast<Rec4<A> *>(s_off + NU * scp);
-
-    load_level_table(tab, p.shapes, p.L);
-
-    const int tid = threadIdx.x;
-    const int unit = tid / G, j = tid % G;
-    const int q = q0 + unit;
-    const bool unit_ok = q < p.Q;
+    const GatherLds<A> lds(NU, scp);
+    LevelTab *tab = lds.tab;
 
     const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);
+    const int row_b = p.D * (int)sizeof(T);
     const T *plane = static_cast<const T *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
     const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(T));
     const rsrc_t rs = make_rsrc(plane, plane_bytes);
 
-    const T *loc = static_cast<const T *>(p.loc);
-    const T *attn = static_cast<const T *>(p.attn);
+    load_level_table(tab, p.shapes, p.L);
+    __syncthreads();
+    if constexpr (STAGE) {
+        stage_levels<T, BLOCK>(tab, lds.plan, lds.stage, rs, row_bytes, row_b, p.stage_bytes, p.L);
+        __syncthreads();
+    }
+
+    const int tid = threadIdx.x;
+    const int wave = tid / kWave, lane = tid % kWave;
+    const int wunit = lane / G, j = lane % G;  // unit inside the wave, lane inside the unit
+    uint4 *w_off = lds.s_off + wave * UPW * scp;
+    Rec4<A> *w_rec = lds.s_rec + wave * UPW * scp;
+    // per-plane bases (64-bit, uniform) + 32-bit per-sample indices (the host checks Q*H*L*P*2 < 2^31)
+    const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
+    const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
+    const T *attn = static_cast<const T *>(p.attn) + plane_s0;
+    const int HLP = p.H * p.LP;
     const float inv_P = 1.0f / (float)p.P;
-
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
-    for (int cc = 0; cc < nchan_chunks; ++cc) {
-        const int c0 = (cc * G + j) * VEC;
-        const bool lane_ok = unit_ok && (c0 < p.D);
-        A acc[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = (A)0;
+    const int qc_end = min(p.nqc, (slot + 1) * p.qw);
 
-        for (int s0 = 0; s0 < p.LP; s0 += p.sc) {
-            const int sc = min(p.sc, p.LP - s0);
-            const float inv_sc = 1.0f / (float)sc;
-            __syncthreads();  // level table ready / previous chunk's records consumed
-            // ---- phase 1: one sample per thread ----
-            for (int f = tid; f < NU * sc; f += kBlock) {
-                const int fu = div_small(f, sc, inv_sc);
-                const int sl = s0 + (f - fu * sc);
-                const int fq = q0 + fu;
-                if (fq < p.Q) {
-                    const int l = div_small(sl, p.P, inv_P);
-                    const size_t sidx = ((size_t)(b * (size_t)p.Q + fq) * p.H + h) * p.LP + sl;
-                    const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
-                    const A a = TR::to_acc(attn[sidx]);
-                    Taps<A> t;
-                    make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], tab->start[l],
-                                 p.zeros, p.align, row_bytes, t);
-                    const A wy0 = (A)1 - t.dy, wx0 = (A)1 - t.dx;
-                    Rec4<A> w;
-                    w.v[0] = a * (wy0 * wx0);
-                    w.v[1] = a * (wy0 * t.dx);
-                    w.v[2] = a * (t.dy * wx0);
-                    w.v[3] = a * (t.dy * t.dx);
-                    const int slot = fu * scp + (sl - s0);
-                    s_off[slot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
-                    s_wt[slot] = w;
+    for (int qc = slot * p.qw; qc < qc_end; ++qc) {
+        const int wq0 = qc * NU + wave * UPW;  // first query of this wave
+        if (wq0 >= p.Q) break;                 // wave-uniform
+        const int q = wq0 + wunit;
+        const bool unit_ok = q < p.Q;
+        for (int cc = 0; cc < nchan_chunks; ++cc) {
+            const int c0 = (cc * G + j) * VEC;
+            const bool lane_ok = unit_ok && (c0 < p.D);
+            const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
+            A acc[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = (A)0;
+
+            for (int s0 = 0; s0 < p.LP; s0 += p.sc) {
+                const int sc = min(p.sc, p.LP - s0);
+                const float inv_sc = 1.0f / (float)sc;
+                wave_lds_sync();  // previous records consumed
+                // ---- phase 1: the wave's UPW * sc samples, one per lane and trip ----
+                for (int f = lane; f < UPW * sc; f += kWave) {
+                    const int fu = div_small(f, sc, inv_sc);
+                    const int sl = s0 + (f - fu * sc);
+                    const int fq = wq0 + fu;
+                    if (fq < p.Q) {
+                        const int l = div_small(sl, p.P, inv_P);
+                        const int sidx = fq * HLP + sl;
+                        const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                        const A a = TR::to_acc(attn[sidx]);
+                        Taps<A> t;
+                        make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], 0, p.zeros, p.align,
+                                     1u, t);
+                        const A wy0 = (A)1 - t.dy, wx0 = (A)1 - t.dx;
+                        Rec4<A> w;
+                        w.v[0] = a * (wy0 * wx0);
+                        w.v[1] = a * (wy0 * t.dx);
+                        w.v[2] = a * (t.dy * wx0);
+                        w.v[3] = a * (t.dy * t.dx);
+                        const int rslot = fu * scp + (sl - s0);
+                        w_off[rslot] =
+                            record_offsets(t, STAGE ? lds.plan->off[l] : -1, STAGE ? lds.plan->zero_off : 0, row_b, tab->start[l],
+                                           row_bytes);
+                        w_rec[rslot] = w;
+                    }
                 }
-            }
-            __syncthreads();
-            // ---- phase 2: gather + blend ----
-            if (lane_ok) {
-                const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
-                const uint4 *uo = s_off + unit * scp;
-                const Rec4<A> *uw = s_wt + unit * scp;
+                wave_lds_sync();
+                // ---- phase 2: gather + blend, one level (run of samples) at a time ----
+                if (lane_ok) {
+                    const uint4 *uo = w_off + wunit * scp;
+                    const Rec4<A> *uw = w_rec + wunit * scp;
+                    int s = 0;
+                    while (s < sc) {
+                        const int l = (s0 + s) / p.P;  // uniform
+                        const int run_end = min(sc, (l + 1) * p.P - s0);
+                        if (STAGE && lds.plan->off[l] >= 0) {
 #pragma unroll 4
-                for (int s = 0; s < sc; ++s) {
-                    const uint4 o = uo[s];
-                    const Rec4<A> w = uw[s];
-                    A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-                    load_row<T, VEC>(rs, o.x + lane_off, v0);
-                    load_row<T, VEC>(rs, o.y + lane_off, v1);
-                    load_row<T, VEC>(rs, o.z + lane_off, v2);
-                    load_row<T, VEC>(rs, o.w + lane_off, v3);
+                            for (; s < run_end; ++s) {
+                                const uint4 o = uo[s];
+                                const Rec4<A> w = uw[s];
+                                A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                                lds_row<T, VEC>(lds.stage, o.x + lane_off, v0);
+                                lds_row<T, VEC>(lds.stage, o.y + lane_off, v1);
+                                lds_row<T, VEC>(lds.stage, o.z + lane_off, v2);
+                                lds_row<T, VEC>(lds.stage, o.w + lane_off, v3);
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i)
-                        acc[i] += w.v[0] * v0[i] + w.v[1] * v1[i] + w.v[2] * v2[i] + w.v[3] * v3[i];
+                                for (int i = 0; i < VEC; ++i) {  // four chained FMAs per channel: no product tree to re-pack
+                                    acc[i] = fma_t(w.v[0], v0[i], acc[i]);
+                                    acc[i] = fma_t(w.v[1], v1[i], acc[i]);
+                                    acc[i] = fma_t(w.v[2], v2[i], acc[i]);
+                                    acc[i] = fma_t(w.v[3], v3[i], acc[i]);
+                                }
+                            }
+                        } else {
+#pragma unroll 4
+                            for (; s < run_end; ++s) {
+                                const uint4 o = uo[s];
+                                const Rec4<A> w = uw[s];
+                                A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                                load_row<T, VEC>(rs, o.x + lane_off, v0);
+                                load_row<T, VEC>(rs, o.y + lane_off, v1);
+                                load_row<T, VEC>(rs, o.z + lane_off, v2);
+                                load_row<T, VEC>(rs, o.w + lane_off, v3);
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) {  // four chained FMAs per channel: no product tree to re-pack
+                                    acc[i] = fma_t(w.v[0], v0[i], acc[i]);
+                                    acc[i] = fma_t(w.v[1], v1[i], acc[i]);
+                                    acc[i] = fma_t(w.v[2], v2[i], acc[i]);
+                                    acc[i] = fma_t(w.v[3], v3[i], acc[i]);
+                                }
+                            }
+                        }
+                    }
                 }
             }
-        }
-        if (lane_ok) {
-            Pack<T, VEC> o;
+            if (lane_ok) {
+                Pack<T, VEC> o;
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) o.v[i] = TR::from_acc(acc[i]);
-            T *dst = static_cast<T *>(p.out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D + c0;
-            *reinterpret_cast<Pack<T, VEC> *>(dst) = o;
+                for (int i = 0; i < VEC; ++i) o.v[i] = TR::from_acc(acc[i]);
+                T *dst = static_cast<T *>(p.out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D + c0;
+                *reinterpret_cast<Pack<T, VEC> *>(dst) = o;
+            }
         }
     }
 }
@@ -164,235 +324,161 @@ __global__ __launch_bounds__(kBlock) void msda_fwd_kernel(const Params p)
 // backward, part 1: grad_loc and grad_attn.  Same decomposition as the forward; every sample's
 // three results are reduced over the unit's G lanes with DPP moves and written exactly once.
 // ==========================================================================================
-template <typename T, int VEC, int G>
-__global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
+template <typename T, int VEC, int G, int BLOCK, bool STAGE>
+__global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
-    constexpr int NU = kBlock / G;
+    constexpr int NU = BLOCK / G;
+    constexpr int UPW = kWave / G;
 
-    int pair, qc;
-    if (!decode_block(blockIdx.x, p.B * p.H, p.nqc, p.xcd_map, pair, qc)) return;
-    const int b = pair / p.H, h = pair - b * p.H;
-    const int q0 = qc * NU;
+    const int slots = (p.nqc + p.qw - 1) / p.qw;
+    int pair, slot;
+    if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
+    const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
 
-    LevelTab *tab = reinterpret_cast<LevelTab *>(msda_smem);
     const int scp = p.sc + 1;
-    uint4 *s_off = reinterpret_cast<uint4 *>(msda_smem + sizeof(LevelTab));
     // record in : {dx, dy, a*sx*gx_on, a*sy*gy_on};  record out (same slot): {gA, gX, gY, -}
-    Rec4<A> *s_par = reinterpret_cast<Rec4<A> *>(s_off + NU * scp);
-
-    load_level_table(tab, p.shapes, p.L);
-
-    const int tid = threadIdx.x;
-    const int unit = tid / G, j = tid % G;
-    const int q = q0 + unit;
-    const bool unit_ok = q < p.Q;
+    const GatherLds<A> lds(NU, scp);
+    LevelTab *tab = lds.tab;
 
     const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);
+    const int row_b = p.D * (int)sizeof(T);
     const T *plane = static_cast<const T *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
     const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(T));
     const rsrc_t rs = make_rsrc(plane, plane_bytes);
 
-    const T *loc = static_cast<const T *>(p.loc);
-    const T *attn = static_cast<const T *>(p.attn);
+    load_level_table(tab, p.shapes, p.L);
+    __syncthreads();
+    if constexpr (STAGE) {
+        stage_levels<T, BLOCK>(tab, lds.plan, lds.stage, rs, row_bytes, row_b, p.stage_bytes, p.L);
+        __syncthreads();
+    }
+
+    const int tid = threadIdx.x;
+    const int wave = tid / kWave, lane = tid % kWave;
+    const int wunit = lane / G, j = lane % G;
+    uint4 *w_off = lds.s_off + wave * UPW * scp;
+    Rec4<A> *w_rec = lds.s_rec + wave * UPW * scp;
+    // per-plane bases (64-bit, uniform) + 32-bit per-sample indices (the host checks Q*H*L*P*2 < 2^31)
+    const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
+    const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
+    const T *attn = static_cast<const T *>(p.attn) + plane_s0;
+    const int HLP = p.H * p.LP;
     const float inv_P = 1.0f / (float)p.P;
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
+    const int qc_end = min(p.nqc, (slot + 1) * p.qw);
 
-    for (int s0 = 0; s0 < p.LP; s0 += p.sc) {
-        const int sc = min(p.sc, p.LP - s0);
-        const float inv_sc = 1.0f / (float)sc;
-        __syncthreads();
-        // ---- phase 1 ----
-        for (int f = tid; f < NU * sc; f += kBlock) {
-            const int fu = div_small(f, sc, inv_sc);
-            const int sl = s0 + (f - fu * sc);
-            const int fq = q0 + fu;
-            if (fq < p.Q) {
-                const int l = div_small(sl, p.P, inv_P);
-                const size_t sidx = ((size_t)(b * (size_t)p.Q + fq) * p.H + h) * p.LP + sl;
-                const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
-                const A a = TR::to_acc(attn[sidx]);
-                const int lh = tab->h[l], lw = tab->w[l];
-                Taps<A> t;
-                make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), lh, lw, tab->start[l], p.zeros, p.align,
-                             row_bytes, t);
-                const A sx = p.align ? (A)(lw - 1) : (A)lw;
-                const A sy = p.align ? (A)(lh - 1) : (A)lh;
-                Rec4<A> r;
-                r.v[0] = t.dx;
-                r.v[1] = t.dy;
-                r.v[2] = t.gx_on ? a * sx : (A)0;
-                r.v[3] = t.gy_on ? a * sy : (A)0;
-                const int slot = fu * scp + (sl - s0);
-                s_off[slot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
-                s_par[slot] = r;
+    for (int qc = slot * p.qw; qc < qc_end; ++qc) {
+        const int wq0 = qc * NU + wave * UPW;
+        if (wq0 >= p.Q) break;
+        const int q = wq0 + wunit;
+        const bool unit_ok = q < p.Q;
+        for (int s0 = 0; s0 < p.LP; s0 += p.sc) {
+            const int sc = min(p.sc, p.LP - s0);
+            const float inv_sc = 1.0f / (float)sc;
+            wave_lds_sync();
+            // ---- phase 1 ----
+            for (int f = lane; f < UPW * sc; f += kWave) {
+                const int fu = div_small(f, sc, inv_sc);
+                const int sl = s0 + (f - fu * sc);
+                const int fq = wq0 + fu;
+                if (fq < p.Q) {
+                    const int l = div_small(sl, p.P, inv_P);
+                    const int sidx = fq * HLP + sl;
+                    const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                    const A a = TR::to_acc(attn[sidx]);
+                    const int lh = tab->h[l], lw = tab->w[l];
+                    Taps<A> t;
+                    make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), lh, lw, 0, p.zeros, p.align, 1u, t);
+                    const A sx = p.align ? (A)(lw - 1) : (A)lw;
+                    const A sy = p.align ? (A)(lh - 1) : (A)lh;
+                    Rec4<A> r;
+                    r.v[0] = t.dx;
+                    r.v[1] = t.dy;
+                    r.v[2] = t.gx_on ? a * sx : (A)0;
+                    r.v[3] = t.gy_on ? a * sy : (A)0;
+                    const int rslot = fu * scp + (sl - s0);
+                    w_off[rslot] =
+                        record_offsets(t, STAGE ? lds.plan->off[l] : -1, STAGE ? lds.plan->zero_off : 0, row_b, tab->start[l],
+                                           row_bytes);
+                    w_rec[rslot] = r;
+                }
             }
-        }
-        __syncthreads();
-        // ---- phase 2: four dot products with grad_out per sample, reduced over the unit ----
-        if (unit_ok) {  // wave-divergent only at the ragged tail; idle lanes of a live unit still join the DPP sums
-            const uint4 *uo = s_off + unit * scp;
-            Rec4<A> *up = s_par + unit * scp;
-            const T *go_row = static_cast<const T *>(p.grad_out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D;
-            for (int s = 0; s < sc; ++s) {
-                const uint4 o = uo[s];
-                const Rec4<A> r = up[s];
-                A d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-                for (int cc = 0; cc < nchan_chunks; ++cc) {
-                    const int c0 = (cc * G + j) * VEC;
-                    if (c0 < p.D) {
-                        const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
-                        const Pack<T, VEC> gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
-                        A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-                        load_row<T, VEC>(rs, o.x + lane_off, v0);
-                        load_row<T, VEC>(rs, o.y + lane_off, v1);
-                        load_row<T, VEC>(rs, o.z + lane_off, v2);
-                        load_row<T, VEC>(rs, o.w + lane_off, v3);
+            wave_lds_sync();
+            // ---- phase 2: four dot products with grad_out per sample, reduced over the unit ----
+            if (unit_ok) {  // idle lanes of a live unit still join the DPP sums
+                const uint4 *uo = w_off + wunit * scp;
+                Rec4<A> *up = w_rec + wunit * scp;
+                const T *go_row = static_cast<const T *>(p.grad_out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D;
+                for (int s = 0; s < sc; ++s) {
+                    const int l = (s0 + s) / p.P;  // uniform
+                    const bool staged = STAGE && lds.plan->off[l] >= 0;
+                    const uint4 o = uo[s];
+                    const Rec4<A> r = up[s];
+                    A d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                    for (int cc = 0; cc < nchan_chunks; ++cc) {
+                        const int c0 = (cc * G + j) * VEC;
+                        if (c0 < p.D) {
+                            const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
+                            const Pack<T, VEC> gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
+                            A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                            if (staged) {
+                                lds_row<T, VEC>(lds.stage, o.x + lane_off, v0);
+                                lds_row<T, VEC>(lds.stage, o.y + lane_off, v1);
+                                lds_row<T, VEC>(lds.stage, o.z + lane_off, v2);
+                                lds_row<T, VEC>(lds.stage, o.w + lane_off, v3);
+                            } else {
+                                load_row<T, VEC>(rs, o.x + lane_off, v0);
+                                load_row<T, VEC>(rs, o.y + lane_off, v1);
+                                load_row<T, VEC>(rs, o.z + lane_off, v2);
+                                load_row<T, VEC>(rs, o.w + lane_off, v3);
+                            }
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) {
-                            const A g = TR::to_acc(gp.v[i]);
-                            d0 += g * v0[i];
-                            d1 += g * v1[i];
-                            d2 += g * v2[i];
-                            d3 += g * v3[i];
+                            for (int i = 0; i < VEC; ++i) {
+                                const A g = TR::to_acc(gp.v[i]);
+                                d0 += g * v0[i];
+                                d1 += g * v1[i];
+                                d2 += g * v2[i];
+                                d3 += g * v3[i];
+                            }
                         }
                     }
-                }
-                const A dx = r.v[0], dy = r.v[1];
-                const A wy0 = (A)1 - dy, wx0 = (A)1 - dx;
-                A gA = (wy0 * wx0) * d0 + (wy0 * dx) * d1 + (dy * wx0) * d2 + (dy * dx) * d3;
-                A gX = wy0 * (d1 - d0) + dy * (d3 - d2);
-                A gY = wx0 * (d2 - d0) + dx * (d3 - d1);
-                gA = group_sum<G>(gA);
-                gX = group_sum<G>(gX);
-                gY = group_sum<G>(gY);
-                if (j == 0) {
-                    Rec4<A> res;
-                    res.v[0] = gA;
-                    res.v[1] = r.v[2] * gX;
-                    res.v[2] = r.v[3] * gY;
-                    res.v[3] = (A)0;
-                    up[s] = res;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- phase 3: coalesced write-out, one sample per thread ----
-        for (int f = tid; f < NU * sc; f += kBlock) {
-            const int fu = div_small(f, sc, inv_sc);
-            const int sl = s0 + (f - fu * sc);
-            const int fq = q0 + fu;
-            if (fq < p.Q) {
-                const size_t sidx = ((size_t)(b * (size_t)p.Q + fq) * p.H + h) * p.LP + sl;
-                const Rec4<A> res = s_par[fu * scp + (sl - s0)];
-                static_cast<T *>(p.grad_attn)[sidx] = TR::from_acc(res.v[0]);
-                Pack<T, 2> g;
-                g.v[0] = TR::from_acc(res.v[1]);
-                g.v[1] = TR::from_acc(res.v[2]);
-                *reinterpret_cast<Pack<T, 2> *>(static_cast<T *>(p.grad_loc) + 2 * sidx) = g;
-            }
-        }
-    }
-}
-
-// ==========================================================================================
-// backward, part 2: grad_value without global atomics.  A workgroup OWNS a tile of grad_value:
-// one (b, h) plane x CH channels x a contiguous pixel range, held as accumulate-typed sums in
-// LDS.  It streams every sample of its plane whose level intersects the range, adds the four
-// corner contributions into LDS (ds_add_f32 / ds_add_f64) and finally stores the tile with plain
-// stores; every element of grad_value is written exactly once, so no memset is needed either.
-// ==========================================================================================
-constexpr int kValueBlock = 1024;
-using TileAcc = double;
-
-template <typename T, int CH>
-__global__ __launch_bounds__(kValueBlock) void msda_bwd_value_kernel(const Params p)
-{
-    using A = typename Traits<T>::acc;
-    using TR = Traits<T>;
-
-    int pair, tile;
-    if (!decode_block(blockIdx.x, p.B * p.H, p.nchunks * p.nranges, p.xcd_map, pair, tile)) return;
-    const int b = pair / p.H, h = pair - b * p.H;
-    const int range = tile / p.nchunks, chunk = tile - range * p.nchunks;
-    const int p0 = range * p.range_px;
-    const int p1 = min(p.I, p0 + p.range_px);
-    const int npx = p1 - p0;
-    if (npx <= 0) return;
-
-    LevelTab *tab = reinterpret_cast<LevelTab *>(msda_smem);
-    // Tile sums are double whatever the storage type: on gfx950 ds_add_f64 retires a wave-instruction
-    // in ~21 cycles while ds_add_f32 takes ~193 (measured, tools/lds_atomic_bench.hip) — and the
-    // wider sums make the scatter order irrelevant at fp32 output precision.  Layout [CH][npx]
-    // (channel-major) spreads a wave's pixels over all LDS banks.
-    TileAcc *s_acc = reinterpret_cast<TileAcc *>(msda_smem + sizeof(LevelTab));
-
-    load_level_table(tab, p.shapes, p.L);
-    const int tid = threadIdx.x;
-    for (int i = tid; i < npx * CH; i += kValueBlock) s_acc[i] = (TileAcc)0;
-    __syncthreads();
-
-    // levels intersecting [p0, p1) form an interval [la, lb)
-    int la = p.L, lb = 0;
-    for (int l = 0; l < p.L; ++l) {
-        const int ls = tab->start[l], le = ls + tab->h[l] * tab->w[l];
-        if (le > p0 && ls < p1) {
-            la = min(la, l);
-            lb = max(lb, l + 1);
-        }
-    }
-    const int nl = lb - la;
-    if (nl > 0) {
-        const int m = nl * p.P;  // samples of one unit that can touch this tile
-        const float inv_P = 1.0f / (float)p.P;
-        const T *loc = static_cast<const T *>(p.loc);
-        const T *attn = static_cast<const T *>(p.attn);
-        const T *gout = static_cast<const T *>(p.grad_out);
-        const int c0 = chunk * CH;
-        // (q, r) walk the flattened (query, sample-in-interval) space with stride kValueBlock
-        int q = tid / m, r = tid - q * m;
-        const int dq = kValueBlock / m, dr = kValueBlock - dq * m;
-        for (; q < p.Q;) {
-            const int li = div_small(r, p.P, inv_P);
-            const int l = la + li;
-            const size_t u = (size_t)(b * (size_t)p.Q + q) * p.H + h;
-            const size_t sidx = u * p.LP + (size_t)la * p.P + r;
-            const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
-            const A a = TR::to_acc(attn[sidx]);
-            const Pack<T, CH> gp = *reinterpret_cast<const Pack<T, CH> *>(gout + u * p.D + c0);
-            Taps<A> t;
-            make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], tab->start[l], p.zeros,
-                         p.align, /*row_bytes=*/1u, t);  // offsets == pixel indices here
-            const A wy0 = (A)1 - t.dy, wx0 = (A)1 - t.dx;
-            A w[4] = {a * (wy0 * wx0), a * (wy0 * t.dx), a * (t.dy * wx0), a * (t.dy * t.dx)};
-            A g[CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) g[c] = TR::to_acc(gp.v[c]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t rel = t.off[k] - (uint32_t)p0;  // masked / out-of-range wrap to huge values
-                if (rel < (uint32_t)npx) {
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) atomicAdd(&s_acc[c * npx + rel], (TileAcc)(w[k] * g[c]));
+                    const A dx = r.v[0], dy = r.v[1];
+                    const A wy0 = (A)1 - dy, wx0 = (A)1 - dx;
+                    A gA = (wy0 * wx0) * d0 + (wy0 * dx) * d1 + (dy * wx0) * d2 + (dy * dx) * d3;
+                    A gX = wy0 * (d1 - d0) + dy * (d3 - d2);
+                    A gY = wx0 * (d2 - d0) + dx * (d3 - d1);
+                    gA = group_sum<G>(gA);
+                    gX = group_sum<G>(gX);
+                    gY = group_sum<G>(gY);
+                    if (j == 0) {
+                        Rec4<A> res;
+                        res.v[0] = gA;
+                        res.v[1] = r.v[2] * gX;
+                        res.v[2] = r.v[3] * gY;
+                        res.v[3] = (A)0;
+                        up[s] = res;
+                    }
                 }
             }
-            q += dq;
-            r += dr;
-            if (r >= m) {
-                r -= m;
-                ++q;
+            wave_lds_sync();
+            // ---- phase 3: coalesced write-out, one sample per lane and trip ----
+            for (int f = lane; f < UPW * sc; f += kWave) {
+                const int fu = div_small(f, sc, inv_sc);
+                const int sl = s0 + (f - fu * sc);
+                const int fq = wq0 + fu;
+                if (fq < p.Q) {
+                    const int sidx = fq * HLP + sl;
+                    const Rec4<A> res = w_rec[fu * scp + (sl - s0)];
+                    static_cast<T *>(p.grad_attn)[plane_s0 + sidx] = TR::from_acc(res.v[0]);
+                    Pack<T, 2> g;
+                    g.v[0] = TR::from_acc(res.v[1]);
+                    g.v[1] = TR::from_acc(res.v[2]);
+                    *reinterpret_cast<Pack<T, 2> *>(static_cast<T *>(p.grad_loc) + 2 * (plane_s0 + sidx)) = g;
+                }
             }
         }
-    }
-    __syncthreads();
-    // tile write-out: CH contiguous channels per pixel
-    T *gv = static_cast<T *>(p.grad_value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D + chunk * CH;
-    for (int i = tid; i < npx; i += kValueBlock) {
-        Pack<T, CH> o;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) o.v[c] = TR::from_acc((A)s_acc[c * npx + i]);
-        *reinterpret_cast<Pack<T, CH> *>(gv + (size_t)(p0 + i) * p.H * p.D) = o;
     }
 }
 

@@ -5,15 +5,19 @@
 #include <stdio.h>
 
 #include "msda_value_sorted.hpp"
+#include "msda_value_tile.hpp"
 
 namespace msda {
 
 // ---- process-wide options and per-thread error text (defined in msda_api.hip) ----
 int option_xcd_map();
 int option_value_path();  // 0: sorted gather when a workspace is supplied (default), 1: always LDS tiles
+int option_stage_kb();    // LDS KiB a gather workgroup may spend on staged pyramid levels (0: off)
+int option_gather_block();  // threads per gather workgroup when staging is on (256 / 512 / 1024)
+int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
 void set_error(const char *fmt, ...);
 
-constexpr int kGatherLdsBudget = 60 * 1024;                // per workgroup, gather kernels
+constexpr int kRecordLdsBudget = 40 * 1024;                // per workgroup, parked sample records
 constexpr int kValueLdsBudget = 160 * 1024 - 2048;         // per workgroup, grad_value tiles
 constexpr int kMaxDynLds = 160 * 1024 - 2048;  // leaves room for small static __shared__ objects
 
@@ -48,7 +52,7 @@ inline int check_common(const Dims &d, int padding_mode, const void *const *ptrs
     }
     const int64_t lim = (int64_t)1 << 31;
     if (d.I * d.H * d.D * (int64_t)sizeof(T) >= lim || d.B >= lim || d.Q >= lim || d.L * d.P >= (1 << 22) ||
-        d.B * d.H >= (1 << 28)) {
+        d.B * d.H >= (1 << 28) || d.Q * d.H * d.L * d.P * 2 >= lim || d.Q * d.H * d.D >= lim) {
         set_error("tensor too large for 32-bit plane offsets (I*H*D*sizeof = %lld bytes)",
                   (long long)(d.I * d.H * d.D * (int64_t)sizeof(T)));
         return MSDA_ERR_TOO_LARGE;
@@ -62,6 +66,42 @@ inline int check_common(const Dims &d, int padding_mode, const void *const *ptrs
     return 0;
 }
 
+// Grid for a (plane, slot) decomposition.  Prefers the 3-D shapes whose linear dispatch order equals
+// decode_block's 1-D formula, so the kernel needs no integer division; falls back to 1-D when a
+// dimension would exceed the 65535 limit.  Returns false if even the 1-D grid is too large.
+inline bool plane_grid(Params &p, int npairs, int64_t slots, dim3 &grid)
+{
+    if (slots < 1) slots = 1;
+    const int64_t groups = (npairs + 7) / 8;
+    if (p.xcd_map && slots <= 65535 && groups <= 65535) {
+        p.grid3d = 1;
+        grid = dim3(8, (unsigned)slots, (unsigned)groups);
+        return true;
+    }
+    if (!p.xcd_map && npairs <= 65535 && slots < ((int64_t)1 << 31)) {
+        p.grid3d = 1;
+        grid = dim3((unsigned)slots, (unsigned)npairs);
+        return true;
+    }
+    p.grid3d = 0;
+    const int64_t blocks = (p.xcd_map ? groups * 8 : (int64_t)npairs) * slots;
+    if (blocks >= ((int64_t)1 << 31)) return false;
+    grid = dim3((unsigned)blocks);
+    return true;
+}
+
+inline FastDiv make_fast_div(uint32_t d)
+{
+    FastDiv fd{0, 0};
+    if (d <= 1) return fd;
+    uint32_t shift = 0;
+    while ((1ull << shift) < d) ++shift;  // ceil(log2 d)
+    const uint64_t m = ((1ull << (32 + shift)) / d) - (1ull << 32) + 1;  // fits 32 bits for d > 1
+    fd.magic = (uint32_t)m;
+    fd.shift = shift;
+    return fd;
+}
+
 inline int pick_group(int lanes_needed)
 {
     if (lanes_needed <= 4) return 4;
@@ -71,34 +111,70 @@ inline int pick_group(int lanes_needed)
     return 64;
 }
 
-// samples of a unit parked in LDS at a time, and the resulting dynamic LDS size
-inline void plan_gather(int G, int LP, size_t acc_bytes, int &sc, size_t &lds)
+// samples of a unit parked in LDS at a time (records), staged-level bytes, total dynamic LDS
+inline void plan_gather(int NU, int LP, size_t acc_bytes, int stage_want, int row_b, int &sc, int &stage_bytes,
+                        size_t &lds)
 {
-    const int NU = kBlock / G;
     const size_t rec = 16 + 4 * acc_bytes;
-    const size_t room = kGatherLdsBudget - sizeof(LevelTab);
-    int cap = (int)(room / (NU * rec)) - 1;
+    const size_t rec_budget = NU > 64 ? (size_t)96 * 1024 : (size_t)kRecordLdsBudget;
+    int cap = (int)(rec_budget / (NU * rec)) - 1;
     if (cap < 1) cap = 1;
     sc = LP < cap ? LP : cap;
-    lds = sizeof(LevelTab) + (size_t)NU * (sc + 1) * rec;
+    const size_t base = kGatherLdsFixed + (size_t)NU * (sc + 1) * rec;
+    long long stage = stage_want;
+    if (stage > (long long)kMaxDynLds - (long long)base) stage = (long long)kMaxDynLds - (long long)base;
+    if (stage < 2LL * row_b) stage = 0;  // not even the zero row plus one pixel
+    stage_bytes = (int)stage;
+    lds = base + (size_t)stage_bytes;
+}
+
+template <typename T, int VEC, int G, bool BWD, int BLOCK> inline int launch_gather_block(Params &p, hipStream_t stream)
+{
+    using A = typename Traits<T>::acc;
+    constexpr int NU = BLOCK / G;
+    size_t lds;
+    const int stage_want = VEC > 1 ? option_stage_kb() * 1024 : 0;
+    plan_gather(NU, p.LP, sizeof(A), stage_want, p.D * (int)sizeof(T), p.sc, p.stage_bytes, lds);
+    p.nqc = (p.Q + NU - 1) / NU;
+    const int npairs = p.B * p.H;
+    // query chunks per workgroup: amortise the level staging, but keep the chip full
+    long long qw = ((long long)p.nqc * npairs) / option_wg_target();
+    p.qw = (int)(qw < 1 ? 1 : qw > 64 ? 64 : qw);
+    const int slots = (p.nqc + p.qw - 1) / p.qw;
+    dim3 grid;
+    if (!plane_grid(p, npairs, slots, grid)) {
+        set_error("grid too large");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    if (p.stage_bytes > 0) {
+        auto kernel = BWD ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, true> : msda_fwd_kernel<T, VEC, G, BLOCK, true>;
+        static bool big_lds_ok = false;
+        if (!big_lds_ok) {
+            allow_big_lds(kernel);
+            big_lds_ok = true;
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(BLOCK), lds, stream, p);
+    } else {
+        auto kernel = BWD ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, false> : msda_fwd_kernel<T, VEC, G, BLOCK, false>;
+        static bool big_lds_ok = false;
+        if (!big_lds_ok) {
+            allow_big_lds(kernel);
+            big_lds_ok = true;
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(BLOCK), lds, stream, p);
+    }
+    return (int)hipGetLastError();
 }
 
 template <typename T, int VEC, int G, bool BWD> inline int launch_gather(Params &p, hipStream_t stream)
 {
-    using A = typename Traits<T>::acc;
-    constexpr int NU = kBlock / G;
-    size_t lds;
-    plan_gather(G, p.LP, sizeof(A), p.sc, lds);
-    p.nqc = (p.Q + NU - 1) / NU;
-    const int npairs = p.B * p.H;
-    const int64_t blocks = (int64_t)(p.xcd_map ? ((npairs + 7) / 8) * 8 : npairs) * p.nqc;
-    if (blocks >= ((int64_t)1 << 31)) {
-        set_error("grid too large");
-        return MSDA_ERR_TOO_LARGE;
+    // staged levels are shared by a whole workgroup: use the biggest one (16 waves) when staging is on
+    if (VEC > 1 && option_stage_kb() > 0) {
+        const int blk = option_gather_block();
+        if (blk == 1024) return launch_gather_block<T, VEC, G, BWD, 1024>(p, stream);
+        if (blk == 512) return launch_gather_block<T, VEC, G, BWD, 512>(p, stream);
     }
-    auto kernel = BWD ? msda_bwd_sample_kernel<T, VEC, G> : msda_fwd_kernel<T, VEC, G>;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(kBlock), lds, stream, p);
-    return (int)hipGetLastError();
+    return launch_gather_block<T, VEC, G, BWD, kBlock>(p, stream);
 }
 
 template <typename T, int VEC, bool BWD> inline int dispatch_group(Params &p, hipStream_t stream)
@@ -130,8 +206,8 @@ template <typename T, int CH> inline int launch_value(Params &p, hipStream_t str
     p.range_px = (p.I + p.nranges - 1) / p.nranges;
     const size_t lds = sizeof(LevelTab) + (size_t)p.range_px * px_bytes;
     const int npairs = p.B * p.H;
-    const int64_t blocks = (int64_t)(p.xcd_map ? ((npairs + 7) / 8) * 8 : npairs) * p.nchunks * p.nranges;
-    if (blocks >= ((int64_t)1 << 31)) {
+    dim3 grid;
+    if (!plane_grid(p, npairs, (int64_t)p.nchunks * p.nranges, grid)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
@@ -140,7 +216,7 @@ template <typename T, int CH> inline int launch_value(Params &p, hipStream_t str
         allow_big_lds(msda_bwd_value_kernel<T, CH>);
         big_lds_ok = true;
     }
-    hipLaunchKernelGGL((msda_bwd_value_kernel<T, CH>), dim3((unsigned)blocks), dim3(kValueBlock), lds, stream, p);
+    hipLaunchKernelGGL((msda_bwd_value_kernel<T, CH>), grid, dim3(kValueBlock), lds, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -161,14 +237,17 @@ template <typename T, int VEC, int G> inline int launch_value_gather(Params &p, 
 {
     constexpr int NU = kBlock / G;
     const int npairs = p.B * p.H;
-    const int64_t ppairs = p.xcd_map ? ((npairs + 7) / 8) * 8 : npairs;
-    const int64_t b4 = ppairs * ((p.it_cap + NU - 1) / NU), b5 = ppairs * ((p.I + NU - 1) / NU);
-    if (b4 >= ((int64_t)1 << 31) || b5 >= ((int64_t)1 << 31)) {
+    dim3 g4, g5;
+    if (!plane_grid(p, npairs, (p.it_cap + NU - 1) / NU, g4)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G>), dim3((unsigned)b4), dim3(kBlock), 0, stream, p);
-    hipLaunchKernelGGL((msda_value_finish_kernel<T, VEC, G>), dim3((unsigned)b5), dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G>), g4, dim3(kBlock), 0, stream, p);
+    if (!plane_grid(p, npairs, (p.I + NU - 1) / NU, g5)) {
+        set_error("grid too large");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    hipLaunchKernelGGL((msda_value_finish_kernel<T, VEC, G>), g5, dim3(kBlock), 0, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -201,12 +280,12 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
     p.nsplit = w.nsplit;
     p.cell_cap = w.nc_cap < kCellLdsInts ? w.nc_cap : kCellLdsInts;
     const int npairs = p.B * p.H;
-    const int64_t ppairs = p.xcd_map ? ((npairs + 7) / 8) * 8 : npairs;
-    const int64_t bcell = ppairs * p.nsplit;
-    if (bcell >= ((int64_t)1 << 31)) {
+    dim3 gcell;
+    if (!plane_grid(p, npairs, p.nsplit, gcell)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
+    const int cell_grid3d = p.grid3d;
     const size_t cell_lds = sizeof(LevelTab) + (size_t)p.cell_cap * sizeof(int);
     static bool big_lds_ok = false;
     if (!big_lds_ok) {
@@ -214,7 +293,7 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
         allow_big_lds(msda_cell_pass_kernel<T, true>);
         big_lds_ok = true;
     }
-    hipLaunchKernelGGL((msda_cell_pass_kernel<T, false>), dim3((unsigned)bcell), dim3(kCellBlock), cell_lds, stream, p);
+    hipLaunchKernelGGL((msda_cell_pass_kernel<T, false>), gcell, dim3(kCellBlock), cell_lds, stream, p);
     const int64_t tot_blocks = (int64_t)((p.nc_cap + kBlock - 1) / kBlock) * npairs;
     if (tot_blocks >= ((int64_t)1 << 31)) {
         set_error("grid too large");
@@ -228,7 +307,8 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
         scan_lds_ok = true;
     }
     hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)npairs), dim3(kCellBlock), scan_lds, stream, p);
-    hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), dim3((unsigned)bcell), dim3(kCellBlock), cell_lds, stream, p);
+    p.grid3d = cell_grid3d;
+    hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     constexpr int VECF = 16 / sizeof(T);
@@ -250,6 +330,10 @@ inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_co
     p.align = align_corners != 0;
     p.xcd_map = option_xcd_map();
     p.nqc = p.sc = p.nchunks = p.nranges = p.range_px = 0;
+    p.qw = 1;
+    p.stage_bytes = 0;
+    p.grid3d = 0;
+    p.div_h = make_fast_div((uint32_t)d.H);
 }
 
 template <typename T>

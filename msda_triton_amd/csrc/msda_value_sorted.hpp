@@ -57,14 +57,14 @@ __device__ __forceinline__ bool sample_cell(A x, A y, int h, int w, int cstart, 
     }
     A x0, y0;
     if (zeros) {
-        x0 = __builtin_floor(px);
-        y0 = __builtin_floor(py);
+        x0 = floor_t(px);
+        y0 = floor_t(py);
         if (!(x0 >= (A)-1 && x0 <= W - (A)1 && y0 >= (A)-1 && y0 <= Hh - (A)1)) return false;  // also NaN
     } else {
-        px = __builtin_fmin(__builtin_fmax(px, (A)0), W - (A)1);
-        py = __builtin_fmin(__builtin_fmax(py, (A)0), Hh - (A)1);
-        x0 = __builtin_floor(px);
-        y0 = __builtin_floor(py);
+        px = fmin_t(fmax_t(px, (A)0), W - (A)1);
+        py = fmin_t(fmax_t(py, (A)0), Hh - (A)1);
+        x0 = floor_t(px);
+        y0 = floor_t(py);
     }
     dx = px - x0;
     dy = py - y0;
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     int pair, slice;
-    if (!decode_block(blockIdx.x, p.B * p.H, p.nsplit, p.xcd_map, pair, slice)) return;
-    const int b = pair / p.H, h = pair - b * p.H;
+    if (!decode_block(p.grid3d, p.B * p.H, p.nsplit, p.xcd_map, pair, slice)) return;
+    const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int qper = (p.Q + p.nsplit - 1) / p.nsplit;
     const int qa = min(p.Q, slice * qper), qb = min(p.Q, qa + qper);
 
@@ -294,13 +294,13 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
     constexpr int UB = G < 8 ? G : 8;  // row loads in flight per lane
     const int slots = (p.it_cap + NU - 1) / NU;
     int pair, slot;
-    if (!decode_block(blockIdx.x, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
+    if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
     const int nitems = p.ws_itemcnt[pair];
     const int tid = threadIdx.x;
     const int unit = tid / G, j = tid % G;
     const int item = slot * NU + unit;
     if (item >= nitems) return;
-    const int b = pair / p.H, h = pair - b * p.H;
+    const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int lane_base = (tid & (kWave - 1)) & ~(G - 1);
 
     const int4 it = p.ws_items[(size_t)pair * p.it_cap + item];
@@ -398,8 +398,8 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
     constexpr int NU = kBlock / G;
     const int slots = (p.I + NU - 1) / NU;
     int pair, slot;
-    if (!decode_block(blockIdx.x, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
-    const int b = pair / p.H, h = pair - b * p.H;
+    if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
+    const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int unit = threadIdx.x / G, j = threadIdx.x % G;
     const int pix = slot * NU + unit;
     if (pix >= p.I) return;
