@@ -14,6 +14,7 @@ static std::atomic<int> g_value_path{0};
 static std::atomic<int> g_stage_kb{0};
 static std::atomic<int> g_gather_block{1024};
 static std::atomic<int> g_wg_target{1 << 30};
+static std::atomic<int> g_debug{0};
 static thread_local char g_err[256] = "";
 
 int option_xcd_map() { return g_xcd_map.load(std::memory_order_relaxed); }
@@ -21,6 +22,7 @@ int option_value_path() { return g_value_path.load(std::memory_order_relaxed); }
 int option_stage_kb() { return g_stage_kb.load(std::memory_order_relaxed); }
 int option_gather_block() { return g_gather_block.load(std::memory_order_relaxed); }
 int option_wg_target() { return g_wg_target.load(std::memory_order_relaxed); }
+int option_debug() { return g_debug.load(std::memory_order_relaxed); }
 
 void set_error(const char *fmt, ...)
 {
@@ -64,6 +66,10 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_gather_block.store(value, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "debug") == 0) {
+        msda::g_debug.store(value, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "wg_target") == 0 && value >= 1) {
         msda::g_wg_target.store(value, std::memory_order_relaxed);
         return 0;
@@ -79,6 +85,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "stage_kb") == 0) return msda::option_stage_kb();
     if (key && strcmp(key, "gather_block") == 0) return msda::option_gather_block();
     if (key && strcmp(key, "wg_target") == 0) return msda::option_wg_target();
+    if (key && strcmp(key, "debug") == 0) return msda::option_debug();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

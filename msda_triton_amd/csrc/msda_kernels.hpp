@@ -42,6 +42,7 @@ struct Params {
     int stage_bytes;  // LDS bytes available for staged levels (0: no staging)
     int zeros, align, xcd_map;
     int grid3d;       // this launch uses the division-free 3-D grid (see decode_block)
+    int debug;        // dev-only ablation mask (msda_set_option("debug", m)); 0 in normal use
     FastDiv div_h;    // pair -> (b, h)
     // grad_value tile kernel
     int nchunks;   // channel chunks (D / CH)
@@ -411,39 +412,8 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                 const uint4 *uo = w_off + wunit * scp;
                 Rec4<A> *up = w_rec + wunit * scp;
                 const T *go_row = static_cast<const T *>(p.grad_out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D;
-                for (int s = 0; s < sc; ++s) {
-                    const int l = (s0 + s) / p.P;  // uniform
-                    const bool staged = STAGE && lds.plan->off[l] >= 0;
-                    const uint4 o = uo[s];
-                    const Rec4<A> r = up[s];
-                    A d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-                    for (int cc = 0; cc < nchan_chunks; ++cc) {
-                        const int c0 = (cc * G + j) * VEC;
-                        if (c0 < p.D) {
-                            const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
-                            const Pack<T, VEC> gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
-                            A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-                            if (staged) {
-                                lds_row<T, VEC>(lds.stage, o.x + lane_off, v0);
-                                lds_row<T, VEC>(lds.stage, o.y + lane_off, v1);
-                                lds_row<T, VEC>(lds.stage, o.z + lane_off, v2);
-                                lds_row<T, VEC>(lds.stage, o.w + lane_off, v3);
-                            } else {
-                                load_row<T, VEC>(rs, o.x + lane_off, v0);
-                                load_row<T, VEC>(rs, o.y + lane_off, v1);
-                                load_row<T, VEC>(rs, o.z + lane_off, v2);
-                                load_row<T, VEC>(rs, o.w + lane_off, v3);
-                            }
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) {
-                                const A g = TR::to_acc(gp.v[i]);
-                                d0 += g * v0[i];
-                                d1 += g * v1[i];
-                                d2 += g * v2[i];
-                                d3 += g * v3[i];
-                            }
-                        }
-                    }
+                // one sample's epilogue: combine the four dot products, reduce over the unit, park the result
+                auto finish = [&](int s, const Rec4<A> &r, A d0, A d1, A d2, A d3) {
                     const A dx = r.v[0], dy = r.v[1];
                     const A wy0 = (A)1 - dy, wx0 = (A)1 - dx;
                     A gA = (wy0 * wx0) * d0 + (wy0 * dx) * d1 + (dy * wx0) * d2 + (dy * dx) * d3;
@@ -459,6 +429,97 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                         res.v[2] = r.v[3] * gY;
                         res.v[3] = (A)0;
                         up[s] = res;
+                    }
+                };
+                if (nchan_chunks == 1) {
+                    // fast path: grad_out row in registers, UB samples' rows (4 * UB loads) in flight at once
+                    constexpr int UB = 4;
+                    const int c0 = j * VEC;
+                    const bool lane_in = c0 < p.D;
+                    const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
+                    A g[VEC];
+                    {
+                        Pack<T, VEC> gp;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) gp.v[i] = TR::from_acc((A)0);
+                        if (lane_in) gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) g[i] = TR::to_acc(gp.v[i]);
+                    }
+                    for (int sb = 0; sb < sc; sb += UB) {
+                        uint4 o[UB];
+                        Rec4<A> r[UB];
+                        A v[UB][4][VEC];
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            const int s = min(sb + u, sc - 1);  // tail: recompute the last sample, its store is skipped
+                            o[u] = uo[s];
+                            r[u] = up[s];
+                        }
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            const int s = min(sb + u, sc - 1);
+                            const bool staged = STAGE && lds.plan->off[(s0 + s) / p.P] >= 0;  // uniform
+                            const uint32_t lo = lane_in ? lane_off : 0u;
+                            if (staged) {
+                                lds_row<T, VEC>(lds.stage, o[u].x + lo, v[u][0]);
+                                lds_row<T, VEC>(lds.stage, o[u].y + lo, v[u][1]);
+                                lds_row<T, VEC>(lds.stage, o[u].z + lo, v[u][2]);
+                                lds_row<T, VEC>(lds.stage, o[u].w + lo, v[u][3]);
+                            } else {
+                                load_row<T, VEC>(rs, o[u].x + lo, v[u][0]);
+                                load_row<T, VEC>(rs, o[u].y + lo, v[u][1]);
+                                load_row<T, VEC>(rs, o[u].z + lo, v[u][2]);
+                                load_row<T, VEC>(rs, o[u].w + lo, v[u][3]);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            A d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                d0 = fma_t(g[i], v[u][0][i], d0);
+                                d1 = fma_t(g[i], v[u][1][i], d1);
+                                d2 = fma_t(g[i], v[u][2][i], d2);
+                                d3 = fma_t(g[i], v[u][3][i], d3);
+                            }
+                            if (sb + u < sc) finish(sb + u, r[u], d0, d1, d2, d3);  // uniform
+                        }
+                    }
+                } else {
+                    for (int s = 0; s < sc; ++s) {
+                        const bool staged = STAGE && lds.plan->off[(s0 + s) / p.P] >= 0;  // uniform
+                        const uint4 o = uo[s];
+                        const Rec4<A> r = up[s];
+                        A d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                        for (int cc = 0; cc < nchan_chunks; ++cc) {
+                            const int c0 = (cc * G + j) * VEC;
+                            if (c0 < p.D) {
+                                const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
+                                const Pack<T, VEC> gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
+                                A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                                if (staged) {
+                                    lds_row<T, VEC>(lds.stage, o.x + lane_off, v0);
+                                    lds_row<T, VEC>(lds.stage, o.y + lane_off, v1);
+                                    lds_row<T, VEC>(lds.stage, o.z + lane_off, v2);
+                                    lds_row<T, VEC>(lds.stage, o.w + lane_off, v3);
+                                } else {
+                                    load_row<T, VEC>(rs, o.x + lane_off, v0);
+                                    load_row<T, VEC>(rs, o.y + lane_off, v1);
+                                    load_row<T, VEC>(rs, o.z + lane_off, v2);
+                                    load_row<T, VEC>(rs, o.w + lane_off, v3);
+                                }
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) {
+                                    const A gg = TR::to_acc(gp.v[i]);
+                                    d0 = fma_t(gg, v0[i], d0);
+                                    d1 = fma_t(gg, v1[i], d1);
+                                    d2 = fma_t(gg, v2[i], d2);
+                                    d3 = fma_t(gg, v3[i], d3);
+                                }
+                            }
+                        }
+                        finish(s, r, d0, d1, d2, d3);
                     }
                 }
             }

@@ -15,6 +15,7 @@ int option_value_path();  // 0: sorted gather when a workspace is supplied (defa
 int option_stage_kb();    // LDS KiB a gather workgroup may spend on staged pyramid levels (0: off)
 int option_gather_block();  // threads per gather workgroup when staging is on (256 / 512 / 1024)
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
+int option_debug();         // dev-only ablation mask
 void set_error(const char *fmt, ...);
 
 constexpr int kRecordLdsBudget = 40 * 1024;                // per workgroup, parked sample records
@@ -333,6 +334,7 @@ inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_co
     p.qw = 1;
     p.stage_bytes = 0;
     p.grid3d = 0;
+    p.debug = option_debug();
     p.div_h = make_fast_div((uint32_t)d.H);
 }
 

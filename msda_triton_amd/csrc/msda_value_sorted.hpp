@@ -111,18 +111,35 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
         const int n = min(cap, ncells - c0);
         for (int i = tid; i < n; i += kCellBlock) {
             int v = 0;
-            if constexpr (PLACE) {  // this slice's first slot in every cell list
-                v = off[c0 + i];
-                for (int jj = 0; jj < slice; ++jj) v += part[(size_t)jj * p.nc_cap + c0 + i];
-            }
+            if constexpr (PLACE)  // this slice's first slot in every cell list
+                v = off[c0 + i] + part[(size_t)slice * p.nc_cap + c0 + i];
             s_cell[i] = v;
         }
         __syncthreads();
+        // software-pipelined walk: the next sample's (x, y, a) are requested before this sample's entry is
+        // stored, so the wait for them never has to drain the scattered store behind it (one vmcnt queue)
         int q = qa + tid / p.LP, sl = tid % p.LP;
-        while (q < qb) {
-            const int l = div_small(sl, p.P, inv_P);
+        Pack<T, 2> xy, xy_n;
+        T at = TR::from_acc((A)0), at_n = at;
+        xy.v[0] = xy.v[1] = at;
+        xy_n = xy;
+        if (q < qb) {
             const size_t sidx = ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.LP + sl;
-            const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+            xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+            if constexpr (PLACE) at = attn[sidx];
+        }
+        while (q < qb) {
+            int qn = q + dq, sn = sl + dr;
+            if (sn >= p.LP) {
+                sn -= p.LP;
+                ++qn;
+            }
+            if (qn < qb) {
+                const size_t sidx_n = ((size_t)(b * (size_t)p.Q + qn) * p.H + h) * p.LP + sn;
+                xy_n = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx_n);
+                if constexpr (PLACE) at_n = attn[sidx_n];
+            }
+            const int l = div_small(sl, p.P, inv_P);
             int cell;
             A dx, dy;
             if (sample_cell<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], tab->cstart[l], p.zeros,
@@ -137,17 +154,16 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
                         e.q = (uint32_t)q;
                         e.dx = dx;
                         e.dy = dy;
-                        e.a = TR::to_acc(attn[sidx]);
-                        entries[pos] = e;
+                        e.a = TR::to_acc(at);
+                        if (!(p.debug & 1)) entries[pos] = e;
+                        else if (pos == -7) entries[0] = e;
                     }
                 }
             }
-            q += dq;
-            sl += dr;
-            if (sl >= p.LP) {
-                sl -= p.LP;
-                ++q;
-            }
+            q = qn;
+            sl = sn;
+            xy = xy_n;
+            at = at_n;
         }
         __syncthreads();
         if constexpr (!PLACE) {
@@ -158,7 +174,8 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
 }
 
 // ------------------------------------------------------------------------------------------
-// K2a: off[cell] = number of samples in the cell (sum over the query slices); grid (cell blocks, planes)
+// K2a: off[cell] = number of samples in the cell (sum over the query slices), and part[j][cell] becomes
+// the exclusive prefix over the slices (slice j's first slot relative to the start of the cell's list)
 // ------------------------------------------------------------------------------------------
 template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_total_kernel(const Params p)
 {
@@ -166,9 +183,23 @@ template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_tota
     const int pair = blockIdx.x / per_plane;
     const int c = (blockIdx.x - pair * per_plane) * kBlock + threadIdx.x;
     if (c >= p.nc_cap) return;  // cells beyond the plane's real count hold garbage that nobody reads
-    const int *part = p.ws_part + (size_t)pair * p.nsplit * p.nc_cap;
+    int *part = p.ws_part + (size_t)pair * p.nsplit * p.nc_cap + c;
     int tot = 0;
-    for (int j = 0; j < p.nsplit; ++j) tot += part[(size_t)j * p.nc_cap + c];
+    int j = 0;
+    for (; j + 4 <= p.nsplit; j += 4) {  // four independent loads in flight
+        const int n0 = part[(size_t)(j + 0) * p.nc_cap], n1 = part[(size_t)(j + 1) * p.nc_cap];
+        const int n2 = part[(size_t)(j + 2) * p.nc_cap], n3 = part[(size_t)(j + 3) * p.nc_cap];
+        part[(size_t)(j + 0) * p.nc_cap] = tot;
+        part[(size_t)(j + 1) * p.nc_cap] = tot + n0;
+        part[(size_t)(j + 2) * p.nc_cap] = tot + n0 + n1;
+        part[(size_t)(j + 3) * p.nc_cap] = tot + n0 + n1 + n2;
+        tot += n0 + n1 + n2 + n3;
+    }
+    for (; j < p.nsplit; ++j) {
+        const int n = part[(size_t)j * p.nc_cap];
+        part[(size_t)j * p.nc_cap] = tot;
+        tot += n;
+    }
     p.ws_off[(size_t)pair * (p.nc_cap + 1) + c] = tot;
 }
 
@@ -199,25 +230,14 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *s_wave, int &tot
     return base + inc - v;
 }
 
-template <typename Tag> __global__ __launch_bounds__(kCellBlock) void msda_cell_scan_kernel(const Params p)
+// The scans proper.  `off` points either at the LDS copy or at global memory; the function is inlined
+// at both call sites so every access has a known address space (a run-time pointer select would turn
+// them all into slow FLAT operations).
+__device__ __forceinline__ void cell_scan_body(int *off, const LevelTab &tab, int *s_wave, const Params &p, int pair,
+                                               int nc, int *goff_copy)
 {
-    const int pair = blockIdx.x;
-    __shared__ LevelTab tab;
-    __shared__ int s_wave[kCellBlock / kWave];
-    int *s_off = reinterpret_cast<int *>(msda_smem);
-    load_level_table(&tab, p.shapes, p.L);
-    __syncthreads();
     const int t = threadIdx.x;
     const int last = p.L - 1;
-    const int nc = plane_cells(tab, p.L);
-    int *goff = p.ws_off + (size_t)pair * (p.nc_cap + 1);
-    const bool in_lds = nc + 1 <= p.cell_cap + 1;  // the launch sized the dynamic LDS for cell_cap + 1 ints
-    int *off = in_lds ? s_off : goff;
-
-    if (in_lds) {
-        for (int c = t; c < nc; c += kCellBlock) s_off[c] = goff[c];
-        __syncthreads();
-    }
     // ---- A: exclusive scan of the per-cell totals ----
     {
         const int seg = (nc + kCellBlock - 1) / kCellBlock;
@@ -235,50 +255,68 @@ template <typename Tag> __global__ __launch_bounds__(kCellBlock) void msda_cell_
     }
     __threadfence_block();
     __syncthreads();
-    if (in_lds)
-        for (int c = t; c <= nc; c += kCellBlock) goff[c] = s_off[c];
+    if (goff_copy != nullptr)
+        for (int c = t; c <= nc; c += kCellBlock) goff_copy[c] = off[c];
 
+    if (p.debug & 2) return;
     // ---- B: per-pixel list records and work items ----
-    {
-        const int seg = (p.I + kCellBlock - 1) / kCellBlock;
-        const int lo = min(p.I, t * seg), hi = min(p.I, lo + seg);
-        int4 *pixrec = p.ws_pixrec + (size_t)pair * p.I * 3;
-        int4 *items = p.ws_items + (size_t)pair * p.it_cap;
-        // pass 1: lists of every pixel of this thread's segment -> pixrec, count chunks
-        int sum = 0, l = 0;
-        for (int pix = lo; pix < hi; ++pix) {
-            while (l < last && pix >= tab.start[l + 1]) ++l;
-            const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
-            const int y = rel / w, x = rel - y * w;
-            const int c11 = tab.cstart[l] + y * cw + x;  // cell (x0 = x-1, y0 = y-1): this pixel is its corner 11
-            // list i = samples for which the pixel is corner i: 00 -> cell (x, y), 01 -> (x-1, y), 10 -> (x, y-1), 11
-            const int cells[4] = {c11 + cw + 1, c11 + cw, c11 + 1, c11};
-            int4 beg, len;
-            beg.x = off[cells[0]];
-            len.x = off[cells[0] + 1] - beg.x;
-            beg.y = off[cells[1]];
-            len.y = off[cells[1] + 1] - beg.y;
-            beg.z = off[cells[2]];
-            len.z = off[cells[2] + 1] - beg.z;
-            beg.w = off[cells[3]];
-            len.w = off[cells[3] + 1] - beg.w;
-            const int n = len.x + len.y + len.z + len.w;
-            const int chunks = max(1, (n + kChunk - 1) / kChunk);
-            pixrec[(size_t)pix * 3 + 0] = beg;
-            pixrec[(size_t)pix * 3 + 1] = len;
-            pixrec[(size_t)pix * 3 + 2] = make_int4(0, chunks, 0, 0);
-            sum += chunks;
-        }
-        int total;
-        int run = block_exclusive_scan(sum, s_wave, total);
-        // pass 2: item table (each thread re-reads the chunk counts it just wrote)
-        for (int pix = lo; pix < hi; ++pix) {
-            const int chunks = pixrec[(size_t)pix * 3 + 2].y;
-            pixrec[(size_t)pix * 3 + 2] = make_int4(run, chunks, 0, 0);
-            for (int k = 0; k < chunks; ++k) items[run + k] = make_int4(pix, k, chunks, 0);
-            run += chunks;
-        }
-        if (t == 0) p.ws_itemcnt[pair] = total;
+    const int seg = (p.I + kCellBlock - 1) / kCellBlock;
+    const int lo = min(p.I, t * seg), hi = min(p.I, lo + seg);
+    int4 *pixrec = p.ws_pixrec + (size_t)pair * p.I * 3;
+    int4 *items = p.ws_items + (size_t)pair * p.it_cap;
+    // the four incident cell lists of a pixel (list i = samples for which the pixel is corner i)
+    auto lists_of = [&](int pix, int &l, int4 &beg, int4 &len) {
+        while (l < last && pix >= tab.start[l + 1]) ++l;
+        const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
+        const int y = rel / w, x = rel - y * w;
+        const int c11 = tab.cstart[l] + y * cw + x;  // cell (x0 = x-1, y0 = y-1): this pixel is its corner 11
+        const int c00 = c11 + cw + 1, c01 = c11 + cw, c10 = c11 + 1;
+        beg.x = off[c00];
+        len.x = off[c00 + 1] - beg.x;
+        beg.y = off[c01];
+        len.y = off[c01 + 1] - beg.y;
+        beg.z = off[c10];
+        len.z = off[c10 + 1] - beg.z;
+        beg.w = off[c11];
+        len.w = off[c11 + 1] - beg.w;
+        return max(1, (len.x + len.y + len.z + len.w + kChunk - 1) / kChunk);
+    };
+    // pass 1: count the work items of this thread's pixel segment (no stores: nothing to wait for)
+    int sum = 0, l = 0;
+    int4 beg, len;
+    for (int pix = lo; pix < hi; ++pix) sum += lists_of(pix, l, beg, len);
+    int total;
+    int run = block_exclusive_scan(sum, s_wave, total);
+    // pass 2: recompute and write the pixel records and the item table
+    l = 0;
+    for (int pix = lo; pix < hi; ++pix) {
+        const int chunks = lists_of(pix, l, beg, len);
+        pixrec[(size_t)pix * 3 + 0] = beg;
+        pixrec[(size_t)pix * 3 + 1] = len;
+        pixrec[(size_t)pix * 3 + 2] = make_int4(run, chunks, 0, 0);
+        for (int k = 0; k < chunks; ++k) items[run + k] = make_int4(pix, k, chunks, 0);
+        run += chunks;
+    }
+    if (t == 0) p.ws_itemcnt[pair] = total;
+}
+
+template <typename Tag> __global__ __launch_bounds__(kCellBlock) void msda_cell_scan_kernel(const Params p)
+{
+    const int pair = blockIdx.x;
+    __shared__ LevelTab tab;
+    __shared__ int s_wave[kCellBlock / kWave];
+    int *s_off = reinterpret_cast<int *>(msda_smem);
+    load_level_table(&tab, p.shapes, p.L);
+    __syncthreads();
+    const int t = threadIdx.x;
+    const int nc = plane_cells(tab, p.L);
+    int *goff = p.ws_off + (size_t)pair * (p.nc_cap + 1);
+    if (nc <= p.cell_cap) {  // the launch sized the dynamic LDS for cell_cap + 1 ints
+        for (int c = t; c < nc; c += kCellBlock) s_off[c] = goff[c];
+        __syncthreads();
+        cell_scan_body(s_off, tab, s_wave, p, pair, nc, goff);
+    } else {
+        cell_scan_body(goff, tab, s_wave, p, pair, nc, nullptr);
     }
 }
 
@@ -311,11 +349,12 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
     const int w0 = chunk * kChunk, w1 = min(n, w0 + kChunk);  // this item's window of the virtual list
 
     const Entry<A> *entries = static_cast<const Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
-    const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;
-    const size_t q_stride = (size_t)p.H * p.D;
+    const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
+    const uint32_t q_stride = (uint32_t)(p.H * p.D);  // elements; q * q_stride < 2^31 is checked on the host
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
 
-    // position v of the pixel's virtual list (lists 0..3 back to back) -> (query, a * fx * fy)
+    // position v of the pixel's virtual list (lists 0..3 back to back) -> (element offset of the query's
+    // grad_out row inside the plane, a * fx * fy)
     auto fetch = [&](int v, uint32_t &q, A &wgt) {
         q = 0;
         wgt = (A)0;
@@ -325,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
             const Entry<A> e = entries[base + v];
             const A fx = (i & 1) ? e.dx : (A)1 - e.dx;
             const A fy = (i & 2) ? e.dy : (A)1 - e.dy;
-            q = e.q;
+            q = e.q * q_stride;
             wgt = e.a * (fy * fx);
         }
     };
@@ -352,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
                 for (int u = 0; u < UB; ++u) {
                     const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj + u, kWave);
                     wgt[u] = __shfl(cur_w, lane_base + jj + u, kWave);
-                    g[u] = *reinterpret_cast<const Pack<T, VEC> *>(grow + q * q_stride);
+                    g[u] = *reinterpret_cast<const Pack<T, VEC> *>(grow + ((p.debug & 4) ? 0u : q));
                 }
 #pragma unroll
                 for (int u = 0; u < UB; ++u)
@@ -362,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
             for (; jj < cnt; ++jj) {
                 const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj, kWave);
                 const A wg = __shfl(cur_w, lane_base + jj, kWave);
-                const Pack<T, VEC> g = *reinterpret_cast<const Pack<T, VEC> *>(grow + q * q_stride);
+                const Pack<T, VEC> g = *reinterpret_cast<const Pack<T, VEC> *>(grow + q);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[v] += wg * TR::to_acc(g.v[v]);
             }

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Dev tool: time fwd / bwd kernels on every BASELINE workload (random device-side inputs)."""
+import json
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from msda_triton_amd import synth, _lib
+from msda_triton_amd.functional import KernelTimer, msda_hip_fwd, msda_hip_bwd
+
+dev = "cuda:0"
+names = sys.argv[1:] or list(synth.WORKLOADS)
+for name in names:
+    wl = synth.WORKLOADS[name]
+    dt = getattr(torch, wl.dtype)
+    torch.manual_seed(0)
+    v = torch.randn(wl.B, wl.I, wl.H, wl.D, device=dev, dtype=torch.float32).to(dt)
+    s = torch.tensor(wl.levels, device=dev)
+    l = torch.rand(wl.B, wl.Q, wl.H, wl.L, wl.P, 2, device=dev, dtype=torch.float32).to(dt)
+    a = torch.softmax(torch.randn(wl.B, wl.Q, wl.H, wl.L, wl.P, device=dev), -1).to(dt)
+    g = torch.rand(wl.B, wl.Q, wl.H, wl.D, device=dev, dtype=torch.float32).to(dt)
+    pm, ac = wl.padding_mode, wl.align_corners
+    for _ in range(3):
+        msda_hip_fwd(v, s, l, a, pm, ac)
+        msda_hip_bwd(g, v, s, l, a, pm, ac)
+    torch.cuda.synchronize()
+    with KernelTimer() as kt:
+        for _ in range(10):
+            msda_hip_fwd(v, s, l, a, pm, ac)
+            msda_hip_bwd(g, v, s, l, a, pm, ac)
+        torch.cuda.synchronize()
+    res = {k: round(ms * 1e3, 1) for k, (n, ms) in kt.summary().items()}
+    fwd_us = res["msda_fwd"]
+    print(json.dumps({"workload": name, "dtype": wl.dtype, "us": res,
+                      "fwd_alg_GBs": round(wl.alg_fwd_bytes / fwd_us / 1e3, 1),
+                      "fwd_gather_TBs": round(wl.gather_fwd_bytes / fwd_us / 1e6, 2),
+                      "ws_MB": round(_lib.load().msda_bwd_workspace_bytes(wl.B, wl.I, wl.H, wl.D, wl.Q, wl.L, wl.P, v.element_size()) / 1e6, 1)}))
+    del v, l, a, g
+    torch.cuda.empty_cache()
