@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--workload", default="c2_q10k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--xcd-map", type=int, default=None, help="override the blockIdx->(b,h) mapping (A/B runs)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and use the sharded code path even with one rank (self-test)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="msda_set_option override for A/B runs, e.g. --opt stage_kb=0 --opt value_path=1")
     args = ap.parse_args()
@@ -113,9 +115,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     if args.xcd_map is not None:
         _lib.set_option("xcd_map", args.xcd_map)
     for kv in args.opt:
@@ -131,7 +135,7 @@ def main():
     pts, attn = d["loc"].requires_grad_(True), d["attn"].requires_grad_(True)
 
     def op():
-        if world == 1:
+        if not use_dist:
             return multiscale_deformable_attention(img, shapes, pts, attn, pm, ac)
         return sharded_multiscale_deformable_attention(img, shapes, pts, attn, pm, ac, inputs_are_sharded=True,
                                                        num_queries=gwl.Q)
@@ -147,7 +151,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -158,7 +162,7 @@ def main():
             fn()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -225,7 +229,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

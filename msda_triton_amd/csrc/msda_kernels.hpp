@@ -51,9 +51,9 @@ struct Params {
     // sorted (gather-formulated) grad_value path: caller-provided workspace, see msda_value_sorted.hpp
     int *ws_part;       // [pairs][nsplit][nc_cap]  per-slice cell counts, then each slice's first slot per cell
     int *ws_off;        // [pairs][nc_cap+1]  exclusive offsets of the cell lists
-    int4 *ws_pixrec;    // [pairs][I][3]      per pixel: list starts, list lengths, (first item, chunks, -, -)
+    int2 *ws_pixinfo;   // [pairs][I]         per pixel: (first work item, number of chunks)
     int *ws_itemcnt;    // [pairs]            work items of the plane
-    int4 *ws_items;     // [pairs][it_cap]    (pixel, chunk, chunks of the pixel, -)
+    int4 *ws_items;     // [pairs][it_cap][3] per work item: (pixel, chunks of the pixel, -, -), 4 entry-list starts, 4 lengths
     void *ws_entries;   // [pairs][Q*L*P]     Entry<acc>: sample records sorted by cell
     void *ws_scratch;   // [pairs][it_cap][D] acc-typed partial rows of multi-chunk pixels
     int nc_cap, it_cap;

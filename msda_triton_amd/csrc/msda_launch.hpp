@@ -271,7 +271,7 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     p.ws_part = reinterpret_cast<int *>(ws + w.off_part);
     p.ws_off = reinterpret_cast<int *>(ws + w.off_off);
-    p.ws_pixrec = reinterpret_cast<int4 *>(ws + w.off_pixrec);
+    p.ws_pixinfo = reinterpret_cast<int2 *>(ws + w.off_pixinfo);
     p.ws_itemcnt = reinterpret_cast<int *>(ws + w.off_itemcnt);
     p.ws_items = reinterpret_cast<int4 *>(ws + w.off_items);
     p.ws_entries = ws + w.off_entries;
@@ -308,6 +308,12 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
         scan_lds_ok = true;
     }
     hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)npairs), dim3(kCellBlock), scan_lds, stream, p);
+    dim3 gitem;
+    if (!plane_grid(p, npairs, (p.I + kBlock - 1) / kBlock, gitem)) {
+        set_error("grid too large");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    hipLaunchKernelGGL((msda_item_kernel<T>), gitem, dim3(kBlock), 0, stream, p);
     p.grid3d = cell_grid3d;
     hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
     int rc = (int)hipGetLastError();

@@ -262,39 +262,27 @@ __device__ __forceinline__ void cell_scan_body(int *off, const LevelTab &tab, in
     // ---- B: per-pixel list records and work items ----
     const int seg = (p.I + kCellBlock - 1) / kCellBlock;
     const int lo = min(p.I, t * seg), hi = min(p.I, lo + seg);
-    int4 *pixrec = p.ws_pixrec + (size_t)pair * p.I * 3;
-    int4 *items = p.ws_items + (size_t)pair * p.it_cap;
-    // the four incident cell lists of a pixel (list i = samples for which the pixel is corner i)
-    auto lists_of = [&](int pix, int &l, int4 &beg, int4 &len) {
+    int2 *pixinfo = p.ws_pixinfo + (size_t)pair * p.I;
+    // chunks of a pixel = ceil(entries of its four incident cells / kChunk), at least one (it writes the row)
+    auto chunks_of = [&](int pix, int &l) {
         while (l < last && pix >= tab.start[l + 1]) ++l;
         const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
         const int y = rel / w, x = rel - y * w;
         const int c11 = tab.cstart[l] + y * cw + x;  // cell (x0 = x-1, y0 = y-1): this pixel is its corner 11
-        const int c00 = c11 + cw + 1, c01 = c11 + cw, c10 = c11 + 1;
-        beg.x = off[c00];
-        len.x = off[c00 + 1] - beg.x;
-        beg.y = off[c01];
-        len.y = off[c01 + 1] - beg.y;
-        beg.z = off[c10];
-        len.z = off[c10 + 1] - beg.z;
-        beg.w = off[c11];
-        len.w = off[c11 + 1] - beg.w;
-        return max(1, (len.x + len.y + len.z + len.w + kChunk - 1) / kChunk);
+        const int n = (off[c11 + 1] - off[c11]) + (off[c11 + 2] - off[c11 + 1]) +
+                      (off[c11 + cw + 1] - off[c11 + cw]) + (off[c11 + cw + 2] - off[c11 + cw + 1]);
+        return max(1, (n + kChunk - 1) / kChunk);
     };
-    // pass 1: count the work items of this thread's pixel segment (no stores: nothing to wait for)
+    // pass 1: count the work items of this thread's pixel segment
     int sum = 0, l = 0;
-    int4 beg, len;
-    for (int pix = lo; pix < hi; ++pix) sum += lists_of(pix, l, beg, len);
+    for (int pix = lo; pix < hi; ++pix) sum += chunks_of(pix, l);
     int total;
     int run = block_exclusive_scan(sum, s_wave, total);
-    // pass 2: recompute and write the pixel records and the item table
+    // pass 2: first item of every pixel (the records themselves are written by msda_item_kernel)
     l = 0;
     for (int pix = lo; pix < hi; ++pix) {
-        const int chunks = lists_of(pix, l, beg, len);
-        pixrec[(size_t)pix * 3 + 0] = beg;
-        pixrec[(size_t)pix * 3 + 1] = len;
-        pixrec[(size_t)pix * 3 + 2] = make_int4(run, chunks, 0, 0);
-        for (int k = 0; k < chunks; ++k) items[run + k] = make_int4(pix, k, chunks, 0);
+        const int chunks = chunks_of(pix, l);
+        pixinfo[pix] = make_int2(run, chunks);
         run += chunks;
     }
     if (t == 0) p.ws_itemcnt[pair] = total;
@@ -321,6 +309,53 @@ template <typename Tag> __global__ __launch_bounds__(kCellBlock) void msda_cell_
 }
 
 // ------------------------------------------------------------------------------------------
+// K2c: work-item records, one thread per pixel (all planes in parallel).  Item k of a pixel covers
+// positions [k*kChunk, (k+1)*kChunk) of the pixel's virtual list (its four cell lists back to back);
+// the record holds that window already clipped against the four lists: (start, count) per list.
+// ------------------------------------------------------------------------------------------
+template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_item_kernel(const Params p)
+{
+    const int slots = (p.I + kBlock - 1) / kBlock;
+    int pair, slot;
+    if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
+    __shared__ LevelTab tab;
+    load_level_table(&tab, p.shapes, p.L);
+    __syncthreads();
+    const int pix = slot * kBlock + threadIdx.x;
+    if (pix >= p.I) return;
+    int l = 0;
+    while (l < p.L - 1 && pix >= tab.start[l + 1]) ++l;
+    const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
+    const int y = rel / w, x = rel - y * w;
+    const int c11 = tab.cstart[l] + y * cw + x;
+    // list i = samples for which the pixel is corner i: 00 -> cell (x, y), 01 -> (x-1, y), 10 -> (x, y-1), 11
+    const int cells[4] = {c11 + cw + 1, c11 + cw, c11 + 1, c11};
+    const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
+    int beg[4], len[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        beg[i] = off[cells[i]];
+        len[i] = off[cells[i] + 1] - beg[i];
+    }
+    const int2 info = p.ws_pixinfo[(size_t)pair * p.I + pix];
+    int4 *items = p.ws_items + ((size_t)pair * p.it_cap + info.x) * 3;
+    for (int k = 0; k < info.y; ++k) {
+        const int w0 = k * kChunk, w1 = w0 + kChunk;
+        int st[4], cn[4], pos = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int lo = max(w0 - pos, 0), hi = min(w1 - pos, len[i]);
+            st[i] = beg[i] + lo;
+            cn[i] = max(hi - lo, 0);
+            pos += len[i];
+        }
+        items[k * 3 + 0] = make_int4(pix, info.y, 0, 0);
+        items[k * 3 + 1] = make_int4(st[0], st[1], st[2], st[3]);
+        items[k * 3 + 2] = make_int4(cn[0], cn[1], cn[2], cn[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K4: gather.  G lanes per work item, VEC channels per lane (same shape as the forward gather).
 // ------------------------------------------------------------------------------------------
 template <typename T, int VEC, int G>
@@ -341,12 +376,11 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int lane_base = (tid & (kWave - 1)) & ~(G - 1);
 
-    const int4 it = p.ws_items[(size_t)pair * p.it_cap + item];
-    const int pix = it.x, chunk = it.y, nchunks = it.z;
-    const int4 *rec = p.ws_pixrec + ((size_t)pair * p.I + pix) * 3;
-    const int4 beg = rec[0], len = rec[1];
-    const int c1 = len.x, c2 = c1 + len.y, c3 = c2 + len.z, n = c3 + len.w;
-    const int w0 = chunk * kChunk, w1 = min(n, w0 + kChunk);  // this item's window of the virtual list
+    const int4 *rec = p.ws_items + ((size_t)pair * p.it_cap + item) * 3;
+    const int4 hdr = rec[0], beg = rec[1], len = rec[2];
+    const int pix = hdr.x, nchunks = hdr.y;
+    const int c1 = len.x, c2 = c1 + len.y, c3 = c2 + len.z;
+    const int w0 = 0, w1 = c3 + len.w;  // the record is already clipped to this item's window
 
     const Entry<A> *entries = static_cast<const Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
     const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
@@ -355,17 +389,20 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
 
     // position v of the pixel's virtual list (lists 0..3 back to back) -> (element offset of the query's
     // grad_out row inside the plane, a * fx * fy)
+    // Positions past the end of the window are padded with the window's last record at weight 0 (so the
+    // unrolled batches need no tail loop; an empty window reads row 0 at weight 0).
     auto fetch = [&](int v, uint32_t &q, A &wgt) {
         q = 0;
         wgt = (A)0;
-        if (v < w1) {
-            const int i = (v >= c1) + (v >= c2) + (v >= c3);
+        if (w1 > 0) {
+            const int vc = min(v, w1 - 1);
+            const int i = (vc >= c1) + (vc >= c2) + (vc >= c3);
             const int base = i == 0 ? beg.x : i == 1 ? beg.y - c1 : i == 2 ? beg.z - c2 : beg.w - c3;
-            const Entry<A> e = entries[base + v];
+            const Entry<A> e = entries[base + vc];
             const A fx = (i & 1) ? e.dx : (A)1 - e.dx;
             const A fy = (i & 2) ? e.dy : (A)1 - e.dy;
             q = e.q * q_stride;
-            wgt = e.a * (fy * fx);
+            wgt = v < w1 ? e.a * (fy * fx) : (A)0;
         }
     };
 
@@ -383,27 +420,22 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
         for (int v0 = w0; v0 < w1; v0 += G) {
             fetch(v0 + G + j, nxt_q, nxt_w);  // next batch's records are in flight while this one is consumed
             const int cnt = min(G, w1 - v0);
-            int jj = 0;
-            for (; jj + UB <= cnt; jj += UB) {  // UB row loads issued back to back, then consumed
-                A wgt[UB];
-                Pack<T, VEC> g[UB];
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj + u, kWave);
-                    wgt[u] = __shfl(cur_w, lane_base + jj + u, kWave);
-                    g[u] = *reinterpret_cast<const Pack<T, VEC> *>(grow + ((p.debug & 4) ? 0u : q));
+            for (int jj = 0; jj < G; jj += UB) {  // UB row loads issued back to back, then consumed
+                if (jj < cnt) {                   // uniform per group; G == UB: always true
+                    A wgt[UB];
+                    Pack<T, VEC> g[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj + u, kWave);
+                        wgt[u] = __shfl(cur_w, lane_base + jj + u, kWave);
+                        g[u] = *reinterpret_cast<const Pack<T, VEC> *>(grow + ((p.debug & 4) ? 0u : q));
+                    }
+#pragma unroll
+                    for (int u = 0; u < UB; ++u)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[v] = fma_t(wgt[u], TR::to_acc(g[u].v[v]), acc[v]);
                 }
-#pragma unroll
-                for (int u = 0; u < UB; ++u)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[v] += wgt[u] * TR::to_acc(g[u].v[v]);
-            }
-            for (; jj < cnt; ++jj) {
-                const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj, kWave);
-                const A wg = __shfl(cur_w, lane_base + jj, kWave);
-                const Pack<T, VEC> g = *reinterpret_cast<const Pack<T, VEC> *>(grow + q);
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[v] += wg * TR::to_acc(g.v[v]);
             }
             cur_q = nxt_q;
             cur_w = nxt_w;
@@ -442,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
     const int unit = threadIdx.x / G, j = threadIdx.x % G;
     const int pix = slot * NU + unit;
     if (pix >= p.I) return;
-    const int4 info = p.ws_pixrec[((size_t)pair * p.I + pix) * 3 + 2];
+    const int2 info = p.ws_pixinfo[(size_t)pair * p.I + pix];
     const int item0 = info.x, nchunks = info.y;
     if (nchunks <= 1) return;
     const A *src = static_cast<const A *>(p.ws_scratch) + ((size_t)pair * p.it_cap + item0) * p.D;
@@ -472,7 +504,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
 // ------------------------------------------------------------------------------------------
 struct SortedWsLayout {
     int nc_cap, it_cap, nsplit;
-    size_t off_part, off_off, off_pixrec, off_itemcnt, off_items, off_entries, off_scratch, total;
+    size_t off_part, off_off, off_pixinfo, off_itemcnt, off_items, off_entries, off_scratch, total;
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -497,9 +529,9 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     size_t o = 0;
     w.off_part = o;     o = align_up(o + pairs * w.nsplit * (size_t)w.nc_cap * 4, 256);
     w.off_off = o;      o = align_up(o + pairs * ((size_t)w.nc_cap + 1) * 4, 256);
-    w.off_pixrec = o;   o = align_up(o + pairs * (size_t)I * 48, 256);
+    w.off_pixinfo = o;  o = align_up(o + pairs * (size_t)I * 8, 256);
     w.off_itemcnt = o;  o = align_up(o + pairs * 4, 256);
-    w.off_items = o;    o = align_up(o + pairs * (size_t)w.it_cap * 16, 256);
+    w.off_items = o;    o = align_up(o + pairs * (size_t)w.it_cap * 48, 256);
     w.off_entries = o;  o = align_up(o + pairs * samples * entry_bytes, 256);
     w.off_scratch = o;  o = align_up(o + pairs * (size_t)w.it_cap * (size_t)D * acc_bytes, 256);
     w.total = o;

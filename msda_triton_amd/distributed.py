@@ -123,11 +123,9 @@ def sharded_multiscale_deformable_attention(
         begin, end = shard_bounds(Q, world, rank)
         pts, att = sampling_points[:, begin:end], attention_weights[:, begin:end]
     per = -(-Q // world)
-    if img.requires_grad and world > 1:
+    if img.requires_grad:
         img = _ReplicatedValue.apply(img, group)
     local = multiscale_deformable_attention(img, img_shapes, pts, att, padding_mode, align_corners)
     if local.shape[1] < per:  # short / empty trailing shard: pad so the all-gather is regular
         local = torch.nn.functional.pad(local, (0, 0, 0, 0, 0, per - local.shape[1]))
-    if world == 1:
-        return local[:, :Q]
     return _GatherQueryShards.apply(local, Q, group, grad_sync)

@@ -468,3 +468,75 @@ def test_graph_capture_replays():
     assert torch.equal(out, eager)
     torch.testing.assert_close(grads[0], eager_g[0], atol=1e-4, rtol=1e-4)
     assert torch.equal(grads[1], eager_g[1]) and torch.equal(grads[2], eager_g[2])
+
+
+# ------------------------------------------------------------------------------------------
+# backward grad_value: both implementations, and the shapes that stress the sorted gather
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("value_path", [0, 1], ids=["sorted_gather", "lds_tiles"])
+@pytest.mark.parametrize("pm,ac", MODES, ids=[mode_key(*m) for m in MODES])
+def test_grad_value_both_paths_and_hot_pixels(oracle, value_path, pm, ac):
+    """Every query samples the same few pixels (lists far longer than one work-item chunk, so pixels are
+    split into many chunks and summed by the finish kernel) plus a uniform background."""
+    from msda_triton_amd import _lib
+    rng = np.random.default_rng(31)
+    c = rand_case(rng, 2, 300, 2, 32, [(9, 7), (4, 4), (1, 1)], 4, lo=-0.2, hi=1.2)
+    hot = c["loc"][:, :, :, 0]                       # level 0: concentrate 3/4 of the points around one spot
+    hot[:, :, :, :3] = 0.43 + 0.02 * rng.standard_normal(hot[:, :, :, :3].shape)
+    try:
+        _lib.set_option("value_path", value_path)
+        check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float32], BWD_TOL[torch.float32])
+    finally:
+        _lib.set_option("value_path", 0)
+
+
+def test_grad_value_without_workspace_uses_tile_kernel(oracle):
+    """The C ABI accepts workspace == NULL and then runs the LDS-tile kernel."""
+    from msda_triton_amd import _lib
+    c = rand_case(np.random.default_rng(32), 1, 40, 2, 32, [(6, 6), (3, 3)], 3)
+    v, l, a, g = (torch.from_numpy(c[k]).to(DEV) for k in ("value", "loc", "attn", "grad_out"))
+    s = torch.from_numpy(c["shapes"]).to(DEV)
+    gv, gl, ga = torch.empty_like(v), torch.empty_like(l), torch.empty_like(a)
+    B, I, H, D = v.shape
+    _, Q, _, L, P, _ = l.shape
+    rc = _lib.load().msda_bwd_f32(g.data_ptr(), v.data_ptr(), s.data_ptr(), l.data_ptr(), a.data_ptr(),
+                                  gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, I, H, D, Q, L, P, 1, 0,
+                                  None, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    r_gv, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
+    np.testing.assert_allclose(gv.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
+    np.testing.assert_allclose(ga.cpu().numpy(), r_ga, **BWD_TOL[torch.float32])
+
+
+def test_level_staging_option_gives_same_results():
+    """msda_set_option("stage_kb", n) copies small pyramid levels into LDS; results must not change."""
+    from msda_triton_amd import _lib, synth
+    ops = _ops()
+    d = synth.make_inputs_torch(synth.WORKLOADS["c1_readme"], DEV, seed=6, loc_lo=-0.1, loc_hi=1.1)
+    res = []
+    try:
+        for kb in (0, 48):
+            _lib.set_option("stage_kb", kb)
+            v, l, a = (d[k].clone().requires_grad_(True) for k in ("value", "loc", "attn"))
+            o = ops.multiscale_deformable_attention(v, d["shapes"], l, a, "zeros", False)
+            o.backward(d["grad_out"])
+            res.append((o.detach(), l.grad, a.grad))
+    finally:
+        _lib.set_option("stage_kb", 0)
+    for x, y in zip(res[0], res[1]):
+        torch.testing.assert_close(x, y, atol=1e-6, rtol=1e-6)
+
+
+def test_c_abi_rejects_bad_arguments_without_launching():
+    from msda_triton_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(64, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    p = x.data_ptr()
+    assert lib.msda_fwd_f32(p, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 7, 0, st) == -1          # unknown padding mode
+    assert lib.msda_fwd_f32(p, p, p, p, p, 1, 33, 1, 4, 1, 33, 1, 0, 0, st) == -2        # too many levels
+    assert lib.msda_fwd_f32(p, p, p, p, p, 1, 1 << 28, 8, 64, 1, 1, 1, 0, 0, st) == -3    # plane offsets overflow
+    assert lib.msda_fwd_f32(p + 2, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, st) == -4      # misaligned
+    assert lib.msda_fwd_f32(None, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, st) == -1       # null buffer
+    assert lib.msda_bwd_workspace_bytes(4, 5440, 8, 32, 10000, 4, 4, 4) > 0
