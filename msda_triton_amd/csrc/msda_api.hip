@@ -55,7 +55,7 @@ extern "C" int msda_set_option(const char *key, int value)
         return 0;
     }
     if (key && strcmp(key, "value_path") == 0) {
-        msda::g_value_path.store(value ? 1 : 0, std::memory_order_relaxed);
+        msda::g_value_path.store(value < 0 || value > 2 ? 0 : value, std::memory_order_relaxed);
         return 0;
     }
     if (key && strcmp(key, "stage_kb") == 0 && value >= 0 && value <= 156) {

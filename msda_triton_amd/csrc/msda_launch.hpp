@@ -11,7 +11,7 @@ namespace msda {
 
 // ---- process-wide options and per-thread error text (defined in msda_api.hip) ----
 int option_xcd_map();
-int option_value_path();  // 0: sorted gather when a workspace is supplied (default), 1: always LDS tiles
+int option_value_path();  // 0: auto (sorted gather for big problems, LDS tiles for small), 1: tiles, 2: sorted
 int option_stage_kb();    // LDS KiB a gather workgroup may spend on staged pyramid levels (0: off)
 int option_gather_block();  // threads per gather workgroup when staging is on (256 / 512 / 1024)
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
@@ -434,8 +434,23 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     }
     if (want_value) {
         using A = typename Traits<T>::acc;
-        const bool sorted = option_value_path() == 0 && workspace != nullptr && aligned_to(workspace, 256) &&
-                            (uint64_t)workspace_bytes >= sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A)).total;
+        bool sorted = option_value_path() != 1 && workspace != nullptr && aligned_to(workspace, 256) &&
+                      (uint64_t)workspace_bytes >= sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A)).total;
+        if (sorted && option_value_path() == 0) {
+            // Small problems: the sorted pipeline's six launches cost ~50 us before any work is done, while the
+            // LDS-tile kernel is one launch whose time grows with (workgroup rounds) x (samples per plane).
+            // Measured on MI355X (c1/c2/c4 sweeps): tiles ~2.2 ns per plane-sample and round, sorted ~50 ps per sample.
+            const size_t room = kValueLdsBudget - sizeof(LevelTab);
+            int ch = 0;
+            for (int c : {4, 2, 1})
+                if (!ch && (D % c) == 0 && (size_t)I * c * sizeof(TileAcc) <= room) ch = c;
+            if (ch) {
+                const double s_plane = (double)Q * (double)(L * P), planes = (double)(B * H);
+                const double rounds = (double)((int64_t)(planes * (double)(D / ch) + 255) / 256);
+                const double t_tile = rounds * s_plane * 2.2e-3, t_sorted = 50.0 + planes * s_plane * 5e-5;
+                if (t_tile < t_sorted) sorted = false;
+            }
+        }
         rc = sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
         if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
     }

@@ -9,7 +9,11 @@ from msda_triton_amd import synth, _lib
 from msda_triton_amd.functional import KernelTimer, msda_hip_fwd, msda_hip_bwd
 
 dev = "cuda:0"
-names = sys.argv[1:] or list(synth.WORKLOADS)
+opts = [a for a in sys.argv[1:] if "=" in a]
+for kv in opts:
+    k, v = kv.split("=")
+    _lib.set_option(k, int(v))
+names = [a for a in sys.argv[1:] if "=" not in a] or list(synth.WORKLOADS)
 for name in names:
     wl = synth.WORKLOADS[name]
     dt = getattr(torch, wl.dtype)
