@@ -18,7 +18,7 @@ int option_wg_target();     // gather workgroups to aim for when choosing query 
 int option_debug();         // dev-only ablation mask
 void set_error(const char *fmt, ...);
 
-constexpr int kRecordLdsBudget = 40 * 1024;                // per workgroup, parked sample records
+constexpr int kRecordLdsBudget = 48 * 1024;                // per workgroup, parked sample records
 constexpr int kValueLdsBudget = 160 * 1024 - 2048;         // per workgroup, grad_value tiles
 constexpr int kMaxDynLds = 160 * 1024 - 2048;  // leaves room for small static __shared__ objects
 

@@ -518,7 +518,7 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     w.nc_cap = (int)(2 * I + 2 * L);             // (w+1)(h+1) <= 2wh + 2 per level
     w.it_cap = (int)(I + (4 * samples + kChunk - 1) / kChunk + 1);
     // query slices per plane: enough workgroups to fill the chip, at least ~2k samples each
-    int64_t ns = pairs ? (int64_t)((512 + pairs - 1) / pairs) : 1;
+    int64_t ns = pairs ? (int64_t)((256 + pairs - 1) / pairs) : 1;
     const int64_t by_work = (int64_t)((samples + 2047) / 2048);
     if (ns > by_work) ns = by_work;
     if (ns > 64) ns = 64;
