@@ -33,6 +33,8 @@
 namespace msda {
 
 constexpr int kChunk = 64;           // entries per work item
+constexpr int kItemBuckets = 9;      // work items are bucketed by ceil(entries / 8) = 0..8
+constexpr int kItemMeta = 32;        // ints of per-plane item metadata: total, bucket starts, bucket cursors
 constexpr int kCellBlock = 1024;     // threads of K1 / K2b / K3
 constexpr int kCellLdsInts = 36864;  // cells a workgroup keeps in LDS at a time (144 KiB)
 
@@ -155,8 +157,7 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
                         e.dx = dx;
                         e.dy = dy;
                         e.a = TR::to_acc(at);
-                        if (!(p.debug & 1)) entries[pos] = e;
-                        else if (pos == -7) entries[0] = e;
+                        entries[pos] = e;
                     }
                 }
             }
@@ -258,41 +259,63 @@ __device__ __forceinline__ void cell_scan_body(int *off, const LevelTab &tab, in
     if (goff_copy != nullptr)
         for (int c = t; c <= nc; c += kCellBlock) goff_copy[c] = off[c];
 
-    if (p.debug & 2) return;
     // ---- B: per-pixel list records and work items ----
     const int seg = (p.I + kCellBlock - 1) / kCellBlock;
     const int lo = min(p.I, t * seg), hi = min(p.I, lo + seg);
     int2 *pixinfo = p.ws_pixinfo + (size_t)pair * p.I;
-    // chunks of a pixel = ceil(entries of its four incident cells / kChunk), at least one (it writes the row)
-    auto chunks_of = [&](int pix, int &l) {
+    // entries of a pixel = entries of its four incident cells
+    auto entries_of = [&](int pix, int &l) {
         while (l < last && pix >= tab.start[l + 1]) ++l;
         const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
         const int y = rel / w, x = rel - y * w;
         const int c11 = tab.cstart[l] + y * cw + x;  // cell (x0 = x-1, y0 = y-1): this pixel is its corner 11
-        const int n = (off[c11 + 1] - off[c11]) + (off[c11 + 2] - off[c11 + 1]) +
-                      (off[c11 + cw + 1] - off[c11 + cw]) + (off[c11 + cw + 2] - off[c11 + cw + 1]);
-        return max(1, (n + kChunk - 1) / kChunk);
+        return (off[c11 + 1] - off[c11]) + (off[c11 + 2] - off[c11 + 1]) + (off[c11 + cw + 1] - off[c11 + cw]) +
+               (off[c11 + cw + 2] - off[c11 + cw + 1]);
     };
+    // Work items are executed in buckets of equal batch count (ceil(entries / 8) in 0..8) so that the groups of a
+    // wave finish together; s_bucket counts the plane's items per bucket.
+    int *s_bucket = s_wave + kCellBlock / kWave;  // 9 ints behind the scan scratch (see the kernel's declaration)
+    if (t < kItemBuckets) s_bucket[t] = 0;
     // pass 1: count the work items of this thread's pixel segment
     int sum = 0, l = 0;
-    for (int pix = lo; pix < hi; ++pix) sum += chunks_of(pix, l);
+    int nb_full = 0;
+    __syncthreads();
+    for (int pix = lo; pix < hi; ++pix) {
+        const int n = entries_of(pix, l);
+        const int full = n / kChunk, rem = n - full * kChunk;
+        sum += max(1, full + (rem > 0));
+        nb_full += full;
+        if (rem > 0 || n == 0) atomicAdd(&s_bucket[(rem + 7) / 8], 1);
+    }
+    if (nb_full) atomicAdd(&s_bucket[kItemBuckets - 1], nb_full);
     int total;
     int run = block_exclusive_scan(sum, s_wave, total);
     // pass 2: first item of every pixel (the records themselves are written by msda_item_kernel)
     l = 0;
     for (int pix = lo; pix < hi; ++pix) {
-        const int chunks = chunks_of(pix, l);
+        const int n = entries_of(pix, l);
+        const int chunks = max(1, (n + kChunk - 1) / kChunk);
         pixinfo[pix] = make_int2(run, chunks);
         run += chunks;
     }
-    if (t == 0) p.ws_itemcnt[pair] = total;
+    __syncthreads();
+    if (t == 0) {
+        int *meta = p.ws_itemcnt + (size_t)pair * kItemMeta;
+        meta[0] = total;
+        int start = 0;
+        for (int k = 0; k < kItemBuckets; ++k) {
+            meta[1 + k] = start;            // bucket start
+            meta[1 + kItemBuckets + k] = 0;  // bucket cursor (msda_item_kernel reserves ranges with it)
+            start += s_bucket[k];
+        }
+    }
 }
 
 template <typename Tag> __global__ __launch_bounds__(kCellBlock) void msda_cell_scan_kernel(const Params p)
 {
     const int pair = blockIdx.x;
     __shared__ LevelTab tab;
-    __shared__ int s_wave[kCellBlock / kWave];
+    __shared__ int s_wave[kCellBlock / kWave + kItemBuckets];  // scan scratch + item bucket counters
     int *s_off = reinterpret_cast<int *>(msda_smem);
     load_level_table(&tab, p.shapes, p.L);
     __syncthreads();
@@ -321,8 +344,9 @@ template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_item_kern
     __shared__ LevelTab tab;
     load_level_table(&tab, p.shapes, p.L);
     __syncthreads();
-    const int pix = slot * kBlock + threadIdx.x;
-    if (pix >= p.I) return;
+    const int pix_raw = slot * kBlock + threadIdx.x;
+    const bool pix_ok = pix_raw < p.I;  // idle threads still take part in the barriers below
+    const int pix = pix_ok ? pix_raw : p.I - 1;
     int l = 0;
     while (l < p.L - 1 && pix >= tab.start[l + 1]) ++l;
     const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
@@ -337,8 +361,27 @@ template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_item_kern
         beg[i] = off[cells[i]];
         len[i] = off[cells[i] + 1] - beg[i];
     }
-    const int2 info = p.ws_pixinfo[(size_t)pair * p.I + pix];
-    int4 *items = p.ws_items + ((size_t)pair * p.it_cap + info.x) * 3;
+    const int2 info = pix_ok ? p.ws_pixinfo[(size_t)pair * p.I + pix] : make_int2(0, 0);
+    const int n = len[0] + len[1] + len[2] + len[3];
+    const int full = n / kChunk, rem = n - full * kChunk;
+    const int last_bucket = (rem + 7) / 8;             // bucket of the (possibly empty) partial item
+    const bool has_last = pix_ok && (rem > 0 || n == 0);
+    // reserve slots: first inside the workgroup (LDS), then one global add per bucket and workgroup
+    __shared__ int s_cnt[kItemBuckets], s_base[kItemBuckets];
+    if (threadIdx.x < kItemBuckets) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int rank_full = 0, rank_last = 0;
+    if (pix_ok && full) rank_full = atomicAdd(&s_cnt[kItemBuckets - 1], full);
+    if (has_last) rank_last = atomicAdd(&s_cnt[last_bucket], 1);
+    __syncthreads();
+    int *meta = p.ws_itemcnt + (size_t)pair * kItemMeta;
+    if (threadIdx.x < kItemBuckets) {
+        const int c = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = meta[1 + threadIdx.x] + (c ? atomicAdd(&meta[1 + kItemBuckets + threadIdx.x], c) : 0);
+    }
+    __syncthreads();
+    if (!pix_ok) return;
+    int4 *items = p.ws_items + (size_t)pair * p.it_cap * 3;
     for (int k = 0; k < info.y; ++k) {
         const int w0 = k * kChunk, w1 = w0 + kChunk;
         int st[4], cn[4], pos = 0;
@@ -349,9 +392,12 @@ template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_item_kern
             cn[i] = max(hi - lo, 0);
             pos += len[i];
         }
-        items[k * 3 + 0] = make_int4(pix, info.y, 0, 0);
-        items[k * 3 + 1] = make_int4(st[0], st[1], st[2], st[3]);
-        items[k * 3 + 2] = make_int4(cn[0], cn[1], cn[2], cn[3]);
+        const bool is_full = k < full;
+        const int slot = is_full ? s_base[kItemBuckets - 1] + rank_full + k : s_base[last_bucket] + rank_last;
+        int4 *rec = items + (size_t)slot * 3;
+        rec[0] = make_int4(pix, info.y, info.x + k, 0);  // pixel, chunks of the pixel, scratch row of this chunk
+        rec[1] = make_int4(st[0], st[1], st[2], st[3]);
+        rec[2] = make_int4(cn[0], cn[1], cn[2], cn[3]);
     }
 }
 
@@ -368,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
     const int slots = (p.it_cap + NU - 1) / NU;
     int pair, slot;
     if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
-    const int nitems = p.ws_itemcnt[pair];
+    const int nitems = p.ws_itemcnt[(size_t)pair * kItemMeta];
     const int tid = threadIdx.x;
     const int unit = tid / G, j = tid % G;
     const int item = slot * NU + unit;
@@ -378,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
 
     const int4 *rec = p.ws_items + ((size_t)pair * p.it_cap + item) * 3;
     const int4 hdr = rec[0], beg = rec[1], len = rec[2];
-    const int pix = hdr.x, nchunks = hdr.y;
+    const int pix = hdr.x, nchunks = hdr.y, scratch_row = hdr.z;
     const int c1 = len.x, c2 = c1 + len.y, c3 = c2 + len.z;
     const int w0 = 0, w1 = c3 + len.w;  // the record is already clipped to this item's window
 
@@ -429,7 +475,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
                     for (int u = 0; u < UB; ++u) {
                         const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj + u, kWave);
                         wgt[u] = __shfl(cur_w, lane_base + jj + u, kWave);
-                        g[u] = *reinterpret_cast<const Pack<T, VEC> *>(grow + ((p.debug & 4) ? 0u : q));
+                        g[u] = *reinterpret_cast<const Pack<T, VEC> *>(grow + q);
                     }
 #pragma unroll
                     for (int u = 0; u < UB; ++u)
@@ -451,7 +497,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params 
                 Pack<A, VEC> o;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) o.v[v] = acc[v];
-                A *dst = static_cast<A *>(p.ws_scratch) + ((size_t)pair * p.it_cap + item) * p.D + c0;
+                A *dst = static_cast<A *>(p.ws_scratch) + ((size_t)pair * p.it_cap + scratch_row) * p.D + c0;
                 *reinterpret_cast<Pack<A, VEC> *>(dst) = o;
             }
         }
@@ -530,7 +576,7 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     w.off_part = o;     o = align_up(o + pairs * w.nsplit * (size_t)w.nc_cap * 4, 256);
     w.off_off = o;      o = align_up(o + pairs * ((size_t)w.nc_cap + 1) * 4, 256);
     w.off_pixinfo = o;  o = align_up(o + pairs * (size_t)I * 8, 256);
-    w.off_itemcnt = o;  o = align_up(o + pairs * 4, 256);
+    w.off_itemcnt = o;  o = align_up(o + pairs * kItemMeta * 4, 256);
     w.off_items = o;    o = align_up(o + pairs * (size_t)w.it_cap * 48, 256);
     w.off_entries = o;  o = align_up(o + pairs * samples * entry_bytes, 256);
     w.off_scratch = o;  o = align_up(o + pairs * (size_t)w.it_cap * (size_t)D * acc_bytes, 256);
