@@ -232,6 +232,10 @@ def hip_multiscale_deformable_attention(
     if any(d.type != "cuda" for d in devices) or any(d != devices[0] for d in devices):
         raise ValueError(f"Expected all inputs to be on one gpu, but got {devices}.")
     _padding_code(padding_mode)
+    if torch.compiler.is_compiling():  # traced by torch.compile / export: use the registered custom ops
+        from .compile_op import compiled_multiscale_deformable_attention
+        return compiled_multiscale_deformable_attention(
+            img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners)
     return _HipMultiscaleDeformableAttentionFunction.apply(
         img, img_shapes, sampling_points, attention_weights, padding_mode, bool(align_corners))
 

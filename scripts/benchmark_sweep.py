@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Runtime / memory sweep over the number of queries — the measurement the reference publishes
+(/root/reference/scripts/benchmark.py:10-180, README.md:6-22): forward ms, forward+backward ms and peak
+memory for Q in {10, 100, 300, 900, 1000, 10000}; B=4, H=8, C=32, L=4 levels 64..8, P=4, fp32,
+border / align_corners=True; providers: the HIP kernels and the plain-PyTorch formulation on the GPU.
+
+Timing follows triton.testing.do_bench's recipe (which the reference uses): ~100 ms warm-up, ~1 s of
+repetitions, one HIP-event pair per repetition, an L2-sized buffer zeroed before each, median and the
+20 / 80 % quantiles.  Results go to outputs/benchmark_results/*.csv.
+
+    python scripts/benchmark_sweep.py [--queries 10 100 ...] [--no-native]
+"""
+import argparse
+import csv
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from msda_triton_amd import multiscale_deformable_attention, native_multiscale_deformable_attention  # noqa: E402
+
+SHAPES = [(64, 64), (32, 32), (16, 16), (8, 8)]
+B, H, C, P = 4, 8, 32, 4
+
+
+def do_bench(fn, warmup_ms=100.0, rep_ms=1000.0):
+    fn()
+    torch.cuda.synchronize()
+    flush = torch.empty(256 << 20, dtype=torch.int8, device="cuda")
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(5):
+        flush.zero_()
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    est = max(s.elapsed_time(e) / 5, 1e-3)
+    n_warm, n_rep = max(1, int(warmup_ms / est)), max(5, min(2000, int(rep_ms / est)))
+    for _ in range(n_warm):
+        fn()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_rep)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_rep)]
+    for i in range(n_rep):
+        flush.zero_()
+        starts[i].record()
+        fn()
+        ends[i].record()
+    torch.cuda.synchronize()
+    t = torch.tensor([a.elapsed_time(b) for a, b in zip(starts, ends)])
+    q = torch.quantile(t, torch.tensor([0.5, 0.2, 0.8]))
+    return [float(x) for x in q]
+
+
+def make_inputs(N, requires_grad):
+    L = len(SHAPES)
+    I = sum(h * w for h, w in SHAPES)  # noqa: E741
+    img = torch.randn(B, I, H, C, device="cuda", requires_grad=requires_grad)
+    shapes = torch.tensor(SHAPES, device="cuda")
+    pts = torch.rand(B, N, H, L, P, 2, device="cuda", requires_grad=requires_grad)
+    att = torch.softmax(torch.randn(B, N, H, L, P, device="cuda"), dim=-1).requires_grad_(requires_grad)
+    return img, shapes, pts, att
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--queries", type=int, nargs="+", default=[10, 100, 300, 900, 1000, 10000])
+    ap.add_argument("--no-native", action="store_true")
+    ap.add_argument("--out", default="outputs/benchmark_results")
+    args = ap.parse_args()
+    providers = {"hip": multiscale_deformable_attention}
+    if not args.no_native:
+        providers["torch"] = native_multiscale_deformable_attention
+    os.makedirs(args.out, exist_ok=True)
+    rows = []
+    for N in args.queries:
+        for name, op in providers.items():
+            img, shapes, pts, att = make_inputs(N, False)
+
+            def fwd():
+                with torch.no_grad():
+                    op(img, shapes, pts, att, "border", True)
+
+            f = do_bench(fwd)
+            img, shapes, pts, att = make_inputs(N, True)
+
+            def fwdbwd():
+                out = op(img, shapes, pts, att, "border", True)
+                out.backward(torch.rand_like(out))
+                img.grad = pts.grad = att.grad = None
+
+            fb = do_bench(fwdbwd)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            fwdbwd()
+            torch.cuda.synchronize()
+            mem = torch.cuda.max_memory_allocated() / 2**20
+            rows.append(dict(num_queries=N, provider=name, fwd_ms=f[0], fwd_ms_p20=f[1], fwd_ms_p80=f[2],
+                             fwdbwd_ms=fb[0], fwdbwd_ms_p20=fb[1], fwdbwd_ms_p80=fb[2], peak_mem_MB=mem))
+            print(rows[-1], flush=True)
+    path = os.path.join(args.out, "msda_sweep.csv")
+    with open(path, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()

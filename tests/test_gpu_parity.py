@@ -540,3 +540,29 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     assert lib.msda_fwd_f32(p + 2, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, st) == -4      # misaligned
     assert lib.msda_fwd_f32(None, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, st) == -1       # null buffer
     assert lib.msda_bwd_workspace_bytes(4, 5440, 8, 32, 10000, 4, 4, 4) > 0
+
+
+def test_torch_compile_fullgraph_uses_registered_custom_op():
+    """§8f-3: the operator survives torch.compile(fullgraph=True) as an opaque custom op, forward and backward."""
+    ops = _ops()
+    import msda_triton_amd.compile_op  # noqa: F401  (registers torch.ops.msda_amd.*)
+    c = rand_case(np.random.default_rng(41), 2, 33, 4, 32, [(8, 6), (4, 3)], 3)
+    s = torch.from_numpy(c["shapes"]).to(DEV)
+    g = torch.from_numpy(c["grad_out"]).to(DEV)
+
+    def fn(v, l, a):
+        return ops.multiscale_deformable_attention(v * 1.0, s, l, a, "zeros", False) * 2.0
+
+    outs = []
+    for compiled in (False, True):
+        v, l, a = (torch.from_numpy(c[k]).to(DEV).requires_grad_(True) for k in ("value", "loc", "attn"))
+        f = torch.compile(fn, fullgraph=True, backend="aot_eager") if compiled else fn
+        o = f(v, l, a)
+        o.backward(g)
+        outs.append((o.detach(), v.grad, l.grad, a.grad))
+    for x, y in zip(*outs):
+        torch.testing.assert_close(x, y, atol=1e-5, rtol=1e-5)
+    torch.library.opcheck(torch.ops.msda_amd.forward.default,
+                          (torch.from_numpy(c["value"]).to(DEV), s, torch.from_numpy(c["loc"]).to(DEV),
+                           torch.from_numpy(c["attn"]).to(DEV), True, False),
+                          test_utils=("test_schema", "test_faketensor"))
