@@ -53,10 +53,18 @@ class _GatherQueryShards(Function):
         ctx.num_queries, ctx.grad_sync = num_queries, grad_sync
         B, per, H, D = local.shape
         ctx.per = per
-        buf = local.new_empty((world, B, per, H, D))
-        _all_gather_into(buf, local.contiguous(), group)
-        full = buf.permute(1, 0, 2, 3, 4).reshape(B, world * per, H, D)
-        return full[:, :num_queries].contiguous()
+        local = local.contiguous()
+        if B <= 8:
+            # gather batch element by batch element straight into the final [B, world*per, H, D] layout:
+            # B small collectives instead of one collective plus a transposing copy of the whole output
+            full = local.new_empty((B, world * per, H, D))
+            for b in range(B):
+                _all_gather_into(full[b].view(world, per, H, D), local[b], group)
+        else:
+            buf = local.new_empty((world, B, per, H, D))
+            _all_gather_into(buf, local, group)
+            full = buf.permute(1, 0, 2, 3, 4).reshape(B, world * per, H, D)
+        return full if world * per == num_queries else full[:, :num_queries].contiguous()
 
     @staticmethod
     def backward(ctx, grad_full: torch.Tensor):

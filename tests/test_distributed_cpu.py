@@ -16,14 +16,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q_total, sharded_inputs, grad_sync, ret):
+def _worker(rank, world, port, q_total, sharded_inputs, grad_sync, batch, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(2)
         from msda_triton_amd import multiscale_deformable_attention, synth
         from msda_triton_amd.distributed import shard_bounds, sharded_multiscale_deformable_attention
-        wl = synth.Workload("t", 2, q_total, 3, 8, ((6, 5), (3, 3)), 2, "float64", "zeros", False)
+        wl = synth.Workload("t", batch, q_total, 3, 8, ((6, 5), (3, 3)), 2, "float64", "zeros", False)
         d = synth.make_inputs_torch(wl, "cpu", seed=2, loc_lo=-0.2, loc_hi=1.2)
         v = d["value"].clone().requires_grad_(True)
         l = d["loc"].clone().requires_grad_(True)
@@ -57,11 +57,12 @@ def _worker(rank, world, port, q_total, sharded_inputs, grad_sync, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("q_total,sharded_inputs,grad_sync", [(10, False, "slice"), (9, True, "slice"), (8, False, "reduce_scatter")])
-def test_query_shard_gloo_world2(q_total, sharded_inputs, grad_sync):
+@pytest.mark.parametrize("q_total,sharded_inputs,grad_sync,batch",
+                         [(10, False, "slice", 2), (9, True, "slice", 2), (8, False, "reduce_scatter", 2), (6, False, "slice", 9)])
+def test_query_shard_gloo_world2(q_total, sharded_inputs, grad_sync, batch):
     world = 2
     ret = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), q_total, sharded_inputs, grad_sync, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), q_total, sharded_inputs, grad_sync, batch, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
 
 
