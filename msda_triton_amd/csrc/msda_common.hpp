@@ -42,6 +42,8 @@ template <> struct Traits<__bf16> {
 // a*b + c in the accumulate type (one v_fma_f32 / v_fma_f64, never a silent promotion to double)
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// low 32 bits of the product of two values < 2^24 (v_mul_u32_u24)
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 __device__ __forceinline__ float floor_t(float a) { return __builtin_floorf(a); }
 __device__ __forceinline__ double floor_t(double a) { return __builtin_floor(a); }
 __device__ __forceinline__ float fmin_t(float a, float b) { return __builtin_fminf(a, b); }
@@ -165,11 +167,12 @@ __device__ __forceinline__ void make_taps(A x, A y, int h, int w, int start, boo
     const int x1c = (int)fmin_t(fmax_t(x1, (A)0), xm);
     const int y0c = (int)fmin_t(fmax_t(y0, (A)0), ym);
     const int y1c = (int)fmin_t(fmax_t(y1, (A)0), ym);
-    const uint32_t r0 = (uint32_t)(start + y0c * w), r1 = (uint32_t)(start + y1c * w);
-    t.off[0] = (r0 + (uint32_t)x0c) * row_bytes;
-    t.off[1] = (r0 + (uint32_t)x1c) * row_bytes;
-    t.off[2] = (r1 + (uint32_t)x0c) * row_bytes;
-    t.off[3] = (r1 + (uint32_t)x1c) * row_bytes;
+    // 24-bit multiplies are full rate (v_mul_lo_u32 is quarter rate); pixel indices and row sizes are < 2^24 (host check)
+    const uint32_t r0 = (uint32_t)start + mul24((uint32_t)y0c, (uint32_t)w), r1 = (uint32_t)start + mul24((uint32_t)y1c, (uint32_t)w);
+    t.off[0] = mul24(r0 + (uint32_t)x0c, row_bytes);
+    t.off[1] = mul24(r0 + (uint32_t)x1c, row_bytes);
+    t.off[2] = mul24(r1 + (uint32_t)x0c, row_bytes);
+    t.off[3] = mul24(r1 + (uint32_t)x1c, row_bytes);
     if (zeros) {
         const bool mx0 = (x0 >= (A)0) && (x0 <= xm), mx1 = (x1 >= (A)0) && (x1 <= xm);
         const bool my0 = (y0 >= (A)0) && (y0 <= ym), my1 = (y1 >= (A)0) && (y1 <= ym);

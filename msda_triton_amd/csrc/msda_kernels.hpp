@@ -123,9 +123,9 @@ __device__ __forceinline__ uint4 record_offsets(const Taps<A> &t, int stage_off,
     for (int k = 0; k < 4; ++k) {
         const uint32_t rel = t.off[k];  // pixel index inside the level, or kMaskedOffset
         if (stage_off >= 0)
-            o[k] = rel == kMaskedOffset ? (uint32_t)zero_off : (uint32_t)stage_off + rel * (uint32_t)row_b;
+            o[k] = rel == kMaskedOffset ? (uint32_t)zero_off : (uint32_t)stage_off + mul24(rel, (uint32_t)row_b);
         else
-            o[k] = rel == kMaskedOffset ? kMaskedOffset : ((uint32_t)start + rel) * row_bytes;
+            o[k] = rel == kMaskedOffset ? kMaskedOffset : mul24((uint32_t)start + rel, row_bytes);
     }
     return make_uint4(o[0], o[1], o[2], o[3]);
 }

@@ -53,7 +53,8 @@ inline int check_common(const Dims &d, int padding_mode, const void *const *ptrs
     }
     const int64_t lim = (int64_t)1 << 31;
     if (d.I * d.H * d.D * (int64_t)sizeof(T) >= lim || d.B >= lim || d.Q >= lim || d.L * d.P >= (1 << 22) ||
-        d.B * d.H >= (1 << 28) || d.Q * d.H * d.L * d.P * 2 >= lim || d.Q * d.H * d.D >= lim) {
+        d.B * d.H >= (1 << 28) || d.Q * d.H * d.L * d.P * 2 >= lim || d.Q * d.H * d.D >= lim || d.I >= (1 << 24) ||
+        d.H * d.D * (int64_t)sizeof(T) >= (1 << 24)) {
         set_error("tensor too large for 32-bit plane offsets (I*H*D*sizeof = %lld bytes)",
                   (long long)(d.I * d.H * d.D * (int64_t)sizeof(T)));
         return MSDA_ERR_TOO_LARGE;
@@ -236,14 +237,14 @@ template <typename T> inline int dispatch_value(Params &p, hipStream_t stream)
 // ---- sorted (gather-formulated) grad_value: K1..K5 of msda_value_sorted.hpp ----
 template <typename T, int VEC, int G> inline int launch_value_gather(Params &p, hipStream_t stream)
 {
-    constexpr int NU = kBlock / G;
+    constexpr int NU = kBlock / G, NUG = kGatherItemBlock / G;
     const int npairs = p.B * p.H;
     dim3 g4, g5;
-    if (!plane_grid(p, npairs, (p.it_cap + NU - 1) / NU, g4)) {
+    if (!plane_grid(p, npairs, (p.it_cap + NUG * kItemsPerGroup - 1) / (NUG * kItemsPerGroup), g4)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G>), g4, dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G>), g4, dim3(kGatherItemBlock), 0, stream, p);
     if (!plane_grid(p, npairs, (p.I + NU - 1) / NU, g5)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;

@@ -33,6 +33,8 @@
 namespace msda {
 
 constexpr int kChunk = 64;           // entries per work item
+constexpr int kItemsPerGroup = 1;    // work items a gather group handles back to back
+constexpr int kGatherItemBlock = 256; // threads per workgroup of the gather kernel (no LDS, no barriers)
 constexpr int kItemBuckets = 9;      // work items are bucketed by ceil(entries / 8) = 0..8
 constexpr int kItemMeta = 32;        // ints of per-plane item metadata: total, bucket starts, bucket cursors
 constexpr int kCellBlock = 1024;     // threads of K1 / K2b / K3
@@ -70,7 +72,7 @@ __device__ __forceinline__ bool sample_cell(A x, A y, int h, int w, int cstart, 
     }
     dx = px - x0;
     dy = py - y0;
-    cell = cstart + ((int)y0 + 1) * (w + 1) + ((int)x0 + 1);
+    cell = cstart + (int)mul24((uint32_t)((int)y0 + 1), (uint32_t)(w + 1)) + ((int)x0 + 1);
     return true;
 }
 
@@ -405,102 +407,116 @@ template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_item_kern
 // K4: gather.  G lanes per work item, VEC channels per lane (same shape as the forward gather).
 // ------------------------------------------------------------------------------------------
 template <typename T, int VEC, int G>
-__global__ __launch_bounds__(kBlock) void msda_value_gather_kernel(const Params p)
+__global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
-    constexpr int NU = kBlock / G;
+    constexpr int NU = kGatherItemBlock / G;
     constexpr int UB = G < 8 ? G : 8;  // row loads in flight per lane
-    const int slots = (p.it_cap + NU - 1) / NU;
+    // A group works through kItemsPerGroup consecutive work items (equal batch counts inside a bucket), fetching
+    // the next item's record while it processes the current one: short items would otherwise be all latency.
+    const int slots = (p.it_cap + NU * kItemsPerGroup - 1) / (NU * kItemsPerGroup);
     int pair, slot;
     if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
     const int nitems = p.ws_itemcnt[(size_t)pair * kItemMeta];
     const int tid = threadIdx.x;
     const int unit = tid / G, j = tid % G;
-    const int item = slot * NU + unit;
-    if (item >= nitems) return;
+    const int item0 = (slot * NU + unit) * kItemsPerGroup;
+    if (item0 >= nitems) return;
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int lane_base = (tid & (kWave - 1)) & ~(G - 1);
-
-    const int4 *rec = p.ws_items + ((size_t)pair * p.it_cap + item) * 3;
-    const int4 hdr = rec[0], beg = rec[1], len = rec[2];
-    const int pix = hdr.x, nchunks = hdr.y, scratch_row = hdr.z;
-    const int c1 = len.x, c2 = c1 + len.y, c3 = c2 + len.z;
-    const int w0 = 0, w1 = c3 + len.w;  // the record is already clipped to this item's window
 
     const Entry<A> *entries = static_cast<const Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
     const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
     const uint32_t q_stride = (uint32_t)(p.H * p.D);  // elements; q * q_stride < 2^31 is checked on the host
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
 
-    // position v of the pixel's virtual list (lists 0..3 back to back) -> (element offset of the query's
-    // grad_out row inside the plane, a * fx * fy)
-    // Positions past the end of the window are padded with the window's last record at weight 0 (so the
-    // unrolled batches need no tail loop; an empty window reads row 0 at weight 0).
-    auto fetch = [&](int v, uint32_t &q, A &wgt) {
-        q = 0;
-        wgt = (A)0;
-        if (w1 > 0) {
-            const int vc = min(v, w1 - 1);
-            const int i = (vc >= c1) + (vc >= c2) + (vc >= c3);
-            const int base = i == 0 ? beg.x : i == 1 ? beg.y - c1 : i == 2 ? beg.z - c2 : beg.w - c3;
-            const Entry<A> e = entries[base + vc];
-            const A fx = (i & 1) ? e.dx : (A)1 - e.dx;
-            const A fy = (i & 2) ? e.dy : (A)1 - e.dy;
-            q = e.q * q_stride;
-            wgt = v < w1 ? e.a * (fy * fx) : (A)0;
+    const int4 *rec = p.ws_items + ((size_t)pair * p.it_cap + item0) * 3;
+    int4 hdr = rec[0], beg = rec[1], len = rec[2];
+    for (int k = 0; k < kItemsPerGroup && item0 + k < nitems; ++k) {
+        int4 hdr_n = hdr, beg_n = beg, len_n = len;
+        if (k + 1 < kItemsPerGroup && item0 + k + 1 < nitems) {
+            hdr_n = rec[(k + 1) * 3 + 0];
+            beg_n = rec[(k + 1) * 3 + 1];
+            len_n = rec[(k + 1) * 3 + 2];
         }
-    };
+        const int pix = hdr.x, nchunks = hdr.y, scratch_row = hdr.z;
+        const int c1 = len.x, c2 = c1 + len.y, c3 = c2 + len.z;
+        const int w0 = 0, w1 = c3 + len.w;  // the record is already clipped to this item's window
 
-    for (int cc = 0; cc < nchan_chunks; ++cc) {
-        const int c0 = (cc * G + j) * VEC;
-        const bool lane_ok = c0 < p.D;
-        const T *grow = gout + (lane_ok ? c0 : 0);
-        A acc[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = (A)0;
+        // position v of the pixel's virtual list (lists 0..3 back to back) -> (element offset of the query's
+        // grad_out row inside the plane, a * fx * fy)
+        // Positions past the end of the window are padded with the window's last record at weight 0 (so the
+        // unrolled batches need no tail loop; an empty window reads row 0 at weight 0).
+        auto fetch = [&](int v, uint32_t &q, A &wgt) {
+            q = 0;
+            wgt = (A)0;
+            if (w1 > 0) {
+                const int vc = min(v, w1 - 1);
+                const int i = (vc >= c1) + (vc >= c2) + (vc >= c3);
+                const int base = i == 0 ? beg.x : i == 1 ? beg.y - c1 : i == 2 ? beg.z - c2 : beg.w - c3;
+                const Entry<A> e = entries[base + vc];
+                const A fx = (i & 1) ? e.dx : (A)1 - e.dx;
+                const A fy = (i & 2) ? e.dy : (A)1 - e.dy;
+                q = e.q * q_stride;
+                wgt = v < w1 ? e.a * (fy * fx) : (A)0;
+            }
+        };
 
-        uint32_t cur_q, nxt_q;
-        A cur_w, nxt_w;
-        fetch(w0 + j, cur_q, cur_w);
-        for (int v0 = w0; v0 < w1; v0 += G) {
-            fetch(v0 + G + j, nxt_q, nxt_w);  // next batch's records are in flight while this one is consumed
-            const int cnt = min(G, w1 - v0);
-#pragma unroll
-            for (int jj = 0; jj < G; jj += UB) {  // UB row loads issued back to back, then consumed
-                if (jj < cnt) {                   // uniform per group; G == UB: always true
-                    A wgt[UB];
-                    Pack<T, VEC> g[UB];
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) {
-                        const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj + u, kWave);
-                        wgt[u] = __shfl(cur_w, lane_base + jj + u, kWave);
-                        g[u] = *reinterpret_cast<const Pack<T, VEC> *>(grow + q);
+        for (int cc = 0; cc < nchan_chunks; ++cc) {
+            const int c0 = (cc * G + j) * VEC;
+            const bool lane_ok = c0 < p.D;
+            const T *grow = gout + (lane_ok ? c0 : 0);
+            A acc[VEC];
+    #pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = (A)0;
+
+            uint32_t cur_q, nxt_q;
+            A cur_w, nxt_w;
+            fetch(w0 + j, cur_q, cur_w);
+            for (int v0 = w0; v0 < w1; v0 += G) {
+                fetch(v0 + G + j, nxt_q, nxt_w);  // next batch's records are in flight while this one is consumed
+                const int cnt = min(G, w1 - v0);
+    #pragma unroll
+                for (int jj = 0; jj < G; jj += UB) {  // UB row loads issued back to back, then consumed
+                    if (jj < cnt) {                   // uniform per group; G == UB: always true
+                        A wgt[UB];
+                        Pack<T, VEC> g[UB];
+    #pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj + u, kWave);
+                            wgt[u] = __shfl(cur_w, lane_base + jj + u, kWave);
+                            g[u] = *reinterpret_cast<const Pack<T, VEC> *>(grow + q);
+                        }
+    #pragma unroll
+                        for (int u = 0; u < UB; ++u)
+    #pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc[v] = fma_t(wgt[u], TR::to_acc(g[u].v[v]), acc[v]);
                     }
-#pragma unroll
-                    for (int u = 0; u < UB; ++u)
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) acc[v] = fma_t(wgt[u], TR::to_acc(g[u].v[v]), acc[v]);
+                }
+                cur_q = nxt_q;
+                cur_w = nxt_w;
+            }
+            if (lane_ok) {
+                if (nchunks == 1) {
+                    Pack<T, VEC> o;
+    #pragma unroll
+                    for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
+                    T *dst = static_cast<T *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
+                    *reinterpret_cast<Pack<T, VEC> *>(dst) = o;
+                } else {
+                    Pack<A, VEC> o;
+    #pragma unroll
+                    for (int v = 0; v < VEC; ++v) o.v[v] = acc[v];
+                    A *dst = static_cast<A *>(p.ws_scratch) + ((size_t)pair * p.it_cap + scratch_row) * p.D + c0;
+                    *reinterpret_cast<Pack<A, VEC> *>(dst) = o;
                 }
             }
-            cur_q = nxt_q;
-            cur_w = nxt_w;
         }
-        if (lane_ok) {
-            if (nchunks == 1) {
-                Pack<T, VEC> o;
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
-                T *dst = static_cast<T *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
-                *reinterpret_cast<Pack<T, VEC> *>(dst) = o;
-            } else {
-                Pack<A, VEC> o;
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) o.v[v] = acc[v];
-                A *dst = static_cast<A *>(p.ws_scratch) + ((size_t)pair * p.it_cap + scratch_row) * p.D + c0;
-                *reinterpret_cast<Pack<A, VEC> *>(dst) = o;
-            }
-        }
+
+        hdr = hdr_n;
+        beg = beg_n;
+        len = len_n;
     }
 }
 
