@@ -35,6 +35,14 @@
  * msda_bwd_*: grad_value may be NULL (that gradient is skipped), and grad_loc / grad_attn may
  * be NULL together (both skipped) — the autograd caller passes only what needs_input_grad asks.
  *
+ * msda_fwd_fused_<dtype> is the forward of the reference's nn.Module core with its prologue fused in
+ * (src/msda_triton/frontend.py:253-282): `proj` [B, Q, H, L, P, 3] is the raw query projection
+ * (x offset, y offset, attention logit); `ref` [B, Q, ref_dim] the reference points, ref_dim 2 = (x, y),
+ * 4 = (cx, cy, w, h).  The kernel takes the softmax over each (b, q, h)'s L*P logits and forms the
+ * sampling points (ref + offset / img_shapes[l] — in the reference's (h, w) order — or
+ * ref_xy + offset * ref_wh / (2 P)) in its prologue, so neither tensor is ever materialised.
+ * Returns MSDA_ERR_UNSUPPORTED when L*P is too large for one pass (callers then use msda_fwd_<dtype>).
+ *
  * Backward workspace: grad_value is computed as a gather over a per-call inverted index (sample
  * records sorted by bilinear cell), which lives in caller-provided device memory so that the
  * library never allocates: pass `workspace` (256-byte aligned) of at least
@@ -57,7 +65,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 2
+#define MSDA_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define MSDA_API __attribute__((visibility("default")))
@@ -74,12 +82,17 @@ extern "C" {
 #define MSDA_ERR_TOO_MANY_LEVELS (-2) /* L > MSDA_MAX_LEVELS */
 #define MSDA_ERR_TOO_LARGE (-3)    /* I*H*D*sizeof(dtype) >= 2^31 bytes per batch element */
 #define MSDA_ERR_MISALIGNED (-4)   /* a buffer is not aligned to its element size */
+#define MSDA_ERR_UNSUPPORTED (-5)  /* valid arguments this entry point cannot serve (use the unfused call) */
 
 #define MSDA_DECLARE(SUF)                                                                          \
     MSDA_API int msda_fwd_##SUF(const void *value, const int64_t *shapes, const void *loc,                  \
                        const void *attn, void *out, int64_t B, int64_t I, int64_t H, int64_t D,    \
                        int64_t Q, int64_t L, int64_t P, int padding_mode, int align_corners,       \
                        void *stream);                                                              \
+    MSDA_API int msda_fwd_fused_##SUF(const void *value, const int64_t *shapes, const void *proj,           \
+                       const void *ref, void *out, int64_t B, int64_t I, int64_t H, int64_t D,    \
+                       int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,             \
+                       int align_corners, void *stream);                                           \
     MSDA_API int msda_bwd_##SUF(const void *grad_out, const void *value, const int64_t *shapes,             \
                        const void *loc, const void *attn, void *grad_value, void *grad_loc,        \
                        void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,     \

@@ -15,13 +15,13 @@ LIB_NAME = "libmsda_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PADDING_MODES = {"border": 0, "zeros": 1}
 DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64")
 
 # every symbol include/msda_hip.h declares
 EXPORTED_SYMBOLS = tuple(
-    [f"msda_{d}_{s}" for d in ("fwd", "bwd") for s in DTYPE_SUFFIXES]
+    [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused") for s in DTYPE_SUFFIXES]
     + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option", "msda_bwd_workspace_bytes"]
 )
 
@@ -67,6 +67,9 @@ def load():
             f = getattr(lib, f"msda_fwd_{suf}")
             f.restype = ci
             f.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, vp]
+            ff = getattr(lib, f"msda_fwd_fused_{suf}")
+            ff.restype = ci
+            ff.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, ci, vp]
             g = getattr(lib, f"msda_bwd_{suf}")
             g.restype = ci
             g.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, vp, i64, vp]

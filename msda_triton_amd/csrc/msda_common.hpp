@@ -212,6 +212,26 @@ template <int G> __device__ __forceinline__ float group_sum(float v)
     return v;
 }
 
+// max over the G lanes of a unit (same lane choreography as group_sum)
+template <int G> __device__ __forceinline__ float group_max(float v)
+{
+    if constexpr (G >= 2) v = fmax_t(v, dpp_f32<0xB1>(v));
+    if constexpr (G >= 4) v = fmax_t(v, dpp_f32<0x4E>(v));
+    if constexpr (G >= 8) v = fmax_t(v, dpp_f32<0x141>(v));
+    if constexpr (G >= 16) v = fmax_t(v, dpp_f32<0x140>(v));
+    if constexpr (G >= 32) v = fmax_t(v, __shfl_xor(v, 16, kWave));
+    if constexpr (G >= 64) v = fmax_t(v, __shfl_xor(v, 32, kWave));
+    return v;
+}
+template <int G> __device__ __forceinline__ double group_max(double v)
+{
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) v = fmax_t(v, __shfl_xor(v, m, kWave));
+    return v;
+}
+__device__ __forceinline__ float exp_t(float a) { return ::expf(a); }
+__device__ __forceinline__ double exp_t(double a) { return ::exp(a); }
+
 template <int G> __device__ __forceinline__ double group_sum(double v)
 {
 #pragma unroll

@@ -41,6 +41,8 @@ struct Params {
     int sc;        // samples of a unit parked in LDS at a time (<= LP)
     int stage_bytes;  // LDS bytes available for staged levels (0: no staging)
     int zeros, align, xcd_map;
+    const void *ref;  // fused module prologue: reference points [B, Q, ref_dim]; then `loc` holds the raw projection [B,Q,H,L,P,3]
+    int ref_dim;      // 2: (x, y)   4: (cx, cy, w, h)
     int grid3d;       // this launch uses the division-free 3-D grid (see decode_block)
     int debug;        // dev-only ablation mask (msda_set_option("debug", m)); 0 in normal use
     FastDiv div_h;    // pair -> (b, h)
@@ -174,7 +176,7 @@ constexpr size_t kGatherLdsFixed = sizeof(LevelTab) + (sizeof(StagePlan) + 15) /
 // forward.  After the one-time staging barrier every wave runs on its own: it parks the records of
 // ITS 64/G units, gathers, stores, and moves to its next query chunk without any block barrier.
 // ==========================================================================================
-template <typename T, int VEC, int G, int BLOCK, bool STAGE>
+template <typename T, int VEC, int G, int BLOCK, bool STAGE, bool FUSED>
 __global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
@@ -209,10 +211,11 @@ __global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
     const int wunit = lane / G, j = lane % G;  // unit inside the wave, lane inside the unit
     uint4 *w_off = lds.s_off + wave * UPW * scp;
     Rec4<A> *w_rec = lds.s_rec + wave * UPW * scp;
-    // per-plane bases (64-bit, uniform) + 32-bit per-sample indices (the host checks Q*H*L*P*2 < 2^31)
+    // per-plane bases (64-bit, uniform) + 32-bit per-sample indices (the host checks Q*H*L*P*3 < 2^31)
     const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
-    const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
-    const T *attn = static_cast<const T *>(p.attn) + plane_s0;
+    const T *loc = static_cast<const T *>(p.loc) + (FUSED ? 3 : 2) * plane_s0;  // FUSED: raw projection (dx, dy, logit)
+    const T *attn = FUSED ? nullptr : static_cast<const T *>(p.attn) + plane_s0;
+    const T *refp = FUSED ? static_cast<const T *>(p.ref) + (size_t)b * p.Q * p.ref_dim : nullptr;
     const int HLP = p.H * p.LP;
     const float inv_P = 1.0f / (float)p.P;
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
@@ -235,6 +238,25 @@ __global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
                 const int sc = min(p.sc, p.LP - s0);
                 const float inv_sc = 1.0f / (float)sc;
                 wave_lds_sync();  // previous records consumed
+                if constexpr (FUSED) {
+                    // ---- phase 0 (module prologue, frontend.py:253-261): softmax over the unit's L*P logits ----
+                    // (sc == LP here.)  The unit's G lanes stride over its logits: max, then exp and sum, DPP-reduced;
+                    // exp(logit - max) is parked in the record slot, (1 / sum) in the unit's padding slot.
+                    if (unit_ok) {
+                        A mx = -__builtin_huge_val();
+                        for (int sl = j; sl < sc; sl += G) mx = fmax_t(mx, TR::to_acc(loc[3 * (q * HLP + sl) + 2]));
+                        mx = group_max<G>(mx);
+                        A sum = (A)0;
+                        for (int sl = j; sl < sc; sl += G) {
+                            const A e = exp_t(TR::to_acc(loc[3 * (q * HLP + sl) + 2]) - mx);
+                            w_rec[wunit * scp + sl].v[0] = e;
+                            sum += e;
+                        }
+                        sum = group_sum<G>(sum);
+                        if (j == 0) w_rec[wunit * scp + sc].v[0] = (A)1 / sum;
+                    }
+                    wave_lds_sync();
+                }
                 // ---- phase 1: the wave's UPW * sc samples, one per lane and trip ----
                 for (int f = lane; f < UPW * sc; f += kWave) {
                     const int fu = div_small(f, sc, inv_sc);
@@ -243,11 +265,29 @@ __global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
                     if (fq < p.Q) {
                         const int l = div_small(sl, p.P, inv_P);
                         const int sidx = fq * HLP + sl;
-                        const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
-                        const A a = TR::to_acc(attn[sidx]);
+                        A sx, sy, a;
+                        if constexpr (FUSED) {
+                            // sampling point from reference point + projected offset (frontend.py:270-282), attention
+                            // weight from the parked softmax pieces
+                            const A ox = TR::to_acc(loc[3 * sidx]), oy = TR::to_acc(loc[3 * sidx + 1]);
+                            const T *r = refp + (size_t)fq * p.ref_dim;
+                            if (p.ref_dim == 2) {
+                                // NB: (x, y) offsets are divided by img_shapes in its stored (h, w) order (frontend.py:275)
+                                sx = TR::to_acc(r[0]) + ox / (A)tab->h[l];
+                                sy = TR::to_acc(r[1]) + oy / (A)tab->w[l];
+                            } else {
+                                sx = TR::to_acc(r[0]) + ox * TR::to_acc(r[2]) / (A)(2 * p.P);
+                                sy = TR::to_acc(r[1]) + oy * TR::to_acc(r[3]) / (A)(2 * p.P);
+                            }
+                            a = w_rec[fu * scp + (sl - s0)].v[0] * w_rec[fu * scp + sc].v[0];
+                        } else {
+                            const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                            sx = TR::to_acc(xy.v[0]);
+                            sy = TR::to_acc(xy.v[1]);
+                            a = TR::to_acc(attn[sidx]);
+                        }
                         Taps<A> t;
-                        make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], 0, p.zeros, p.align,
-                                     1u, t);
+                        make_taps<A>(sx, sy, tab->h[l], tab->w[l], 0, p.zeros, p.align, 1u, t);
                         const A wy0 = (A)1 - t.dy, wx0 = (A)1 - t.dx;
                         Rec4<A> w;
                         w.v[0] = a * (wy0 * wx0);

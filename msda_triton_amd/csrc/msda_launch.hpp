@@ -130,7 +130,7 @@ inline void plan_gather(int NU, int LP, size_t acc_bytes, int stage_want, int ro
     lds = base + (size_t)stage_bytes;
 }
 
-template <typename T, int VEC, int G, bool BWD, int BLOCK> inline int launch_gather_block(Params &p, hipStream_t stream)
+template <typename T, int VEC, int G, int MODE, int BLOCK> inline int launch_gather_block(Params &p, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
     constexpr int NU = BLOCK / G;
@@ -148,8 +148,14 @@ template <typename T, int VEC, int G, bool BWD, int BLOCK> inline int launch_gat
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
+    if (MODE == 2 && p.sc != p.LP) {
+        set_error("fused prologue needs all L*P=%d samples of a unit in LDS at once (limit %d)", p.LP, p.sc);
+        return MSDA_ERR_UNSUPPORTED;
+    }
     if (p.stage_bytes > 0) {
-        auto kernel = BWD ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, true> : msda_fwd_kernel<T, VEC, G, BLOCK, true>;
+        auto kernel = MODE == 1   ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, true>
+                      : MODE == 2 ? msda_fwd_kernel<T, VEC, G, BLOCK, true, true>
+                                  : msda_fwd_kernel<T, VEC, G, BLOCK, true, false>;
         static bool big_lds_ok = false;
         if (!big_lds_ok) {
             allow_big_lds(kernel);
@@ -157,7 +163,9 @@ template <typename T, int VEC, int G, bool BWD, int BLOCK> inline int launch_gat
         }
         hipLaunchKernelGGL(kernel, grid, dim3(BLOCK), lds, stream, p);
     } else {
-        auto kernel = BWD ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, false> : msda_fwd_kernel<T, VEC, G, BLOCK, false>;
+        auto kernel = MODE == 1   ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, false>
+                      : MODE == 2 ? msda_fwd_kernel<T, VEC, G, BLOCK, false, true>
+                                  : msda_fwd_kernel<T, VEC, G, BLOCK, false, false>;
         static bool big_lds_ok = false;
         if (!big_lds_ok) {
             allow_big_lds(kernel);
@@ -168,34 +176,34 @@ template <typename T, int VEC, int G, bool BWD, int BLOCK> inline int launch_gat
     return (int)hipGetLastError();
 }
 
-template <typename T, int VEC, int G, bool BWD> inline int launch_gather(Params &p, hipStream_t stream)
+template <typename T, int VEC, int G, int MODE> inline int launch_gather(Params &p, hipStream_t stream)
 {
     // staged levels are shared by a whole workgroup: use the biggest one (16 waves) when staging is on
     if (VEC > 1 && option_stage_kb() > 0) {
         const int blk = option_gather_block();
-        if (blk == 1024) return launch_gather_block<T, VEC, G, BWD, 1024>(p, stream);
-        if (blk == 512) return launch_gather_block<T, VEC, G, BWD, 512>(p, stream);
+        if (blk == 1024) return launch_gather_block<T, VEC, G, MODE, 1024>(p, stream);
+        if (blk == 512) return launch_gather_block<T, VEC, G, MODE, 512>(p, stream);
     }
-    return launch_gather_block<T, VEC, G, BWD, kBlock>(p, stream);
+    return launch_gather_block<T, VEC, G, MODE, kBlock>(p, stream);
 }
 
-template <typename T, int VEC, bool BWD> inline int dispatch_group(Params &p, hipStream_t stream)
+template <typename T, int VEC, int MODE> inline int dispatch_group(Params &p, hipStream_t stream)
 {
     const int lanes = (p.D + VEC - 1) / VEC;
     switch (pick_group(lanes)) {
-    case 4: return launch_gather<T, VEC, 4, BWD>(p, stream);
-    case 8: return launch_gather<T, VEC, 8, BWD>(p, stream);
-    case 16: return launch_gather<T, VEC, 16, BWD>(p, stream);
-    case 32: return launch_gather<T, VEC, 32, BWD>(p, stream);
-    default: return launch_gather<T, VEC, 64, BWD>(p, stream);
+    case 4: return launch_gather<T, VEC, 4, MODE>(p, stream);
+    case 8: return launch_gather<T, VEC, 8, MODE>(p, stream);
+    case 16: return launch_gather<T, VEC, 16, MODE>(p, stream);
+    case 32: return launch_gather<T, VEC, 32, MODE>(p, stream);
+    default: return launch_gather<T, VEC, 64, MODE>(p, stream);
     }
 }
 
-template <typename T, bool BWD> inline int dispatch_gather(Params &p, bool vec_ok, hipStream_t stream)
+template <typename T, int MODE> inline int dispatch_gather(Params &p, bool vec_ok, hipStream_t stream)
 {
     constexpr int VECF = 16 / sizeof(T);
-    if (vec_ok && (p.D % VECF) == 0) return dispatch_group<T, VECF, BWD>(p, stream);
-    return dispatch_group<T, 1, BWD>(p, stream);
+    if (vec_ok && (p.D % VECF) == 0) return dispatch_group<T, VECF, MODE>(p, stream);
+    return dispatch_group<T, 1, MODE>(p, stream);
 }
 
 template <typename T, int CH> inline int launch_value(Params &p, hipStream_t stream)
@@ -341,6 +349,8 @@ inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_co
     p.qw = 1;
     p.stage_bytes = 0;
     p.grid3d = 0;
+    p.ref = nullptr;
+    p.ref_dim = 0;
     p.debug = option_debug();
     p.div_h = make_fast_div((uint32_t)d.H);
 }
@@ -376,8 +386,54 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
     p.out = out;
     fill_params(p, d, padding_mode, align_corners);
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
-    rc = dispatch_gather<T, false>(p, vec_ok, stream);
+    rc = dispatch_gather<T, 0>(p, vec_ok, stream);
     if (rc) set_error("forward launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
+// Module forward with the prologue fused in: `proj` is the raw query projection
+// [B, Q, H, L, P, 3] = (x offset, y offset, attention logit), `ref` the reference points [B, Q, ref_dim].
+template <typename T>
+int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, const void *ref, void *out, int64_t B,
+                  int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,
+                  int align_corners, void *stream_)
+{
+    const Dims d{B, I, H, D, Q, L, P};
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t out_bytes = (size_t)(B * Q * H * D) * sizeof(T);
+    if (out_bytes == 0) return 0;
+    if (ref_dim != 2 && ref_dim != 4) {
+        set_error("ref_dim must be 2 or 4, got %d", ref_dim);
+        return MSDA_ERR_BAD_ARG;
+    }
+    const void *ptrs[] = {out};
+    int rc = check_common<T>(d, padding_mode, ptrs, 1);
+    if (rc) return rc;
+    if (L * P == 0 || I == 0) return (int)hipMemsetAsync(out, 0, out_bytes, stream);
+    const void *ptrs2[] = {value, shapes, proj, ref};
+    rc = check_common<T>(d, padding_mode, ptrs2, 4);
+    if (rc) return rc;
+    if (Q * H * L * P * 3 >= ((int64_t)1 << 31)) {
+        set_error("projection too large for 32-bit sample offsets");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    if (!aligned_to(value, sizeof(T)) || !aligned_to(out, sizeof(T)) || !aligned_to(proj, sizeof(T)) ||
+        !aligned_to(ref, sizeof(T)) || !aligned_to(shapes, 8)) {
+        set_error("misaligned buffer");
+        return MSDA_ERR_MISALIGNED;
+    }
+    Params p{};
+    p.value = value;
+    p.shapes = shapes;
+    p.loc = proj;
+    p.attn = nullptr;
+    p.out = out;
+    fill_params(p, d, padding_mode, align_corners);
+    p.ref = ref;
+    p.ref_dim = ref_dim;
+    const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
+    rc = dispatch_gather<T, 2>(p, vec_ok, stream);
+    if (rc > 0) set_error("fused forward launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }
 
@@ -427,7 +483,7 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     fill_params(p, d, padding_mode, align_corners);
     if (want_sample) {
         const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
-        rc = dispatch_gather<T, true>(p, vec_ok, stream);
+        rc = dispatch_gather<T, 1>(p, vec_ok, stream);
         if (rc) {
             set_error("backward (grad_loc/grad_attn) launch failed: %s", hipGetErrorString((hipError_t)rc));
             return rc;
@@ -467,6 +523,14 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     {                                                                                                            \
         return msda::run_fwd<T>(value, shapes, loc, attn, out, B, I, H, D, Q, L, P, padding_mode,               \
                                 align_corners, stream);                                                          \
+    }                                                                                                            \
+    extern "C" int msda_fwd_fused_##SUF(const void *value, const int64_t *shapes, const void *proj,             \
+                                        const void *ref, void *out, int64_t B, int64_t I, int64_t H, int64_t D,  \
+                                        int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,          \
+                                        int align_corners, void *stream)                                         \
+    {                                                                                                            \
+        return msda::run_fwd_fused<T>(value, shapes, proj, ref, out, B, I, H, D, Q, L, P, ref_dim, padding_mode, \
+                                      align_corners, stream);                                                    \
     }                                                                                                            \
     extern "C" int msda_bwd_##SUF(const void *grad_out, const void *value, const int64_t *shapes,               \
                                   const void *loc, const void *attn, void *grad_value, void *grad_loc,          \

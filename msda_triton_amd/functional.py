@@ -241,6 +241,113 @@ def hip_multiscale_deformable_attention(
 
 
 # ------------------------------------------------------------------------------------------
+# module core with the prologue fused into the kernel (reference frontend.py:253-289)
+# ------------------------------------------------------------------------------------------
+def module_sampling_inputs(proj: torch.Tensor, img_shapes: torch.Tensor, reference_points: torch.Tensor):
+    """The reference module's prologue in plain PyTorch: raw projection [B,N,H,L,P,3] ->
+    (sampling_points [B,N,H,L,P,2], attention_weights [B,N,H,L,P])  (frontend.py:253-284)."""
+    B, N, H, L, P, _ = proj.shape
+    offsets, logits = proj[..., :2], proj[..., 2]
+    attention_weights = logits.reshape(B, N, H, L * P).softmax(dim=-1).reshape(B, N, H, L, P)
+    ref = reference_points[:, :, None, None, None, :]
+    coords = reference_points.shape[-1]
+    if coords == 2:
+        # NB: the reference divides the (x, y) offsets by img_shapes in its stored (h, w) order
+        # (frontend.py:275); reproduced for parity — it only matters for non-square levels.
+        sampling_points = ref + offsets / img_shapes[:, None, :]
+    elif coords == 4:
+        sampling_points = ref[..., :2] + offsets * ref[..., 2:] / (2 * P)
+    else:
+        raise ValueError(f"`reference_points` should have the last dim either 2 or 4, but got {coords}.")
+    return sampling_points, attention_weights
+
+
+def msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, align_corners) -> Optional[torch.Tensor]:
+    """Forward with softmax + sampling-point math done in the kernel prologue.  Returns None when the
+    library declines (L*P too large for one pass): the caller then takes the unfused route."""
+    B, I, H, D = img.shape
+    B2, Q, H2, L, P, three = proj.shape
+    if (B2, H2, three) != (B, H, 3) or tuple(reference_points.shape[:2]) != (B, Q):
+        raise ValueError(f"inconsistent shapes: img {tuple(img.shape)}, proj {tuple(proj.shape)}, "
+                         f"reference_points {tuple(reference_points.shape)}")
+    ref_dim = reference_points.shape[-1]
+    if ref_dim not in (2, 4):
+        raise ValueError(f"`reference_points` should have the last dim either 2 or 4, but got {ref_dim}.")
+    if tuple(img_shapes.shape) != (L, 2):
+        raise ValueError(f"`img_shapes` should be [{L}, 2], but got {tuple(img_shapes.shape)}.")
+    pad = _padding_code(padding_mode)
+    suf = _SUFFIX[img.dtype]
+    img, proj, reference_points = img.contiguous(), proj.contiguous(), reference_points.contiguous()
+    shapes = _shapes_i64(img_shapes)
+    out = torch.empty((B, Q, H, D), dtype=img.dtype, device=img.device)
+    fn = getattr(_lib.load(), f"msda_fwd_fused_{suf}")
+
+    def call():
+        return fn(img.data_ptr(), shapes.data_ptr(), proj.data_ptr(), reference_points.data_ptr(), out.data_ptr(),
+                  B, I, H, D, Q, L, P, ref_dim, pad, int(bool(align_corners)), _stream_ptr(img.device))
+
+    with torch.cuda.device(img.device):
+        timer = KernelTimer.active
+        rc = timer.launch("msda_fwd_fused", img.device, call) if timer else call()
+    if rc == -5:  # MSDA_ERR_UNSUPPORTED
+        return None
+    _lib.check(rc, f"msda_fwd_fused_{suf}")
+    return out
+
+
+class _HipFusedModuleCoreFunction(Function):
+    """value, raw projection, reference points -> attended values.  Forward: one fused kernel.  Backward:
+    the prologue is recomputed in PyTorch (cheap elementwise ops), the operator's HIP backward supplies the
+    gradients of the sampling points / attention weights, and autograd chains them to the projection."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, img, img_shapes, proj, reference_points, padding_mode, align_corners):
+        out = msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, align_corners)
+        if out is None:
+            pts, att = module_sampling_inputs(proj, img_shapes, reference_points)
+            out = msda_hip_fwd(img, img_shapes, pts, att, padding_mode, align_corners)
+        ctx.save_for_backward(img, img_shapes, proj, reference_points)
+        ctx.padding_mode, ctx.align_corners = padding_mode, align_corners
+        return out
+
+    @staticmethod
+    @once_differentiable
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, out_grad):
+        img, img_shapes, proj, reference_points = ctx.saved_tensors
+        need_img, _, need_proj, need_ref = ctx.needs_input_grad[:4]
+        with torch.enable_grad():
+            proj_ = proj.detach().requires_grad_(need_proj)
+            ref_ = reference_points.detach().requires_grad_(need_ref)
+            pts, att = module_sampling_inputs(proj_, img_shapes, ref_)
+        need_sample = need_proj or need_ref
+        g_img, g_pts, g_att = msda_hip_bwd(out_grad, img, img_shapes, pts.detach(), att.detach(), ctx.padding_mode,
+                                           ctx.align_corners, (need_img, need_sample, need_sample))
+        g_proj = g_ref = None
+        if need_sample:
+            wrt = [t for t, n in ((proj_, need_proj), (ref_, need_ref)) if n]
+            grads = list(torch.autograd.grad([pts, att], wrt, [g_pts, g_att], allow_unused=True))
+            if need_proj:
+                g_proj = grads.pop(0)
+            if need_ref:
+                g_ref = grads.pop(0)
+        return g_img, None, g_proj, g_ref, None, None
+
+
+def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, align_corners) -> torch.Tensor:
+    """``multiscale_deformable_attention(img, img_shapes, *module_sampling_inputs(proj, ...))`` — on GPU tensors
+    with the prologue fused into the forward kernel; on host tensors exactly that composition."""
+    if img.device.type == "cuda" and img.dtype in VALID_DTYPES and proj.dtype == img.dtype and \
+            reference_points.dtype == img.dtype and not torch.compiler.is_compiling():
+        _padding_code(padding_mode)
+        return _HipFusedModuleCoreFunction.apply(img, img_shapes, proj, reference_points, padding_mode,
+                                                 bool(align_corners))
+    pts, att = module_sampling_inputs(proj, img_shapes, reference_points)
+    return multiscale_deformable_attention(img, img_shapes, pts, att, padding_mode, align_corners)
+
+
+# ------------------------------------------------------------------------------------------
 # host-tensor path (reference: native_multiscale_deformable_attention, frontend.py:15-68)
 # ------------------------------------------------------------------------------------------
 def _unnormalise(coord: torch.Tensor, size: int, padding_mode: str, align_corners: bool) -> torch.Tensor:

@@ -12,7 +12,7 @@ from typing import Literal
 import torch
 from torch import nn
 
-from .functional import multiscale_deformable_attention
+from .functional import fused_module_core, module_sampling_inputs
 
 
 class MultiscaleDeformableAttention(nn.Module):
@@ -51,22 +51,8 @@ class MultiscaleDeformableAttention(nn.Module):
     def sampling_inputs(self, img_shapes: torch.Tensor, queries: torch.Tensor, reference_points: torch.Tensor):
         """Query projection -> (sampling_points [B,N,H,L,P,2], attention_weights [B,N,H,L,P])."""
         B, N, _ = queries.shape
-        H, L, P = self.num_heads, self.num_levels, self.num_points
-        proj = self.query_input_proj(queries).reshape(B, N, H, L, P, 3)
-        offsets, logits = proj[..., :2], proj[..., 2]
-        attention_weights = logits.reshape(B, N, H, L * P).softmax(dim=-1).reshape(B, N, H, L, P)
-
-        ref = reference_points[:, :, None, None, None, :]
-        coords = reference_points.shape[-1]
-        if coords == 2:
-            # NB: the reference divides the (x, y) offsets by img_shapes in its stored (h, w) order
-            # (frontend.py:275); reproduced for parity — it only matters for non-square levels.
-            sampling_points = ref + offsets / img_shapes[:, None, :]
-        elif coords == 4:
-            sampling_points = ref[..., :2] + offsets * ref[..., 2:] / (2 * P)
-        else:
-            raise ValueError(f"`reference_points` should have the last dim either 2 or 4, but got {coords}.")
-        return sampling_points, attention_weights
+        proj = self.query_input_proj(queries).reshape(B, N, self.num_heads, self.num_levels, self.num_points, 3)
+        return module_sampling_inputs(proj, img_shapes, reference_points)
 
     def forward(self, img: torch.Tensor, img_shapes: torch.Tensor, queries: torch.Tensor,
                 reference_points: torch.Tensor) -> torch.Tensor:
@@ -83,9 +69,13 @@ class MultiscaleDeformableAttention(nn.Module):
         """
         B, I, _ = img.shape  # noqa: E741
         N = queries.shape[1]
-        H = self.num_heads
-        sampling_points, attention_weights = self.sampling_inputs(img_shapes, queries, reference_points)
+        H, L, P = self.num_heads, self.num_levels, self.num_points
+        if reference_points.shape[-1] not in (2, 4):
+            raise ValueError(
+                f"`reference_points` should have the last dim either 2 or 4, but got {reference_points.shape[-1]}.")
+        # one projection holds (x offset, y offset, attention logit) per (head, level, point); on the GPU the softmax
+        # and the offset -> sampling-point math run inside the attention kernel's prologue
+        proj = self.query_input_proj(queries).reshape(B, N, H, L, P, 3)
         value = self.img_input_proj(img).reshape(B, I, H, self.hidden_dim // H)
-        attended = multiscale_deformable_attention(
-            value, img_shapes, sampling_points, attention_weights, self.padding_mode, self.align_corners)
+        attended = fused_module_core(value, img_shapes, proj, reference_points, self.padding_mode, self.align_corners)
         return self.query_output_proj(attended.reshape(B, N, self.hidden_dim))

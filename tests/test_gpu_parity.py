@@ -566,3 +566,67 @@ def test_torch_compile_fullgraph_uses_registered_custom_op():
                           (torch.from_numpy(c["value"]).to(DEV), s, torch.from_numpy(c["loc"]).to(DEV),
                            torch.from_numpy(c["attn"]).to(DEV), True, False),
                           test_utils=("test_schema", "test_faketensor"))
+
+
+# ------------------------------------------------------------------------------------------
+# §8f-1: module prologue (softmax + offsets -> sampling points) fused into the forward kernel
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("coords", [2, 4])
+@pytest.mark.parametrize("name", ["d32_vec_g8", "d5_scalar", "d8_vec_g4", "d64_vec_g16"])
+@pytest.mark.parametrize("pm,ac", [("zeros", False), ("border", True)], ids=["zeros_0", "border_1"])
+def test_fused_module_core_matches_unfused(coords, name, pm, ac):
+    """fused kernel == operator(prologue in PyTorch), forward and every gradient (non-square levels: Q6 order)."""
+    from msda_triton_amd.functional import fused_module_core, module_sampling_inputs
+    ops = _ops()
+    B, Q, H, D, levels, P = SHAPE_MATRIX[name]
+    L = len(levels)
+    g = torch.Generator(device="cpu").manual_seed(zlib.crc32(name.encode()) + coords)
+    value = torch.randn(B, sum(h * w for h, w in levels), H, D, generator=g)
+    proj = torch.randn(B, Q, H, L, P, 3, generator=g) * 1.5
+    ref = torch.rand(B, Q, coords, generator=g)
+    gout = torch.rand(B, Q, H, D, generator=g)
+    s = torch.tensor(levels, device=DEV)
+    res = []
+    for fused in (True, False):
+        v, pr, rf = (t.clone().to(DEV).requires_grad_(True) for t in (value, proj, ref))
+        if fused:
+            out = fused_module_core(v, s, pr, rf, pm, ac)
+        else:
+            pts, att = module_sampling_inputs(pr, s, rf)
+            out = ops.multiscale_deformable_attention(v, s, pts, att, pm, ac)
+        out.backward(gout.to(DEV))
+        res.append((out.detach(), v.grad, pr.grad, rf.grad))
+    torch.testing.assert_close(res[0][0], res[1][0], atol=2e-5, rtol=1e-4)
+    for a, b in zip(res[0][1:], res[1][1:]):
+        torch.testing.assert_close(a, b, atol=1e-3, rtol=1e-3)
+
+
+def test_fused_module_core_is_the_module_path_and_handles_large_lp():
+    """The nn.Module uses the fused kernel on the GPU (same numbers as its host path); L*P too large for one
+    LDS pass falls back to the unfused GPU route without error."""
+    from msda_triton_amd import _lib
+    from msda_triton_amd.functional import KernelTimer, fused_module_core, module_sampling_inputs
+    ops = _ops()
+    torch.manual_seed(3)
+    m = ops.MultiscaleDeformableAttention(64, 64, 3, 4, 4, "zeros", False)
+    shapes = [(7, 5), (4, 3), (2, 2)]
+    I = sum(h * w for h, w in shapes)  # noqa: E741
+    img, q, ref = torch.randn(2, I, 64), torch.randn(2, 50, 64), torch.rand(2, 50, 4)
+    out_cpu = m(img, torch.tensor(shapes), q, ref)
+    m = m.to(DEV)
+    with KernelTimer() as kt:
+        out_gpu = m(img.to(DEV), torch.tensor(shapes, device=DEV), q.to(DEV), ref.to(DEV))
+        torch.cuda.synchronize()
+    assert "msda_fwd_fused" in kt.summary()
+    torch.testing.assert_close(out_gpu.cpu(), out_cpu, atol=1e-4, rtol=1e-3)
+    # L*P = 2 * 640 = 1280 samples per unit do not fit one pass
+    levels = [(3, 3), (2, 2)]
+    v = torch.randn(1, 13, 1, 8, device=DEV)
+    pr = torch.randn(1, 3, 1, 2, 640, 3, device=DEV)
+    rf = torch.rand(1, 3, 2, device=DEV)
+    s = torch.tensor(levels, device=DEV)
+    got = fused_module_core(v, s, pr, rf, "border", True)
+    pts, att = module_sampling_inputs(pr, s, rf)
+    want = ops.multiscale_deformable_attention(v, s, pts, att, "border", True)
+    torch.testing.assert_close(got, want, atol=2e-5, rtol=1e-4)
+    assert _lib.load().msda_abi_version() == _lib.ABI_VERSION

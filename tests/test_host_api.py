@@ -18,7 +18,7 @@ def _declared_symbols():
     names = {n for n in names if "##" not in n}
     for suf in re.findall(r"MSDA_DECLARE\((\w+)\)", text):
         if suf != "SUF":
-            names |= {f"msda_fwd_{suf}", f"msda_bwd_{suf}"}
+            names |= {f"msda_fwd_{suf}", f"msda_bwd_{suf}", f"msda_fwd_fused_{suf}"}
     return names
 
 
