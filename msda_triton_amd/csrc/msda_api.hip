@@ -3,7 +3,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <hip/hip_runtime.h>
+
 #include <atomic>
+#include <mutex>
 
 #include "../../include/msda_hip.h"
 
@@ -15,6 +18,54 @@ static std::atomic<int> g_stage_kb{0};
 static std::atomic<int> g_gather_block{1024};
 static std::atomic<int> g_wg_target{1 << 30};
 static std::atomic<int> g_debug{0};
+static std::atomic<int> g_overlap{0};
+
+// one side stream + two events per device, created on first use and kept for the life of the process
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool tried = false;
+};
+static SideStream g_side[64];
+static std::mutex g_side_mutex;
+
+static SideStream *side_for_current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    SideStream &s = g_side[dev];
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    if (!s.tried) {
+        s.tried = true;
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            s.stream = nullptr;
+        }
+    }
+    return s.stream ? &s : nullptr;
+}
+
+hipStream_t side_stream_fork(hipStream_t user)
+{
+    SideStream *s = side_for_current_device();
+    if (s == nullptr) return nullptr;
+    if (hipEventRecord(s->fork, user) != hipSuccess || hipStreamWaitEvent(s->stream, s->fork, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return s->stream;
+}
+
+int side_stream_join(hipStream_t user)
+{
+    SideStream *s = side_for_current_device();
+    if (s == nullptr) return (int)hipErrorInvalidValue;
+    hipError_t e = hipEventRecord(s->join, s->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(user, s->join, 0);
+    return (int)e;
+}
 static thread_local char g_err[256] = "";
 
 int option_xcd_map() { return g_xcd_map.load(std::memory_order_relaxed); }
@@ -23,6 +74,7 @@ int option_stage_kb() { return g_stage_kb.load(std::memory_order_relaxed); }
 int option_gather_block() { return g_gather_block.load(std::memory_order_relaxed); }
 int option_wg_target() { return g_wg_target.load(std::memory_order_relaxed); }
 int option_debug() { return g_debug.load(std::memory_order_relaxed); }
+int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
 
 void set_error(const char *fmt, ...)
 {
@@ -70,6 +122,10 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_debug.store(value, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "overlap") == 0) {
+        msda::g_overlap.store(value ? 1 : 0, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "wg_target") == 0 && value >= 1) {
         msda::g_wg_target.store(value, std::memory_order_relaxed);
         return 0;
@@ -86,6 +142,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "gather_block") == 0) return msda::option_gather_block();
     if (key && strcmp(key, "wg_target") == 0) return msda::option_wg_target();
     if (key && strcmp(key, "debug") == 0) return msda::option_debug();
+    if (key && strcmp(key, "overlap") == 0) return msda::option_overlap();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

@@ -16,6 +16,10 @@ int option_stage_kb();    // LDS KiB a gather workgroup may spend on staged pyra
 int option_gather_block();  // threads per gather workgroup when staging is on (256 / 512 / 1024)
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
 int option_debug();         // dev-only ablation mask
+int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream
+// fork-join helpers around a lazily created per-device side stream (msda_api.hip)
+hipStream_t side_stream_fork(hipStream_t user);   // side stream that waits for everything queued on `user`
+int side_stream_join(hipStream_t user);            // `user` waits for everything queued on the side stream
 void set_error(const char *fmt, ...);
 
 constexpr int kRecordLdsBudget = 48 * 1024;                // per workgroup, parked sample records
@@ -481,11 +485,23 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     p.grad_loc = grad_loc;
     p.grad_attn = grad_attn;
     fill_params(p, d, padding_mode, align_corners);
+    // The two halves of the backward are independent: when both are wanted, grad_loc/grad_attn run on a
+    // forked side stream next to the grad_value pipeline (fork/join with events: still graph-capturable).
+    hipStream_t sample_stream = stream;
+    bool forked = false;
+    if (want_sample && want_value && option_overlap()) {
+        hipStream_t side = side_stream_fork(stream);
+        if (side != nullptr) {
+            sample_stream = side;
+            forked = true;
+        }
+    }
     if (want_sample) {
         const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
-        rc = dispatch_gather<T, 1>(p, vec_ok, stream);
+        rc = dispatch_gather<T, 1>(p, vec_ok, sample_stream);
         if (rc) {
             set_error("backward (grad_loc/grad_attn) launch failed: %s", hipGetErrorString((hipError_t)rc));
+            if (forked) (void)side_stream_join(stream);
             return rc;
         }
     }
@@ -510,6 +526,13 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
         }
         rc = sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
         if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
+    }
+    if (forked) {
+        const int jrc = side_stream_join(stream);
+        if (rc == 0 && jrc != 0) {
+            set_error("joining the side stream failed: %s", hipGetErrorString((hipError_t)jrc));
+            rc = jrc;
+        }
     }
     return rc;
 }
