@@ -287,7 +287,8 @@ __global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
                             a = TR::to_acc(attn[sidx]);
                         }
                         Taps<A> t;
-                        make_taps<A>(sx, sy, tab->h[l], tab->w[l], 0, p.zeros, p.align, 1u, t);
+                        make_taps<A>(sx, sy, tab->h[l], tab->w[l], STAGE ? 0 : tab->start[l], p.zeros, p.align,
+                                     STAGE ? 1u : row_bytes, t);
                         const A wy0 = (A)1 - t.dy, wx0 = (A)1 - t.dx;
                         Rec4<A> w;
                         w.v[0] = a * (wy0 * wx0);
@@ -295,9 +296,10 @@ __global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
                         w.v[2] = a * (t.dy * wx0);
                         w.v[3] = a * (t.dy * t.dx);
                         const int rslot = fu * scp + (sl - s0);
-                        w_off[rslot] =
-                            record_offsets(t, STAGE ? lds.plan->off[l] : -1, STAGE ? lds.plan->zero_off : 0, row_b, tab->start[l],
-                                           row_bytes);
+                        if constexpr (STAGE)
+                            w_off[rslot] = record_offsets(t, lds.plan->off[l], lds.plan->zero_off, row_b, tab->start[l], row_bytes);
+                        else
+                            w_off[rslot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
                         w_rec[rslot] = w;
                     }
                 }
@@ -307,8 +309,8 @@ __global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
                     const uint4 *uo = w_off + wunit * scp;
                     const Rec4<A> *uw = w_rec + wunit * scp;
                     int s = 0;
-                    while (s < sc) {
-                        const int l = (s0 + s) / p.P;  // uniform
+                    int l = div_small(s0, p.P, inv_P);  // level of the first sample; later runs are the next levels
+                    for (; s < sc; ++l) {
                         const int run_end = min(sc, (l + 1) * p.P - s0);
                         if (STAGE && lds.plan->off[l] >= 0) {
 #pragma unroll 4
@@ -431,7 +433,8 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                     const A a = TR::to_acc(attn[sidx]);
                     const int lh = tab->h[l], lw = tab->w[l];
                     Taps<A> t;
-                    make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), lh, lw, 0, p.zeros, p.align, 1u, t);
+                    make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), lh, lw, STAGE ? 0 : tab->start[l], p.zeros, p.align,
+                                 STAGE ? 1u : row_bytes, t);
                     const A sx = p.align ? (A)(lw - 1) : (A)lw;
                     const A sy = p.align ? (A)(lh - 1) : (A)lh;
                     Rec4<A> r;
@@ -440,9 +443,10 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                     r.v[2] = t.gx_on ? a * sx : (A)0;
                     r.v[3] = t.gy_on ? a * sy : (A)0;
                     const int rslot = fu * scp + (sl - s0);
-                    w_off[rslot] =
-                        record_offsets(t, STAGE ? lds.plan->off[l] : -1, STAGE ? lds.plan->zero_off : 0, row_b, tab->start[l],
-                                           row_bytes);
+                    if constexpr (STAGE)
+                        w_off[rslot] = record_offsets(t, lds.plan->off[l], lds.plan->zero_off, row_b, tab->start[l], row_bytes);
+                    else
+                        w_off[rslot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
                     w_rec[rslot] = r;
                 }
             }
