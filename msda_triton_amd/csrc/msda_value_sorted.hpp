@@ -428,7 +428,9 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
 
     const Entry<A> *entries = static_cast<const Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
     const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
-    const uint32_t q_stride = (uint32_t)(p.H * p.D);  // elements; q * q_stride < 2^31 is checked on the host
+    const uint32_t q_stride = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);  // bytes; Q*H*D*sizeof < 2^31 is checked on the host
+    // grad_out rows of this plane through a buffer descriptor: scalar base + 32-bit byte offset per lane
+    const rsrc_t rs_go = make_rsrc(gout, (uint32_t)(((size_t)p.Q * p.H * p.D - (size_t)h * p.D) * sizeof(T)));
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
 
     const int4 *rec = p.ws_items + ((size_t)pair * p.it_cap + item0) * 3;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
         for (int cc = 0; cc < nchan_chunks; ++cc) {
             const int c0 = (cc * G + j) * VEC;
             const bool lane_ok = c0 < p.D;
-            const T *grow = gout + (lane_ok ? c0 : 0);
+            const uint32_t lane_elem = (lane_ok ? (uint32_t)c0 : 0u) * (uint32_t)sizeof(T);
             A acc[VEC];
     #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = (A)0;
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
                         for (int u = 0; u < UB; ++u) {
                             const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj + u, kWave);
                             wgt[u] = __shfl(cur_w, lane_base + jj + u, kWave);
-                            g[u] = *reinterpret_cast<const Pack<T, VEC> *>(grow + q);
+                            g[u] = __builtin_bit_cast(Pack<T, VEC>, RawLoad<sizeof(T) * VEC>::load(rs_go, q + lane_elem));
                         }
     #pragma unroll
                         for (int u = 0; u < UB; ++u)
