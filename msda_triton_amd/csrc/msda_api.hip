@@ -17,6 +17,7 @@ static std::atomic<int> g_value_path{0};
 static std::atomic<int> g_stage_kb{0};
 static std::atomic<int> g_gather_block{1024};
 static std::atomic<int> g_wg_target{1 << 30};
+static std::atomic<int> g_cell_slices{0};
 static std::atomic<int> g_debug{0};
 static std::atomic<int> g_overlap{0};
 
@@ -73,6 +74,7 @@ int option_value_path() { return g_value_path.load(std::memory_order_relaxed); }
 int option_stage_kb() { return g_stage_kb.load(std::memory_order_relaxed); }
 int option_gather_block() { return g_gather_block.load(std::memory_order_relaxed); }
 int option_wg_target() { return g_wg_target.load(std::memory_order_relaxed); }
+int option_cell_slices() { return g_cell_slices.load(std::memory_order_relaxed); }
 int option_debug() { return g_debug.load(std::memory_order_relaxed); }
 int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
 
@@ -126,6 +128,10 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_overlap.store(value ? 1 : 0, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "cell_slices") == 0 && value >= 0 && value <= 64) {
+        msda::g_cell_slices.store(value, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "wg_target") == 0 && value >= 1) {
         msda::g_wg_target.store(value, std::memory_order_relaxed);
         return 0;
@@ -141,6 +147,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "stage_kb") == 0) return msda::option_stage_kb();
     if (key && strcmp(key, "gather_block") == 0) return msda::option_gather_block();
     if (key && strcmp(key, "wg_target") == 0) return msda::option_wg_target();
+    if (key && strcmp(key, "cell_slices") == 0) return msda::option_cell_slices();
     if (key && strcmp(key, "debug") == 0) return msda::option_debug();
     if (key && strcmp(key, "overlap") == 0) return msda::option_overlap();
     msda::set_error("unknown option '%s'", key ? key : "(null)");

@@ -53,11 +53,11 @@ struct Params {
     // sorted (gather-formulated) grad_value path: caller-provided workspace, see msda_value_sorted.hpp
     int *ws_part;       // [pairs][nsplit][nc_cap]  per-slice cell counts, then each slice's first slot per cell
     int *ws_off;        // [pairs][nc_cap+1]  exclusive offsets of the cell lists
-    int2 *ws_pixinfo;   // [pairs][I]         per pixel: (first work item, number of chunks)
+    int *ws_cellitem;   // [pairs][nc_cap+1]  first work item of every cell (and the plane's total behind the last cell)
     int *ws_itemcnt;    // [pairs]            work items of the plane
-    int4 *ws_items;     // [pairs][it_cap][3] per work item: (pixel, chunks of the pixel, -, -), 4 entry-list starts, 4 lengths
+    int2 *ws_items;     // [pairs][it_cap]    per work item: (first record, records) — a window of one cell's list
     void *ws_entries;   // [pairs][Q*L*P]     Entry<acc>: sample records sorted by cell
-    void *ws_scratch;   // [pairs][it_cap][D] acc-typed partial rows of multi-chunk pixels
+    void *ws_scratch;   // [pairs][it_cap][4][D] acc-typed partial rows: one per work item and cell corner
     int nc_cap, it_cap;
     int nsplit;         // query slices per plane in the count / place passes
     int cell_cap;       // cells a count / place workgroup holds in LDS at a time

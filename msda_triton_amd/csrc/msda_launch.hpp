@@ -252,7 +252,7 @@ template <typename T, int VEC, int G> inline int launch_value_gather(Params &p, 
     constexpr int NU = kBlock / G, NUG = kGatherItemBlock / G;
     const int npairs = p.B * p.H;
     dim3 g4, g5;
-    if (!plane_grid(p, npairs, (p.it_cap + NUG * kItemsPerGroup - 1) / (NUG * kItemsPerGroup), g4)) {
+    if (!plane_grid(p, npairs, (p.it_cap + NUG - 1) / NUG, g4)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
@@ -284,9 +284,9 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     p.ws_part = reinterpret_cast<int *>(ws + w.off_part);
     p.ws_off = reinterpret_cast<int *>(ws + w.off_off);
-    p.ws_pixinfo = reinterpret_cast<int2 *>(ws + w.off_pixinfo);
+    p.ws_cellitem = reinterpret_cast<int *>(ws + w.off_cellitem);
     p.ws_itemcnt = reinterpret_cast<int *>(ws + w.off_itemcnt);
-    p.ws_items = reinterpret_cast<int4 *>(ws + w.off_items);
+    p.ws_items = reinterpret_cast<int2 *>(ws + w.off_items);
     p.ws_entries = ws + w.off_entries;
     p.ws_scratch = ws + w.off_scratch;
     p.nc_cap = w.nc_cap;
@@ -299,7 +299,6 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    const int cell_grid3d = p.grid3d;
     const size_t cell_lds = sizeof(LevelTab) + (size_t)p.cell_cap * sizeof(int);
     static bool big_lds_ok = false;
     if (!big_lds_ok) {
@@ -321,13 +320,6 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
         scan_lds_ok = true;
     }
     hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)npairs), dim3(kCellBlock), scan_lds, stream, p);
-    dim3 gitem;
-    if (!plane_grid(p, npairs, (p.I + kBlock - 1) / kBlock, gitem)) {
-        set_error("grid too large");
-        return MSDA_ERR_TOO_LARGE;
-    }
-    hipLaunchKernelGGL((msda_item_kernel<T>), gitem, dim3(kBlock), 0, stream, p);
-    p.grid3d = cell_grid3d;
     hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
     int rc = (int)hipGetLastError();
     if (rc) return rc;

@@ -33,10 +33,9 @@
 namespace msda {
 
 constexpr int kChunk = 64;           // entries per work item
-constexpr int kItemsPerGroup = 1;    // work items a gather group handles back to back
-constexpr int kGatherItemBlock = 256; // threads per workgroup of the gather kernel (no LDS, no barriers)
-constexpr int kItemBuckets = 9;      // work items are bucketed by ceil(entries / 8) = 0..8
-constexpr int kItemMeta = 32;        // ints of per-plane item metadata: total, bucket starts, bucket cursors
+constexpr int kGatherItemBlock = 256; // threads per workgroup of the gather kernel (no block barriers)
+constexpr int kBigChunks = 16;       // cells with more work items than this have their records written by the whole block
+constexpr int kBigCells = 64;        // ... at most this many per plane (the rest falls back to the owning thread)
 constexpr int kCellBlock = 1024;     // threads of K1 / K2b / K3
 constexpr int kCellLdsInts = 36864;  // cells a workgroup keeps in LDS at a time (144 KiB)
 
@@ -240,7 +239,6 @@ __device__ __forceinline__ void cell_scan_body(int *off, const LevelTab &tab, in
                                                int nc, int *goff_copy)
 {
     const int t = threadIdx.x;
-    const int last = p.L - 1;
     // ---- A: exclusive scan of the per-cell totals ----
     {
         const int seg = (nc + kCellBlock - 1) / kCellBlock;
@@ -261,55 +259,43 @@ __device__ __forceinline__ void cell_scan_body(int *off, const LevelTab &tab, in
     if (goff_copy != nullptr)
         for (int c = t; c <= nc; c += kCellBlock) goff_copy[c] = off[c];
 
-    // ---- B: per-pixel list records and work items ----
-    const int seg = (p.I + kCellBlock - 1) / kCellBlock;
-    const int lo = min(p.I, t * seg), hi = min(p.I, lo + seg);
-    int2 *pixinfo = p.ws_pixinfo + (size_t)pair * p.I;
-    // entries of a pixel = entries of its four incident cells
-    auto entries_of = [&](int pix, int &l) {
-        while (l < last && pix >= tab.start[l + 1]) ++l;
-        const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
-        const int y = rel / w, x = rel - y * w;
-        const int c11 = tab.cstart[l] + y * cw + x;  // cell (x0 = x-1, y0 = y-1): this pixel is its corner 11
-        return (off[c11 + 1] - off[c11]) + (off[c11 + 2] - off[c11 + 1]) + (off[c11 + cw + 1] - off[c11 + cw]) +
-               (off[c11 + cw + 2] - off[c11 + cw + 1]);
-    };
-    // Work items are executed in buckets of equal batch count (ceil(entries / 8) in 0..8) so that the groups of a
-    // wave finish together; s_bucket counts the plane's items per bucket.
-    int *s_bucket = s_wave + kCellBlock / kWave;  // 9 ints behind the scan scratch (see the kernel's declaration)
-    if (t < kItemBuckets) s_bucket[t] = 0;
-    // pass 1: count the work items of this thread's pixel segment
-    int sum = 0, l = 0;
-    int nb_full = 0;
-    __syncthreads();
-    for (int pix = lo; pix < hi; ++pix) {
-        const int n = entries_of(pix, l);
-        const int full = n / kChunk, rem = n - full * kChunk;
-        sum += max(1, full + (rem > 0));
-        nb_full += full;
-        if (rem > 0 || n == 0) atomicAdd(&s_bucket[(rem + 7) / 8], 1);
-    }
-    if (nb_full) atomicAdd(&s_bucket[kItemBuckets - 1], nb_full);
+    // ---- B: work items: every non-empty cell list is cut into kChunk-entry windows ----
+    int *cellitem = p.ws_cellitem + (size_t)pair * (p.nc_cap + 1);
+    int2 *items = p.ws_items + (size_t)pair * p.it_cap;
+    int *s_big = s_wave + kCellBlock / kWave;  // [0] = count, [1..kBigCells] = cells whose records the whole block writes
+    if (t == 0) s_big[0] = 0;
+    const int seg = (nc + kCellBlock - 1) / kCellBlock;
+    const int lo = min(nc, t * seg), hi = min(nc, lo + seg);
+    int sum = 0;
+    for (int c = lo; c < hi; ++c) sum += (off[c + 1] - off[c] + kChunk - 1) / kChunk;
     int total;
-    int run = block_exclusive_scan(sum, s_wave, total);
-    // pass 2: first item of every pixel (the records themselves are written by msda_item_kernel)
-    l = 0;
-    for (int pix = lo; pix < hi; ++pix) {
-        const int n = entries_of(pix, l);
-        const int chunks = max(1, (n + kChunk - 1) / kChunk);
-        pixinfo[pix] = make_int2(run, chunks);
+    int run = block_exclusive_scan(sum, s_wave, total);  // (its barriers also publish s_big[0] = 0)
+    for (int c = lo; c < hi; ++c) {
+        const int beg = off[c], n = off[c + 1] - beg;
+        const int chunks = (n + kChunk - 1) / kChunk;
+        cellitem[c] = run;
+        int slot = kBigCells;
+        if (chunks > kBigChunks) slot = atomicAdd(&s_big[0], 1);
+        if (chunks <= kBigChunks || slot >= kBigCells) {
+            for (int k = 0; k < chunks; ++k) items[run + k] = make_int2(beg + k * kChunk, min(kChunk, n - k * kChunk));
+        } else {
+            s_big[1 + slot] = c;
+            s_big[1 + kBigCells + slot] = run;
+        }
         run += chunks;
     }
-    __syncthreads();
     if (t == 0) {
-        int *meta = p.ws_itemcnt + (size_t)pair * kItemMeta;
-        meta[0] = total;
-        int start = 0;
-        for (int k = 0; k < kItemBuckets; ++k) {
-            meta[1 + k] = start;            // bucket start
-            meta[1 + kItemBuckets + k] = 0;  // bucket cursor (msda_item_kernel reserves ranges with it)
-            start += s_bucket[k];
-        }
+        cellitem[nc] = total;
+        p.ws_itemcnt[pair] = total;
+    }
+    __syncthreads();
+    const int nbig = min(s_big[0], kBigCells);
+    for (int i = 0; i < nbig; ++i) {  // hot cells (coarse levels, clustered samples): records written by all threads
+        const int c = s_big[1 + i], first = s_big[1 + kBigCells + i];
+        const int beg = off[c], n = off[c + 1] - beg;
+        const int chunks = (n + kChunk - 1) / kChunk;
+        for (int k = t; k < chunks; k += kCellBlock)
+            items[first + k] = make_int2(beg + k * kChunk, min(kChunk, n - k * kChunk));
     }
 }
 
@@ -317,7 +303,7 @@ template <typename Tag> __global__ __launch_bounds__(kCellBlock) void msda_cell_
 {
     const int pair = blockIdx.x;
     __shared__ LevelTab tab;
-    __shared__ int s_wave[kCellBlock / kWave + kItemBuckets];  // scan scratch + item bucket counters
+    __shared__ int s_wave[kCellBlock / kWave + 1 + 2 * kBigCells];  // scan scratch + hot-cell list
     int *s_off = reinterpret_cast<int *>(msda_smem);
     load_level_table(&tab, p.shapes, p.L);
     __syncthreads();
@@ -334,78 +320,14 @@ template <typename Tag> __global__ __launch_bounds__(kCellBlock) void msda_cell_
 }
 
 // ------------------------------------------------------------------------------------------
-// K2c: work-item records, one thread per pixel (all planes in parallel).  Item k of a pixel covers
-// positions [k*kChunk, (k+1)*kChunk) of the pixel's virtual list (its four cell lists back to back);
-// the record holds that window already clipped against the four lists: (start, count) per list.
+// K4: gather.  One G-lane group per work item (a window of <= kChunk records of ONE cell), VEC channels per lane.
+// A sample's grad_out row is loaded once and blended into the cell's four corner rows; the four partial rows
+// go to scratch[item][corner].
 // ------------------------------------------------------------------------------------------
-template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_item_kernel(const Params p)
-{
-    const int slots = (p.I + kBlock - 1) / kBlock;
-    int pair, slot;
-    if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
-    __shared__ LevelTab tab;
-    load_level_table(&tab, p.shapes, p.L);
-    __syncthreads();
-    const int pix_raw = slot * kBlock + threadIdx.x;
-    const bool pix_ok = pix_raw < p.I;  // idle threads still take part in the barriers below
-    const int pix = pix_ok ? pix_raw : p.I - 1;
-    int l = 0;
-    while (l < p.L - 1 && pix >= tab.start[l + 1]) ++l;
-    const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
-    const int y = rel / w, x = rel - y * w;
-    const int c11 = tab.cstart[l] + y * cw + x;
-    // list i = samples for which the pixel is corner i: 00 -> cell (x, y), 01 -> (x-1, y), 10 -> (x, y-1), 11
-    const int cells[4] = {c11 + cw + 1, c11 + cw, c11 + 1, c11};
-    const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
-    int beg[4], len[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        beg[i] = off[cells[i]];
-        len[i] = off[cells[i] + 1] - beg[i];
-    }
-    const int2 info = pix_ok ? p.ws_pixinfo[(size_t)pair * p.I + pix] : make_int2(0, 0);
-    const int n = len[0] + len[1] + len[2] + len[3];
-    const int full = n / kChunk, rem = n - full * kChunk;
-    const int last_bucket = (rem + 7) / 8;             // bucket of the (possibly empty) partial item
-    const bool has_last = pix_ok && (rem > 0 || n == 0);
-    // reserve slots: first inside the workgroup (LDS), then one global add per bucket and workgroup
-    __shared__ int s_cnt[kItemBuckets], s_base[kItemBuckets];
-    if (threadIdx.x < kItemBuckets) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    int rank_full = 0, rank_last = 0;
-    if (pix_ok && full) rank_full = atomicAdd(&s_cnt[kItemBuckets - 1], full);
-    if (has_last) rank_last = atomicAdd(&s_cnt[last_bucket], 1);
-    __syncthreads();
-    int *meta = p.ws_itemcnt + (size_t)pair * kItemMeta;
-    if (threadIdx.x < kItemBuckets) {
-        const int c = s_cnt[threadIdx.x];
-        s_base[threadIdx.x] = meta[1 + threadIdx.x] + (c ? atomicAdd(&meta[1 + kItemBuckets + threadIdx.x], c) : 0);
-    }
-    __syncthreads();
-    if (!pix_ok) return;
-    int4 *items = p.ws_items + (size_t)pair * p.it_cap * 3;
-    for (int k = 0; k < info.y; ++k) {
-        const int w0 = k * kChunk, w1 = w0 + kChunk;
-        int st[4], cn[4], pos = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int lo = max(w0 - pos, 0), hi = min(w1 - pos, len[i]);
-            st[i] = beg[i] + lo;
-            cn[i] = max(hi - lo, 0);
-            pos += len[i];
-        }
-        const bool is_full = k < full;
-        const int slot = is_full ? s_base[kItemBuckets - 1] + rank_full + k : s_base[last_bucket] + rank_last;
-        int4 *rec = items + (size_t)slot * 3;
-        rec[0] = make_int4(pix, info.y, info.x + k, 0);  // pixel, chunks of the pixel, scratch row of this chunk
-        rec[1] = make_int4(st[0], st[1], st[2], st[3]);
-        rec[2] = make_int4(cn[0], cn[1], cn[2], cn[3]);
-    }
-}
+template <typename A> struct alignas(16) CornerW {
+    A w[4];  // a * {(1-dx)(1-dy), dx(1-dy), (1-dx)dy, dx dy}: corners 00, 01, 10, 11
+};
 
-// ------------------------------------------------------------------------------------------
-// K4: gather.  G lanes per work item, VEC channels per lane (same shape as the forward gather).
-// ------------------------------------------------------------------------------------------
 template <typename T, int VEC, int G>
 __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(const Params p)
 {
@@ -413,18 +335,19 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
     using TR = Traits<T>;
     constexpr int NU = kGatherItemBlock / G;
     constexpr int UB = G < 8 ? G : 8;  // row loads in flight per lane
-    // A group works through kItemsPerGroup consecutive work items (equal batch counts inside a bucket), fetching
-    // the next item's record while it processes the current one: short items would otherwise be all latency.
-    const int slots = (p.it_cap + NU * kItemsPerGroup - 1) / (NU * kItemsPerGroup);
+    const int slots = (p.it_cap + NU - 1) / NU;
     int pair, slot;
     if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
-    const int nitems = p.ws_itemcnt[(size_t)pair * kItemMeta];
+    const int nitems = p.ws_itemcnt[pair];
     const int tid = threadIdx.x;
     const int unit = tid / G, j = tid % G;
-    const int item0 = (slot * NU + unit) * kItemsPerGroup;
-    if (item0 >= nitems) return;
+    const int item = slot * NU + unit;
+    if (item >= nitems) return;  // (no block barriers below: the record hand-off is wave-local)
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
-    const int lane_base = (tid & (kWave - 1)) & ~(G - 1);
+    const int gbase = tid - j;
+
+    __shared__ CornerW<A> s_w[kGatherItemBlock];
+    __shared__ uint32_t s_q[kGatherItemBlock];
 
     const Entry<A> *entries = static_cast<const Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
     const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
@@ -433,97 +356,95 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
     const rsrc_t rs_go = make_rsrc(gout, (uint32_t)(((size_t)p.Q * p.H * p.D - (size_t)h * p.D) * sizeof(T)));
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
 
-    const int4 *rec = p.ws_items + ((size_t)pair * p.it_cap + item0) * 3;
-    int4 hdr = rec[0], beg = rec[1], len = rec[2];
-    for (int k = 0; k < kItemsPerGroup && item0 + k < nitems; ++k) {
-        int4 hdr_n = hdr, beg_n = beg, len_n = len;
-        if (k + 1 < kItemsPerGroup && item0 + k + 1 < nitems) {
-            hdr_n = rec[(k + 1) * 3 + 0];
-            beg_n = rec[(k + 1) * 3 + 1];
-            len_n = rec[(k + 1) * 3 + 2];
-        }
-        const int pix = hdr.x, nchunks = hdr.y, scratch_row = hdr.z;
-        const int c1 = len.x, c2 = c1 + len.y, c3 = c2 + len.z;
-        const int w0 = 0, w1 = c3 + len.w;  // the record is already clipped to this item's window
+    const int2 rec = p.ws_items[(size_t)pair * p.it_cap + item];
+    const int start = rec.x, count = rec.y;  // 1 <= count <= kChunk
 
-        // position v of the pixel's virtual list (lists 0..3 back to back) -> (element offset of the query's
-        // grad_out row inside the plane, a * fx * fy)
-        // Positions past the end of the window are padded with the window's last record at weight 0 (so the
-        // unrolled batches need no tail loop; an empty window reads row 0 at weight 0).
-        auto fetch = [&](int v, uint32_t &q, A &wgt) {
-            q = 0;
-            wgt = (A)0;
-            if (w1 > 0) {
-                const int vc = min(v, w1 - 1);
-                const int i = (vc >= c1) + (vc >= c2) + (vc >= c3);
-                const int base = i == 0 ? beg.x : i == 1 ? beg.y - c1 : i == 2 ? beg.z - c2 : beg.w - c3;
-                const Entry<A> e = entries[base + vc];
-                const A fx = (i & 1) ? e.dx : (A)1 - e.dx;
-                const A fy = (i & 2) ? e.dy : (A)1 - e.dy;
-                q = e.q * q_stride;
-                wgt = v < w1 ? e.a * (fy * fx) : (A)0;
-            }
-        };
+    // record v of the window -> (byte offset of the query's grad_out row inside the plane, four corner weights);
+    // positions past the end are padded with the last record at weight 0 (no tail loop in the unrolled batches)
+    auto fetch = [&](int v, uint32_t &q, CornerW<A> &cw) {
+        const Entry<A> e = entries[start + min(v, count - 1)];
+        const A a = v < count ? e.a : (A)0;
+        const A ax1 = a * e.dx, ax0 = a - ax1;
+        q = e.q * q_stride;
+        cw.w[3] = ax1 * e.dy;
+        cw.w[2] = ax0 * e.dy;
+        cw.w[1] = ax1 - cw.w[3];
+        cw.w[0] = ax0 - cw.w[2];
+    };
 
-        for (int cc = 0; cc < nchan_chunks; ++cc) {
-            const int c0 = (cc * G + j) * VEC;
-            const bool lane_ok = c0 < p.D;
-            const uint32_t lane_elem = (lane_ok ? (uint32_t)c0 : 0u) * (uint32_t)sizeof(T);
-            A acc[VEC];
-    #pragma unroll
-            for (int i = 0; i < VEC; ++i) acc[i] = (A)0;
+    A *scratch = static_cast<A *>(p.ws_scratch) + ((size_t)pair * p.it_cap + item) * 4 * p.D;
+    for (int cc = 0; cc < nchan_chunks; ++cc) {
+        const int c0 = (cc * G + j) * VEC;
+        const bool lane_ok = c0 < p.D;
+        const uint32_t lane_elem = (lane_ok ? (uint32_t)c0 : 0u) * (uint32_t)sizeof(T);
+        A acc[4][VEC];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[k][i] = (A)0;
 
-            uint32_t cur_q, nxt_q;
-            A cur_w, nxt_w;
-            fetch(w0 + j, cur_q, cur_w);
-            for (int v0 = w0; v0 < w1; v0 += G) {
-                fetch(v0 + G + j, nxt_q, nxt_w);  // next batch's records are in flight while this one is consumed
-                const int cnt = min(G, w1 - v0);
-    #pragma unroll
-                for (int jj = 0; jj < G; jj += UB) {  // UB row loads issued back to back, then consumed
-                    if (jj < cnt) {                   // uniform per group; G == UB: always true
-                        A wgt[UB];
-                        Pack<T, VEC> g[UB];
-    #pragma unroll
-                        for (int u = 0; u < UB; ++u) {
-                            const uint32_t q = (uint32_t)__shfl((int)cur_q, lane_base + jj + u, kWave);
-                            wgt[u] = __shfl(cur_w, lane_base + jj + u, kWave);
-                            g[u] = __builtin_bit_cast(Pack<T, VEC>, RawLoad<sizeof(T) * VEC>::load(rs_go, q + lane_elem));
-                        }
-    #pragma unroll
-                        for (int u = 0; u < UB; ++u)
-    #pragma unroll
-                            for (int v = 0; v < VEC; ++v) acc[v] = fma_t(wgt[u], TR::to_acc(g[u].v[v]), acc[v]);
+        uint32_t cur_q;
+        CornerW<A> cur_w;
+        fetch(j, cur_q, cur_w);
+        for (int v0 = 0; v0 < count; v0 += G) {
+            wave_lds_sync();  // the previous batch's records have been read
+            s_q[tid] = cur_q;
+            s_w[tid] = cur_w;
+            if (v0 + G < count) fetch(v0 + G + j, cur_q, cur_w);  // next batch's records in flight meanwhile
+            wave_lds_sync();
+            const int cnt = min(G, count - v0);
+#pragma unroll
+            for (int jj = 0; jj < G; jj += UB) {  // UB row loads issued back to back, then consumed
+                if (jj < cnt) {                   // uniform per group; G == UB: always true
+                    Pack<T, VEC> g[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u)
+                        g[u] = __builtin_bit_cast(Pack<T, VEC>,
+                                                  RawLoad<sizeof(T) * VEC>::load(rs_go, s_q[gbase + jj + u] + lane_elem));
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const CornerW<A> w = s_w[gbase + jj + u];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc[k][v] = fma_t(w.w[k], TR::to_acc(g[u].v[v]), acc[k][v]);
                     }
                 }
-                cur_q = nxt_q;
-                cur_w = nxt_w;
-            }
-            if (lane_ok) {
-                if (nchunks == 1) {
-                    Pack<T, VEC> o;
-    #pragma unroll
-                    for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
-                    T *dst = static_cast<T *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
-                    *reinterpret_cast<Pack<T, VEC> *>(dst) = o;
-                } else {
-                    Pack<A, VEC> o;
-    #pragma unroll
-                    for (int v = 0; v < VEC; ++v) o.v[v] = acc[v];
-                    A *dst = static_cast<A *>(p.ws_scratch) + ((size_t)pair * p.it_cap + scratch_row) * p.D + c0;
-                    *reinterpret_cast<Pack<A, VEC> *>(dst) = o;
-                }
             }
         }
+        if (lane_ok) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Pack<A, VEC> o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o.v[v] = acc[k][v];
+                *reinterpret_cast<Pack<A, VEC> *>(scratch + (size_t)k * p.D + c0) = o;
+            }
+        }
+    }
+}
 
-        hdr = hdr_n;
-        beg = beg_n;
-        len = len_n;
+template <typename A, int VEC> __device__ __forceinline__ Pack<A, VEC> load_acc_pack(rsrc_t r, uint32_t off)
+{
+    constexpr int BYTES = (int)sizeof(A) * VEC;
+    if constexpr (BYTES <= 16) {
+        return __builtin_bit_cast(Pack<A, VEC>, RawLoad<BYTES>::load(r, off));
+    } else {
+        constexpr int N = BYTES / 16, SUB = VEC / N;
+        Pack<A, VEC> o;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const Pack<A, SUB> part = __builtin_bit_cast(Pack<A, SUB>, RawLoad<16>::load(r, off + 16u * i));
+#pragma unroll
+            for (int v = 0; v < SUB; ++v) o.v[i * SUB + v] = part.v[v];
+        }
+        return o;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K5: pixels that were split into several work items: sum the partial rows in chunk order
+// K5: per pixel: sum the partial rows of its four incident cells (the pixel is corner 00 of cell (x, y), 01 of
+// (x-1, y), 10 of (x, y-1), 11 of (x-1, y-1)), in cell and chunk order; every grad_value row is stored here.
 // ------------------------------------------------------------------------------------------
 template <typename T, int VEC, int G>
 __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params p)
@@ -534,26 +455,63 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
     const int slots = (p.I + NU - 1) / NU;
     int pair, slot;
     if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
+    __shared__ LevelTab tab;
+    load_level_table(&tab, p.shapes, p.L);
+    __syncthreads();
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int unit = threadIdx.x / G, j = threadIdx.x % G;
     const int pix = slot * NU + unit;
     if (pix >= p.I) return;
-    const int2 info = p.ws_pixinfo[(size_t)pair * p.I + pix];
-    const int item0 = info.x, nchunks = info.y;
-    if (nchunks <= 1) return;
-    const A *src = static_cast<const A *>(p.ws_scratch) + ((size_t)pair * p.it_cap + item0) * p.D;
+    int l = 0;
+    while (l < p.L - 1 && pix >= tab.start[l + 1]) ++l;
+    const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
+    const int y = rel / w, x = rel - y * w;
+    const int c11 = tab.cstart[l] + y * cw + x;  // cell (x-1, y-1)
+    const int *cellitem = p.ws_cellitem + (size_t)pair * (p.nc_cap + 1);
+    // item ranges of the cells (x-1,y-1), (x,y-1) | (x-1,y), (x,y): consecutive cell ids, consecutive item ranges
+    const int t0 = cellitem[c11], t1 = cellitem[c11 + 1], t2 = cellitem[c11 + 2];
+    const int u0 = cellitem[c11 + cw], u1 = cellitem[c11 + cw + 1], u2 = cellitem[c11 + cw + 2];
+    const A *src = static_cast<const A *>(p.ws_scratch) + (size_t)pair * p.it_cap * 4 * p.D;
+    // the plane's partial rows through a buffer descriptor: an offset of 0x80000000 is out of range and reads 0,
+    // which is how an empty cell contributes nothing without a branch
+    const size_t plane_bytes = (size_t)p.it_cap * 4 * p.D * sizeof(A);
+    const bool use_rsrc = plane_bytes < ((size_t)1 << 31);
+    const rsrc_t rs = make_rsrc(src, (uint32_t)(use_rsrc ? plane_bytes : 0));
+    const uint32_t row_bytes = (uint32_t)p.D * (uint32_t)sizeof(A);
+    const bool simple = use_rsrc && (t1 - t0) <= 1 && (t2 - t1) <= 1 && (u1 - u0) <= 1 && (u2 - u1) <= 1;
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
     for (int cc = 0; cc < nchan_chunks; ++cc) {
         const int c0 = (cc * G + j) * VEC;
         if (c0 >= p.D) continue;
         A acc[VEC];
+        if (simple) {  // at most one work item per cell (fine levels): four independent loads
+            const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(A);
+            const uint32_t o0 = u2 > u1 ? ((uint32_t)u1 * 4 + 0) * row_bytes + lane_off : 0x80000000u;
+            const uint32_t o1 = u1 > u0 ? ((uint32_t)u0 * 4 + 1) * row_bytes + lane_off : 0x80000000u;
+            const uint32_t o2 = t2 > t1 ? ((uint32_t)t1 * 4 + 2) * row_bytes + lane_off : 0x80000000u;
+            const uint32_t o3 = t1 > t0 ? ((uint32_t)t0 * 4 + 3) * row_bytes + lane_off : 0x80000000u;
+            const Pack<A, VEC> r0 = load_acc_pack<A, VEC>(rs, o0);
+            const Pack<A, VEC> r1 = load_acc_pack<A, VEC>(rs, o1);
+            const Pack<A, VEC> r2 = load_acc_pack<A, VEC>(rs, o2);
+            const Pack<A, VEC> r3 = load_acc_pack<A, VEC>(rs, o3);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = (A)0;
-#pragma unroll 8
-        for (int k = 0; k < nchunks; ++k) {
-            const Pack<A, VEC> r = *reinterpret_cast<const Pack<A, VEC> *>(src + (size_t)k * p.D + c0);
+            for (int v = 0; v < VEC; ++v) acc[v] = ((r0.v[v] + r1.v[v]) + r2.v[v]) + r3.v[v];
+        } else {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] += r.v[v];
+            for (int v = 0; v < VEC; ++v) acc[v] = (A)0;
+            auto add = [&](int first, int last, int corner) {
+#pragma unroll 4
+                for (int it = first; it < last; ++it) {
+                    const Pack<A, VEC> r =
+                        *reinterpret_cast<const Pack<A, VEC> *>(src + ((size_t)it * 4 + corner) * p.D + c0);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] += r.v[v];
+                }
+            };
+            add(u1, u2, 0);
+            add(u0, u1, 1);
+            add(t1, t2, 2);
+            add(t0, t1, 3);
         }
         Pack<T, VEC> o;
 #pragma unroll
@@ -568,8 +526,10 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
 // ------------------------------------------------------------------------------------------
 struct SortedWsLayout {
     int nc_cap, it_cap, nsplit;
-    size_t off_part, off_off, off_pixinfo, off_itemcnt, off_items, off_entries, off_scratch, total;
+    size_t off_part, off_off, off_cellitem, off_itemcnt, off_items, off_entries, off_scratch, total;
 };
+
+int option_cell_slices();  // 0: automatic (msda_api.hip)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -580,11 +540,12 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     const size_t pairs = (size_t)(B * H);
     const size_t samples = (size_t)(Q * L * P);  // per plane
     w.nc_cap = (int)(2 * I + 2 * L);             // (w+1)(h+1) <= 2wh + 2 per level
-    w.it_cap = (int)(I + (4 * samples + kChunk - 1) / kChunk + 1);
+    w.it_cap = (int)(w.nc_cap + samples / kChunk + 1);  // sum over cells of ceil(n / kChunk)
     // query slices per plane: enough workgroups to fill the chip, at least ~2k samples each
     int64_t ns = pairs ? (int64_t)((256 + pairs - 1) / pairs) : 1;
     const int64_t by_work = (int64_t)((samples + 2047) / 2048);
     if (ns > by_work) ns = by_work;
+    if (option_cell_slices() > 0) ns = option_cell_slices();
     if (ns > 64) ns = 64;
     if (ns > Q) ns = Q;
     if (ns < 1) ns = 1;
@@ -593,11 +554,11 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     size_t o = 0;
     w.off_part = o;     o = align_up(o + pairs * w.nsplit * (size_t)w.nc_cap * 4, 256);
     w.off_off = o;      o = align_up(o + pairs * ((size_t)w.nc_cap + 1) * 4, 256);
-    w.off_pixinfo = o;  o = align_up(o + pairs * (size_t)I * 8, 256);
-    w.off_itemcnt = o;  o = align_up(o + pairs * kItemMeta * 4, 256);
-    w.off_items = o;    o = align_up(o + pairs * (size_t)w.it_cap * 48, 256);
+    w.off_cellitem = o; o = align_up(o + pairs * ((size_t)w.nc_cap + 1) * 4, 256);
+    w.off_itemcnt = o;  o = align_up(o + pairs * 4, 256);
+    w.off_items = o;    o = align_up(o + pairs * (size_t)w.it_cap * 8, 256);
     w.off_entries = o;  o = align_up(o + pairs * samples * entry_bytes, 256);
-    w.off_scratch = o;  o = align_up(o + pairs * (size_t)w.it_cap * (size_t)D * acc_bytes, 256);
+    w.off_scratch = o;  o = align_up(o + pairs * (size_t)w.it_cap * 4 * (size_t)D * acc_bytes, 256);
     w.total = o;
     return w;
 }

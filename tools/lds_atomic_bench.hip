@@ -11,7 +11,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 __device__ __forceinline__ uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s >> 8; }
 
 // MODE 0: f32 atomic AoS [pix][4]; 1: f32 atomic SoA [4][npx]; 2: u32 atomic AoS; 3: u32 SoA; 4: u64 atomic SoA
-// 5: non-atomic f32 RMW SoA; 6: f32 atomic with return SoA; 7: f32 atomic, 1 channel only (SoA); 8: f64 atomic SoA
+// 5: non-atomic f32 RMW SoA; 9: u32 atomic with return SoA; 6: f32 atomic with return SoA; 7: f32 atomic, 1 channel only (SoA); 8: f64 atomic SoA
 template <int MODE> __global__ __launch_bounds__(1024) void k(int npx, int iters, float *sink)
 {
     float *f = reinterpret_cast<float *>(smem);
@@ -49,6 +49,9 @@ template <int MODE> __global__ __launch_bounds__(1024) void k(int npx, int iters
             for (int c = 0; c < 4; ++c) acc += atomicAdd(&f[c * npx + pix], v);
         } else if constexpr (MODE == 7) {
             atomicAdd(&f[pix], v);
+        } else if constexpr (MODE == 9) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc += (float)atomicAdd(&u[c * npx + pix], 1u);
         } else if constexpr (MODE == 8) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) atomicAdd(&d[c * npx + pix], (double)v);
@@ -96,6 +99,7 @@ int main()
         run<5>("f32 plain RMW SoA (racy)", npx, iters, sink);
         run<6>("f32 atomic rtn SoA", npx, iters, sink);
         run<7>("f32 atomic 1 channel", npx, iters, sink);
+        run<9>("u32 atomic rtn SoA", npx, iters, sink);
         if (npx * 32 <= 160 * 1024) run<8>("f64 atomic  SoA", npx, iters, sink);
     }
     return 0;
