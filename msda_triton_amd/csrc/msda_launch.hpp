@@ -512,7 +512,7 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
             if (ch) {
                 const double s_plane = (double)Q * (double)(L * P), planes = (double)(B * H);
                 const double rounds = (double)((int64_t)(planes * (double)(D / ch) + 255) / 256);
-                const double t_tile = rounds * s_plane * 2.2e-3, t_sorted = 50.0 + planes * s_plane * 5e-5;
+                const double t_tile = rounds * s_plane * 2.2e-3, t_sorted = 50.0 + planes * s_plane * 3.5e-5;
                 if (t_tile < t_sorted) sorted = false;
             }
         }

@@ -359,13 +359,14 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
     const int2 rec = p.ws_items[(size_t)pair * p.it_cap + item];
     const int start = rec.x, count = rec.y;  // 1 <= count <= kChunk
 
-    // record v of the window -> (byte offset of the query's grad_out row inside the plane, four corner weights);
-    // positions past the end are padded with the last record at weight 0 (no tail loop in the unrolled batches)
-    auto fetch = [&](int v, uint32_t &q, CornerW<A> &cw) {
-        const Entry<A> e = entries[start + min(v, count - 1)];
-        const A a = v < count ? e.a : (A)0;
+    // record v of the window -> (byte offset of the query's grad_out row inside the plane, four corner weights).
+    // Positions past the end get weight 0 and an out-of-range offset (the buffer load then returns 0 without
+    // touching memory), so the unrolled batches need no tail loop.
+    auto convert = [&](const Entry<A> &e, int v, uint32_t &q, CornerW<A> &cw) {
+        const bool ok = v < count;
+        const A a = ok ? e.a : (A)0;
         const A ax1 = a * e.dx, ax0 = a - ax1;
-        q = e.q * q_stride;
+        q = ok ? e.q * q_stride : 0x80000000u;
         cw.w[3] = ax1 * e.dy;
         cw.w[2] = ax0 * e.dy;
         cw.w[1] = ax1 - cw.w[3];
@@ -383,14 +384,16 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[k][i] = (A)0;
 
-        uint32_t cur_q;
-        CornerW<A> cur_w;
-        fetch(j, cur_q, cur_w);
+        Entry<A> e_cur = entries[start + min(j, count - 1)];
         for (int v0 = 0; v0 < count; v0 += G) {
+            uint32_t cur_q;
+            CornerW<A> cur_w;
+            convert(e_cur, v0 + j, cur_q, cur_w);
             wave_lds_sync();  // the previous batch's records have been read
             s_q[tid] = cur_q;
             s_w[tid] = cur_w;
-            if (v0 + G < count) fetch(v0 + G + j, cur_q, cur_w);  // next batch's records in flight meanwhile
+            // the next batch's record (clamped: always a valid address) is in flight while this batch is consumed
+            e_cur = entries[start + min(v0 + G + j, count - 1)];
             wave_lds_sync();
             const int cnt = min(G, count - v0);
 #pragma unroll
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
                     for (int u = 0; u < UB; ++u)
                         g[u] = __builtin_bit_cast(Pack<T, VEC>,
                                                   RawLoad<sizeof(T) * VEC>::load(rs_go, s_q[gbase + jj + u] + lane_elem));
+                    __builtin_amdgcn_sched_barrier(0);  // keep the UB loads together: hipcc otherwise serialises some
 #pragma unroll
                     for (int u = 0; u < UB; ++u) {
                         const CornerW<A> w = s_w[gbase + jj + u];
