@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--workload", default="c2_q10k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--xcd-map", type=int, default=None, help="override the blockIdx->(b,h) mapping (A/B runs)")
+    ap.add_argument("--grad-value-sync", default="owners", choices=["owners", "all_reduce", "none"],
+                    help="multi-GPU: how grad_value is combined (owners: among the ranks sharing a batch element)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and use the sharded code path even with one rank (self-test)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
@@ -101,7 +103,7 @@ def main():
     import torch.distributed as dist
 
     from msda_triton_amd import _lib, synth
-    from msda_triton_amd.distributed import sharded_multiscale_deformable_attention
+    from msda_triton_amd.distributed import row_shard_bounds, row_sharded_multiscale_deformable_attention
     from msda_triton_amd.functional import KernelTimer, multiscale_deformable_attention
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,17 +130,22 @@ def main():
 
     wl = synth.WORKLOADS[args.workload]
     pm, ac = wl.padding_mode, wl.align_corners
-    # rank r owns global queries [r*Q, (r+1)*Q) of a (world*Q)-query problem; value is replicated
+    # Weak scaling: the global problem has B batch elements of world*Q queries; rank r owns B*Q contiguous rows of
+    # the flattened (b, q) row space — whole batch elements while the ranks divide B.
     gwl = synth.Workload(wl.name, wl.B, wl.Q * world, wl.H, wl.D, wl.levels, wl.P, wl.dtype, pm, ac)
-    d = synth.make_inputs_torch(gwl, dev, seed=0, q_begin=rank * wl.Q, q_end=(rank + 1) * wl.Q)
+    if use_dist:
+        r0, r1 = row_shard_bounds(gwl.B * gwl.Q, world, rank)
+        d = synth.make_inputs_torch(gwl, dev, seed=0, rows=(r0, r1))
+    else:
+        d = synth.make_inputs_torch(gwl, dev, seed=0)
     img, shapes = d["value"].requires_grad_(True), d["shapes"]
     pts, attn = d["loc"].requires_grad_(True), d["attn"].requires_grad_(True)
 
     def op():
         if not use_dist:
             return multiscale_deformable_attention(img, shapes, pts, attn, pm, ac)
-        return sharded_multiscale_deformable_attention(img, shapes, pts, attn, pm, ac, inputs_are_sharded=True,
-                                                       num_queries=gwl.Q)
+        return row_sharded_multiscale_deformable_attention(img, shapes, pts, attn, pm, ac, inputs_are_sharded=True,
+                                                           num_queries=gwl.Q, grad_value_sync=args.grad_value_sync)
 
     def step():
         out = op()
@@ -212,7 +219,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{wl.name}: B={wl.B} Q={wl.Q}/rank H={wl.H} D={wl.D} L={wl.L} "
                                    f"levels={list(wl.levels)} P={wl.P} {wl.dtype} {pm} align_corners={ac}",
-                       "global_queries": gwl.Q, "parallelism": f"query-shard x{world}",
+                       "global_queries": gwl.Q,
+                       "parallelism": f"row-shard x{world} (B*Q rows per rank, one all-gather of the outputs"
+                                      f"{', grad_value ' + args.grad_value_sync if use_dist else ''})",
                        "step": "public autograd API: fwd + backward(rand_like(out)) + grad reset"},
             "fwd_ms": ms_fwd,
             "fwd_bwd_ms": ms_step,
@@ -223,7 +232,7 @@ def main():
             "reference_readme_rtx2060_ms": README_RTX2060_MS,
             "speedup_vs_reference_readme": {"fwd": README_RTX2060_MS["fwd"] / ms_fwd,
                                             "fwd_bwd": README_RTX2060_MS["fwd_bwd"] / ms_step},
-            "roofline": {"kernel": dom + (" (sorted-gather pipeline: cell_pass x2, cell_total, cell_scan, item, "
+            "roofline": {"kernel": dom + (" (sorted-gather pipeline: cell_pass x2, cell_total, cell_scan, "
                                           "value_gather, value_finish; timed as one C-ABI call)"
                                           if dom == "msda_bwd_value" else ""), "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic,

@@ -136,12 +136,30 @@ def make_inputs_numpy(wl: Workload, seed: int = 0, q_begin: int = 0, q_end: int 
     return {"value": value, "shapes": shapes, "loc": loc, "attn": att, "grad_out": gout}
 
 
-def make_inputs_torch(wl: Workload, device="cpu", seed: int = 0, dtype=None, **kw):
-    """Same data as :func:`make_inputs_numpy`, as torch tensors of the workload dtype."""
+def make_row_inputs_numpy(wl: Workload, seed: int = 0, r_begin: int = 0, r_end: int | None = None):
+    """Rows [r_begin, r_end) of the flattened (b, q) row space (row = b * Q + q): the same numbers as the
+    corresponding slices of :func:`make_inputs_numpy` (softmax attention, loc in [0, 1]).
+    Returns dict(value [B,I,H,D], shapes, loc [n,H,L,P,2], attn [n,H,L,P], grad_out [n,H,D])."""
+    B, I, H, D, Q, L, P = wl.B, wl.I, wl.H, wl.D, wl.Q, wl.L, wl.P
+    r_end = B * Q if r_end is None else r_end
+    n = r_end - r_begin
+    per_q_loc, per_q_att, per_q_out = H * L * P * 2, H * L * P, H * D
+    value = normal(seed, 1, B * I * H * D).reshape(B, I, H, D)
+    loc = uniform(seed, 2, n * per_q_loc, r_begin * per_q_loc).reshape(n, H, L, P, 2)
+    a = normal(seed, 3, n * per_q_att, r_begin * per_q_att).reshape(n, H, L, P)
+    a = np.exp(a - a.max(-1, keepdims=True))
+    att = a / a.sum(-1, keepdims=True)
+    gout = uniform(seed, 4, n * per_q_out, r_begin * per_q_out).reshape(n, H, D)
+    return {"value": value, "shapes": np.asarray(wl.levels, dtype=np.int64), "loc": loc, "attn": att, "grad_out": gout}
+
+
+def make_inputs_torch(wl: Workload, device="cpu", seed: int = 0, dtype=None, rows=None, **kw):
+    """Same data as :func:`make_inputs_numpy` (or, with ``rows=(r0, r1)``, :func:`make_row_inputs_numpy`), as torch
+    tensors of the workload dtype."""
     import torch
 
     dt = getattr(torch, wl.dtype) if dtype is None else dtype
-    d = make_inputs_numpy(wl, seed, **kw)
+    d = make_row_inputs_numpy(wl, seed, rows[0], rows[1]) if rows is not None else make_inputs_numpy(wl, seed, **kw)
     out = {}
     for k, v in d.items():
         t = torch.from_numpy(v)

@@ -74,3 +74,83 @@ def test_shard_bounds_cover_and_partition():
             assert spans[0][0] == 0 and spans[-1][1] == q
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert len({e - b for b, e in spans if e - b == -(-q // world)}) <= 1
+
+
+# ---------------------------------------------------------------------------------------------
+# row partition (flattened (b, q) row space): what bench.py --gpus N runs
+# ---------------------------------------------------------------------------------------------
+def _row_worker(rank, world, port, batch, q_total, sharded_inputs, value_sync, grad_sync, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from msda_triton_amd import multiscale_deformable_attention, synth
+        from msda_triton_amd.distributed import (row_segments, row_shard_bounds,
+                                                 row_sharded_multiscale_deformable_attention)
+        wl = synth.Workload("t", batch, q_total, 3, 8, ((6, 5), (3, 3)), 2, "float64", "zeros", False)
+        d = synth.make_inputs_torch(wl, "cpu", seed=5)
+        rows = batch * q_total
+        r0, r1 = row_shard_bounds(rows, world, rank)
+        v = d["value"].clone().requires_grad_(True)
+        if sharded_inputs:
+            dr = synth.make_inputs_torch(wl, "cpu", seed=5, rows=(r0, r1))
+            l_in, a_in = dr["loc"].clone().requires_grad_(True), dr["attn"].clone().requires_grad_(True)
+            out = row_sharded_multiscale_deformable_attention(v, d["shapes"], l_in, a_in, "zeros", False,
+                                                              inputs_are_sharded=True, num_queries=q_total,
+                                                              grad_value_sync=value_sync, grad_sync=grad_sync)
+        else:
+            l_in, a_in = d["loc"].clone().requires_grad_(True), d["attn"].clone().requires_grad_(True)
+            out = row_sharded_multiscale_deformable_attention(v, d["shapes"], l_in, a_in, "zeros", False,
+                                                              grad_value_sync=value_sync, grad_sync=grad_sync)
+        g = d["grad_out"] if grad_sync == "slice" else d["grad_out"] / world
+        out.backward(g)
+        v2, l2, a2 = (t.detach().clone().requires_grad_(True) for t in (d["value"], d["loc"], d["attn"]))
+        ref = multiscale_deformable_attention(v2, d["shapes"], l2, a2, "zeros", False)
+        ref.backward(d["grad_out"])
+        ok = out.shape == ref.shape and torch.allclose(out, ref, atol=1e-12)
+        mine = sorted({b for b, _, _ in row_segments(q_total, r0, r1)})
+        vg = v.grad if v.grad is not None else torch.zeros_like(v)
+        if value_sync == "all_reduce":
+            ok &= torch.allclose(vg, v2.grad, atol=1e-10)
+        elif value_sync == "owners":
+            for b in range(batch):
+                want = v2.grad[b] if b in mine else torch.zeros_like(v2.grad[b])
+                ok &= torch.allclose(vg[b], want, atol=1e-10)
+        else:  # local partial sums: they add up to the full gradient
+            tot = vg.clone()
+            dist.all_reduce(tot)
+            ok &= torch.allclose(tot, v2.grad, atol=1e-10)
+        l2r = l2.grad.reshape(rows, *l2.grad.shape[2:])[r0:r1]
+        a2r = a2.grad.reshape(rows, *a2.grad.shape[2:])[r0:r1]
+        lg = l_in.grad if sharded_inputs else l_in.grad.reshape(rows, *l_in.grad.shape[2:])[r0:r1]
+        ag = a_in.grad if sharded_inputs else a_in.grad.reshape(rows, *a_in.grad.shape[2:])[r0:r1]
+        ok &= torch.allclose(lg, l2r, atol=1e-10) and torch.allclose(ag, a2r, atol=1e-10)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,batch,q_total,sharded_inputs,value_sync,grad_sync", [
+    (2, 2, 7, True, "owners", "slice"),            # ranks divide B: whole batch elements, no grad_value traffic
+    (2, 1, 9, False, "owners", "slice"),           # more ranks than batch elements: both share b = 0
+    (2, 3, 5, True, "all_reduce", "slice"),        # rank boundaries inside a batch element
+    (2, 3, 4, False, "none", "reduce_scatter"),
+    (3, 2, 5, True, "owners", "slice"),            # the middle rank belongs to two owner groups
+])
+def test_row_shard_gloo(world, batch, q_total, sharded_inputs, value_sync, grad_sync):
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_row_worker, args=(world, _free_port(), batch, q_total, sharded_inputs, value_sync, grad_sync, ret),
+             nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_row_segments_partition_the_row_space():
+    from msda_triton_amd.distributed import row_segments, row_shard_bounds
+    for B, Q, world in ((4, 10, 8), (3, 7, 2), (1, 5, 4), (8, 900, 8), (4, 10000, 8)):
+        seen = []
+        for r in range(world):
+            r0, r1 = row_shard_bounds(B * Q, world, r)
+            for b, q0, q1 in row_segments(Q, r0, r1):
+                assert 0 <= b < B and 0 <= q0 < q1 <= Q
+                seen.extend(range(b * Q + q0, b * Q + q1))
+        assert seen == list(range(B * Q))

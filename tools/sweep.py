@@ -9,14 +9,19 @@ from msda_triton_amd import synth, _lib
 from msda_triton_amd.functional import KernelTimer, msda_hip_fwd, msda_hip_bwd
 
 dev = "cuda:0"
-opts = [a for a in sys.argv[1:] if "=" in a]
+opts = [a for a in sys.argv[1:] if "=" in a and ":" not in a]
 for kv in opts:
     k, v = kv.split("=")
     _lib.set_option(k, int(v))
-names = [a for a in sys.argv[1:] if "=" not in a] or list(synth.WORKLOADS)
+names = [a for a in sys.argv[1:] if "=" not in a or ":" in a] or list(synth.WORKLOADS)
 for name in names:
-    wl = synth.WORKLOADS[name]
-    dt = getattr(torch, wl.dtype)
+    if ":" in name:  # e.g. c2_q10k:B=1:Q=40000 — a BASELINE workload with fields overridden
+        import dataclasses
+        base, *over = name.split(":")
+        wl = dataclasses.replace(synth.WORKLOADS[base], **{k: int(v) for k, v in (o.split("=") for o in over)})
+    else:
+        wl = synth.WORKLOADS[name]
+    dt = getattr(torch, os.environ.get("MSDA_SWEEP_DTYPE", wl.dtype))
     torch.manual_seed(0)
     v = torch.randn(wl.B, wl.I, wl.H, wl.D, device=dev, dtype=torch.float32).to(dt)
     s = torch.tensor(wl.levels, device=dev)
