@@ -87,6 +87,36 @@ template <> struct RawLoad<2> {
     static __device__ __forceinline__ type load(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0); }
 };
 
+// Streaming (nontemporal) store of a small POD: for outputs that are written once and not read again by the
+// kernels of this call, so they do not displace the gathered rows in L2.
+template <int BYTES> struct StreamBits {
+    using type = __attribute__((ext_vector_type(BYTES / 4))) uint32_t;
+};
+template <> struct StreamBits<4> {
+    using type = uint32_t;
+};
+template <> struct StreamBits<2> {
+    using type = uint16_t;
+};
+template <typename V> __device__ __forceinline__ void store_stream(void *dst, const V &v)
+{
+    if constexpr (sizeof(V) <= 16) {
+        using B = typename StreamBits<sizeof(V)>::type;
+        __builtin_nontemporal_store(__builtin_bit_cast(B, v), static_cast<B *>(dst));
+    } else {
+        struct Halves {
+            unsigned char a[sizeof(V) / 2], b[sizeof(V) / 2];
+        };
+        using B = typename StreamBits<sizeof(V) / 2>::type;
+        struct Two {
+            B lo, hi;
+        };
+        const Two t = __builtin_bit_cast(Two, v);
+        __builtin_nontemporal_store(t.lo, static_cast<B *>(dst));
+        __builtin_nontemporal_store(t.hi, static_cast<B *>(dst) + 1);
+    }
+}
+
 // Load VEC consecutive elements of T at byte offset `off` and widen them to the accumulate type.
 template <typename T, int VEC>
 __device__ __forceinline__ void load_row(rsrc_t r, uint32_t off, typename Traits<T>::acc (&dst)[VEC])

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) o.v[i] = TR::from_acc(acc[i]);
                 T *dst = static_cast<T *>(p.out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D + c0;
-                *reinterpret_cast<Pack<T, VEC> *>(dst) = o;
+                store_stream(dst, o);
             }
         }
     }
@@ -576,11 +576,13 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                 if (fq < p.Q) {
                     const int sidx = fq * HLP + sl;
                     const Rec4<A> res = w_rec[fu * scp + (sl - s0)];
-                    static_cast<T *>(p.grad_attn)[plane_s0 + sidx] = TR::from_acc(res.v[0]);
+                    Pack<T, 1> ga;
+                    ga.v[0] = TR::from_acc(res.v[0]);
+                    store_stream(static_cast<T *>(p.grad_attn) + plane_s0 + sidx, ga);
                     Pack<T, 2> g;
                     g.v[0] = TR::from_acc(res.v[1]);
                     g.v[1] = TR::from_acc(res.v[2]);
-                    *reinterpret_cast<Pack<T, 2> *>(static_cast<T *>(p.grad_loc) + 2 * (plane_s0 + sidx)) = g;
+                    store_stream(static_cast<T *>(p.grad_loc) + 2 * (plane_s0 + sidx), g);
                 }
             }
         }

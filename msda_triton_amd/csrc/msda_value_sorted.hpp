@@ -422,7 +422,8 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
                 Pack<A, VEC> o;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) o.v[v] = acc[k][v];
-                *reinterpret_cast<Pack<A, VEC> *>(scratch + (size_t)k * p.D + c0) = o;
+                // written once, read once by the finish kernel: keep it from displacing grad_out rows in L2
+                store_stream(scratch + (size_t)k * p.D + c0, o);
             }
         }
     }
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
         T *dst = static_cast<T *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
-        *reinterpret_cast<Pack<T, VEC> *>(dst) = o;
+        store_stream(dst, o);
     }
 }
 
