@@ -34,6 +34,7 @@ namespace msda {
 
 constexpr int kChunk = 64;           // entries per work item
 constexpr int kGatherItemBlock = 256; // threads per workgroup of the gather kernel (no block barriers)
+constexpr int kContFlag = 1 << 30;   // work-item record: this window continues the previous item's cell
 constexpr int kBigChunks = 16;       // cells with more work items than this have their records written by the whole block
 constexpr int kBigCells = 64;        // ... at most this many per plane (the rest falls back to the owning thread)
 constexpr int kCellBlock = 1024;     // threads of K1 / K2b / K3
@@ -277,7 +278,8 @@ __device__ __forceinline__ void cell_scan_body(int *off, const LevelTab &tab, in
         int slot = kBigCells;
         if (chunks > kBigChunks) slot = atomicAdd(&s_big[0], 1);
         if (chunks <= kBigChunks || slot >= kBigCells) {
-            for (int k = 0; k < chunks; ++k) items[run + k] = make_int2(beg + k * kChunk, min(kChunk, n - k * kChunk));
+            for (int k = 0; k < chunks; ++k)
+                items[run + k] = make_int2(beg + k * kChunk, min(kChunk, n - k * kChunk) | (k ? kContFlag : 0));
         } else {
             s_big[1 + slot] = c;
             s_big[1 + kBigCells + slot] = run;
@@ -295,7 +297,7 @@ __device__ __forceinline__ void cell_scan_body(int *off, const LevelTab &tab, in
         const int beg = off[c], n = off[c + 1] - beg;
         const int chunks = (n + kChunk - 1) / kChunk;
         for (int k = t; k < chunks; k += kCellBlock)
-            items[first + k] = make_int2(beg + k * kChunk, min(kChunk, n - k * kChunk));
+            items[first + k] = make_int2(beg + k * kChunk, min(kChunk, n - k * kChunk) | (k ? kContFlag : 0));
     }
 }
 
@@ -339,15 +341,18 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
     int pair, slot;
     if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
     const int nitems = p.ws_itemcnt[pair];
+    if (slot * NU >= nitems) return;  // block-uniform
     const int tid = threadIdx.x;
     const int unit = tid / G, j = tid % G;
     const int item = slot * NU + unit;
-    if (item >= nitems) return;  // (no block barriers below: the record hand-off is wave-local)
+    const bool valid = item < nitems;  // idle groups still take part in the block barriers below
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int gbase = tid - j;
 
     __shared__ CornerW<A> s_w[kGatherItemBlock];
     __shared__ uint32_t s_q[kGatherItemBlock];
+    __shared__ __attribute__((aligned(32))) A s_rows[kGatherItemBlock * 4 * VEC];  // [unit][corner][G * VEC]: partial rows of continuation items
+    __shared__ int s_cont[NU];
 
     const Entry<A> *entries = static_cast<const Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
     const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
@@ -356,8 +361,14 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
     const rsrc_t rs_go = make_rsrc(gout, (uint32_t)(((size_t)p.Q * p.H * p.D - (size_t)h * p.D) * sizeof(T)));
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
 
-    const int2 rec = p.ws_items[(size_t)pair * p.it_cap + item];
-    const int start = rec.x, count = rec.y;  // 1 <= count <= kChunk
+    int start = 0, count = 0;  // valid items: 1 <= count <= kChunk
+    bool follower = false;     // this item continues the cell of the previous item of the same workgroup
+    if (valid) {
+        const int2 rec = p.ws_items[(size_t)pair * p.it_cap + item];
+        start = rec.x;
+        count = rec.y & (kContFlag - 1);
+        follower = (rec.y & kContFlag) != 0 && unit != 0;
+    }
 
     // record v of the window -> (byte offset of the query's grad_out row inside the plane, four corner weights).
     // Positions past the end get weight 0 and an out-of-range offset (the buffer load then returns 0 without
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[k][i] = (A)0;
 
-        Entry<A> e_cur = entries[start + min(j, count - 1)];
+        Entry<A> e_cur = entries[start + max(min(j, count - 1), 0)];  // (idle groups: count == 0, record 0 of the plane, unused)
         for (int v0 = 0; v0 < count; v0 += G) {
             uint32_t cur_q;
             CornerW<A> cur_w;
@@ -416,14 +427,39 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
                 }
             }
         }
-        if (lane_ok) {
+        // Items of one cell that sit in the same workgroup are summed here (in item order) and leave as ONE set of
+        // four rows, stored at the first of them: hot cells (coarse levels, clustered samples) then cost the finish
+        // kernel one row per NU items, not one per item.
+        if (cc > 0) __syncthreads();  // the previous channel chunk's rows have been consumed
+        if (j == 0) s_cont[unit] = follower ? 1 : 0;
+        if (follower) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 Pack<A, VEC> o;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) o.v[v] = acc[k][v];
-                // written once, read once by the finish kernel: keep it from displacing grad_out rows in L2
-                store_stream(scratch + (size_t)k * p.D + c0, o);
+                *reinterpret_cast<Pack<A, VEC> *>(&s_rows[((unit * 4 + k) * G + j) * VEC]) = o;
+            }
+        }
+        __syncthreads();
+        if (valid && !follower) {
+            for (int u = unit + 1; u < NU && s_cont[u]; ++u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const Pack<A, VEC> r = *reinterpret_cast<const Pack<A, VEC> *>(&s_rows[((u * 4 + k) * G + j) * VEC]);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[k][v] += r.v[v];
+                }
+            }
+            if (lane_ok) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    Pack<A, VEC> o;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o.v[v] = acc[k][v];
+                    // written once, read once by the finish kernel: keep it from displacing grad_out rows in L2
+                    store_stream(scratch + (size_t)k * p.D + c0, o);
+                }
             }
         }
     }
@@ -504,9 +540,10 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
         } else {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = (A)0;
+            // rows of a cell: its first item, then the first item of every further gather workgroup it extends into
+            constexpr int NUG = kGatherItemBlock / G;
             auto add = [&](int first, int last, int corner) {
-#pragma unroll 4
-                for (int it = first; it < last; ++it) {
+                for (int it = first; it < last; it = (it / NUG + 1) * NUG) {
                     const Pack<A, VEC> r =
                         *reinterpret_cast<const Pack<A, VEC> *>(src + ((size_t)it * 4 + corner) * p.D + c0);
 #pragma unroll

@@ -25,7 +25,8 @@ for name in names:
     torch.manual_seed(0)
     v = torch.randn(wl.B, wl.I, wl.H, wl.D, device=dev, dtype=torch.float32).to(dt)
     s = torch.tensor(wl.levels, device=dev)
-    l = torch.rand(wl.B, wl.Q, wl.H, wl.L, wl.P, 2, device=dev, dtype=torch.float32).to(dt)
+    lo, hi = (float(x) for x in os.environ.get("MSDA_SWEEP_LOC", "0,1").split(","))  # clustered sampling: e.g. 0.45,0.55
+    l = (lo + (hi - lo) * torch.rand(wl.B, wl.Q, wl.H, wl.L, wl.P, 2, device=dev, dtype=torch.float32)).to(dt)
     a = torch.softmax(torch.randn(wl.B, wl.Q, wl.H, wl.L, wl.P, device=dev), -1).to(dt)
     g = torch.rand(wl.B, wl.Q, wl.H, wl.D, device=dev, dtype=torch.float32).to(dt)
     pm, ac = wl.padding_mode, wl.align_corners
