@@ -490,6 +490,32 @@ def test_grad_value_both_paths_and_hot_pixels(oracle, value_path, pm, ac):
         _lib.set_option("value_path", 0)
 
 
+@pytest.mark.parametrize("D,Q,td", [(32, 3000, torch.float32), (512, 700, torch.float32), (32, 3000, torch.float64),
+                                    (32, 3000, torch.bfloat16)],
+                         ids=["f32_d32", "f32_d512_two_channel_chunks", "f64_d32", "bf16_d32"])
+def test_grad_value_cell_flood_spans_gather_workgroups(oracle, D, Q, td):
+    """A 1x1 level: every sample falls into one of four cells, so a cell's list is cut into far more work items
+    than one gather workgroup holds — items are merged inside workgroups, the finish kernel adds one row per
+    workgroup, and the cell-scan kernel writes these records with the whole block."""
+    from msda_triton_amd import _lib
+    rng = np.random.default_rng(77)
+    npdt = np.float64 if td == torch.float64 else np.float32
+    c = rand_case(rng, 1, Q, 2, D, [(1, 1), (3, 2)], 4, lo=0.0, hi=1.0, dtype=npdt)
+    c["grad_out"] = (c["grad_out"] / Q).astype(npdt)   # keep the sums O(1)
+    if td == torch.bfloat16:
+        for k in ("value", "loc", "attn", "grad_out"):
+            c[k] = torch.from_numpy(c[k]).to(td).float().numpy()
+    try:
+        _lib.set_option("value_path", 2)
+        for pm, ac in (("zeros", False), ("border", True)):
+            _, gv, _, _ = run_hip(c["value"], c["shapes"], c["loc"], c["attn"], c["grad_out"], pm, ac, dtype=td)
+            r_gv, _, _ = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], pm, ac)
+            tol = dict(atol=2e-2, rtol=2e-2) if td == torch.bfloat16 else BWD_TOL[td]
+            np.testing.assert_allclose(gv, r_gv, err_msg=f"{pm} {ac}", **tol)
+    finally:
+        _lib.set_option("value_path", 0)
+
+
 def test_grad_value_without_workspace_uses_tile_kernel(oracle):
     """The C ABI accepts workspace == NULL and then runs the LDS-tile kernel."""
     from msda_triton_amd import _lib
