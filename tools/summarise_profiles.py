@@ -28,7 +28,11 @@ GROUPS = {  # launcher-level groups timed by bench.py's KernelTimer
                        "msda_value_gather_kernel", "msda_value_finish_kernel", "msda_bwd_value_kernel"],
 }
 
-stats = glob.glob(os.path.join(root, "gpurun_out", f"{tag}_stats", "*", "*kernel_stats.csv"))[0]
+def newest(pattern):  # gpurun merges new outputs next to older ones: take the most recent
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats = newest(os.path.join(root, "gpurun_out", f"{tag}_stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(out_dir, f"{tag}_{workload}_kernel_stats.csv"))
 per_kernel = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(stats)):
@@ -40,7 +44,7 @@ for r in csv.DictReader(open(stats)):
 pmc = {}
 rows = []
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(os.path.join(root, "gpurun_out", f"{tag}_{counter.split('_')[0].lower()}", "*", "*counter_collection.csv"))[0]
+    f = newest(os.path.join(root, "gpurun_out", f"{tag}_{counter.split('_')[0].lower()}", "*", "*counter_collection.csv"))
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter and "msda::" in r["Kernel_Name"]:
