@@ -43,6 +43,14 @@
  * ref_xy + offset * ref_wh / (2 P)) in its prologue, so neither tensor is ever materialised.
  * Returns MSDA_ERR_UNSUPPORTED when L*P is too large for one pass (callers then use msda_fwd_<dtype>).
  *
+ * msda_bwd_fused_<dtype> is its backward with the prologue's chain rule fused in (what autograd does for
+ * frontend.py:253-282): from grad_out to grad_value [B, I, H, D] (may be NULL), grad_proj [B, Q, H, L, P, 3]
+ * (offset gradients scaled back, softmax backward applied to the logits) and grad_ref_partial
+ * [B, Q, H, ref_dim] — the per-head partial sums of the reference points' gradient, which the caller adds up
+ * over H.  It needs msda_bwd_fused_workspace_bytes(...) of workspace when grad_value is wanted (the derived
+ * sampling points / attention weights are parked there for the grad_value passes).  Same
+ * MSDA_ERR_UNSUPPORTED rule as the fused forward (nothing is launched then).
+ *
  * Backward workspace: grad_value is computed as a gather over a per-call inverted index (sample
  * records sorted by bilinear cell), which lives in caller-provided device memory so that the
  * library never allocates: pass `workspace` (256-byte aligned) of at least
@@ -65,7 +73,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 3
+#define MSDA_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define MSDA_API __attribute__((visibility("default")))
@@ -97,7 +105,12 @@ extern "C" {
                        const void *loc, const void *attn, void *grad_value, void *grad_loc,        \
                        void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,     \
                        int64_t L, int64_t P, int padding_mode, int align_corners, void *workspace, \
-                       int64_t workspace_bytes, void *stream);
+                       int64_t workspace_bytes, void *stream);                                     \
+    MSDA_API int msda_bwd_fused_##SUF(const void *grad_out, const void *value, const int64_t *shapes, \
+                       const void *proj, const void *ref, void *grad_value, void *grad_proj,       \
+                       void *grad_ref_partial, int64_t B, int64_t I, int64_t H, int64_t D,          \
+                       int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,              \
+                       int align_corners, void *workspace, int64_t workspace_bytes, void *stream);
 
 MSDA_DECLARE(f32)
 MSDA_DECLARE(f16)
@@ -108,6 +121,10 @@ MSDA_DECLARE(f64)
 /* Bytes of device workspace msda_bwd_<dtype> wants for these sizes; elem_size = sizeof(dtype). */
 MSDA_API int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
                                           int64_t P, int elem_size);
+
+/* Bytes of device workspace msda_bwd_fused_<dtype> wants (grad_value != NULL) for these sizes. */
+MSDA_API int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
+                                                int64_t P, int elem_size);
 
 /* ABI version of the loaded library (== MSDA_ABI_VERSION it was built with). */
 MSDA_API int msda_abi_version(void);

@@ -15,14 +15,15 @@ LIB_NAME = "libmsda_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PADDING_MODES = {"border": 0, "zeros": 1}
 DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64")
 
 # every symbol include/msda_hip.h declares
 EXPORTED_SYMBOLS = tuple(
-    [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused") for s in DTYPE_SUFFIXES]
-    + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option", "msda_bwd_workspace_bytes"]
+    [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused", "bwd_fused") for s in DTYPE_SUFFIXES]
+    + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option", "msda_bwd_workspace_bytes",
+       "msda_bwd_fused_workspace_bytes"]
 )
 
 _lib = None
@@ -73,8 +74,13 @@ def load():
             g = getattr(lib, f"msda_bwd_{suf}")
             g.restype = ci
             g.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, vp, i64, vp]
+            gf = getattr(lib, f"msda_bwd_fused_{suf}")
+            gf.restype = ci
+            gf.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, vp, i64, vp]
         lib.msda_bwd_workspace_bytes.restype = i64
         lib.msda_bwd_workspace_bytes.argtypes = [i64] * 7 + [ci]
+        lib.msda_bwd_fused_workspace_bytes.restype = i64
+        lib.msda_bwd_fused_workspace_bytes.argtypes = [i64] * 7 + [ci]
         lib.msda_abi_version.restype = ci
         lib.msda_last_error.restype = ctypes.c_char_p
         lib.msda_set_option.restype = ci

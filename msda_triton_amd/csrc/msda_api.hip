@@ -100,6 +100,16 @@ extern "C" int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int
     return msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
 }
 
+extern "C" int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
+                                                  int64_t P, int elem_size)
+{
+    if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0 || elem_size <= 0) return 0;
+    // the derived sampling points + attention weights (3 elements per sample, rounded up to 256 bytes), then
+    // the sorted pipeline's own workspace (msda_launch.hpp: fused_mat_bytes)
+    const int64_t mat = (B * Q * H * L * P * 3 * (int64_t)elem_size + 255) / 256 * 256;
+    return mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
+}
+
 extern "C" const char *msda_last_error(void) { return msda::g_err; }
 
 extern "C" int msda_set_option(const char *key, int value)

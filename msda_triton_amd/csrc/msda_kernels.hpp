@@ -43,6 +43,10 @@ struct Params {
     int zeros, align, xcd_map;
     const void *ref;  // fused module prologue: reference points [B, Q, ref_dim]; then `loc` holds the raw projection [B,Q,H,L,P,3]
     int ref_dim;      // 2: (x, y)   4: (cx, cy, w, h)
+    // fused backward prologue: grad_loc holds grad_proj [B,Q,H,L,P,3], grad_attn the per-head partial sums of
+    // grad_reference_points [B,Q,H,ref_dim]; the sampling points / attention weights the kernel derives are also
+    // written out (workspace) for the grad_value passes that follow
+    void *mat_loc, *mat_attn;
     int grid3d;       // this launch uses the division-free 3-D grid (see decode_block)
     int debug;        // dev-only ablation mask (msda_set_option("debug", m)); 0 in normal use
     FastDiv div_h;    // pair -> (b, h)
@@ -155,8 +159,9 @@ template <typename A> struct GatherLds {
     StagePlan *plan;
     uint4 *s_off;
     Rec4<A> *s_rec;
+    A *s_aux;  // fused backward only: per record slot (attention weight, x offset, y offset)
     unsigned char *stage;
-    __device__ __forceinline__ GatherLds(int units, int scp)
+    __device__ __forceinline__ GatherLds(int units, int scp, bool aux = false)
     {
         unsigned char *p = msda_smem;
         tab = reinterpret_cast<LevelTab *>(p);
@@ -167,6 +172,8 @@ template <typename A> struct GatherLds {
         p += (size_t)units * scp * sizeof(uint4);
         s_rec = reinterpret_cast<Rec4<A> *>(p);
         p += (size_t)units * scp * sizeof(Rec4<A>);
+        s_aux = reinterpret_cast<A *>(p);
+        if (aux) p += (size_t)units * scp * 3 * sizeof(A);
         stage = p;
     }
 };
@@ -239,21 +246,46 @@ __global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
                 const float inv_sc = 1.0f / (float)sc;
                 wave_lds_sync();  // previous records consumed
                 if constexpr (FUSED) {
-                    // ---- phase 0 (module prologue, frontend.py:253-261): softmax over the unit's L*P logits ----
-                    // (sc == LP here.)  The unit's G lanes stride over its logits: max, then exp and sum, DPP-reduced;
-                    // exp(logit - max) is parked in the record slot, (1 / sum) in the unit's padding slot.
+                    // ---- phase 0 (module prologue, frontend.py:253-282; sc == LP): ONE round of global loads — every
+                    // lane fetches its samples' (x offset, y offset, logit) and reference point, forms the sampling
+                    // point and parks {logit, px, py}; then the unit's lanes take max and sum(exp) over the parked
+                    // logits (DPP-reduced) and leave them in the unit's padding slot ----
+                    for (int f = lane; f < UPW * sc; f += kWave) {
+                        const int fu = div_small(f, sc, inv_sc);
+                        const int sl = f - fu * sc;
+                        const int fq = wq0 + fu;
+                        if (fq < p.Q) {
+                            const int l = div_small(sl, p.P, inv_P);
+                            const int sidx = fq * HLP + sl;
+                            const A ox = TR::to_acc(loc[3 * sidx]), oy = TR::to_acc(loc[3 * sidx + 1]);
+                            const A lg = TR::to_acc(loc[3 * sidx + 2]);
+                            const T *r = refp + (size_t)fq * p.ref_dim;
+                            Rec4<A> w;
+                            w.v[0] = lg;
+                            if (p.ref_dim == 2) {
+                                // NB: (x, y) offsets are divided by img_shapes in its stored (h, w) order (frontend.py:275)
+                                w.v[1] = TR::to_acc(r[0]) + ox / (A)tab->h[l];
+                                w.v[2] = TR::to_acc(r[1]) + oy / (A)tab->w[l];
+                            } else {
+                                w.v[1] = TR::to_acc(r[0]) + ox * TR::to_acc(r[2]) / (A)(2 * p.P);
+                                w.v[2] = TR::to_acc(r[1]) + oy * TR::to_acc(r[3]) / (A)(2 * p.P);
+                            }
+                            w.v[3] = (A)0;
+                            w_rec[fu * scp + sl] = w;
+                        }
+                    }
+                    wave_lds_sync();
                     if (unit_ok) {
                         A mx = -__builtin_huge_val();
-                        for (int sl = j; sl < sc; sl += G) mx = fmax_t(mx, TR::to_acc(loc[3 * (q * HLP + sl) + 2]));
+                        for (int sl = j; sl < sc; sl += G) mx = fmax_t(mx, w_rec[wunit * scp + sl].v[0]);
                         mx = group_max<G>(mx);
                         A sum = (A)0;
-                        for (int sl = j; sl < sc; sl += G) {
-                            const A e = exp_t(TR::to_acc(loc[3 * (q * HLP + sl) + 2]) - mx);
-                            w_rec[wunit * scp + sl].v[0] = e;
-                            sum += e;
-                        }
+                        for (int sl = j; sl < sc; sl += G) sum += exp_t(w_rec[wunit * scp + sl].v[0] - mx);
                         sum = group_sum<G>(sum);
-                        if (j == 0) w_rec[wunit * scp + sc].v[0] = (A)1 / sum;
+                        if (j == 0) {
+                            w_rec[wunit * scp + sc].v[0] = mx;
+                            w_rec[wunit * scp + sc].v[1] = (A)1 / sum;
+                        }
                     }
                     wave_lds_sync();
                 }
@@ -266,20 +298,11 @@ __global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
                         const int l = div_small(sl, p.P, inv_P);
                         const int sidx = fq * HLP + sl;
                         A sx, sy, a;
-                        if constexpr (FUSED) {
-                            // sampling point from reference point + projected offset (frontend.py:270-282), attention
-                            // weight from the parked softmax pieces
-                            const A ox = TR::to_acc(loc[3 * sidx]), oy = TR::to_acc(loc[3 * sidx + 1]);
-                            const T *r = refp + (size_t)fq * p.ref_dim;
-                            if (p.ref_dim == 2) {
-                                // NB: (x, y) offsets are divided by img_shapes in its stored (h, w) order (frontend.py:275)
-                                sx = TR::to_acc(r[0]) + ox / (A)tab->h[l];
-                                sy = TR::to_acc(r[1]) + oy / (A)tab->w[l];
-                            } else {
-                                sx = TR::to_acc(r[0]) + ox * TR::to_acc(r[2]) / (A)(2 * p.P);
-                                sy = TR::to_acc(r[1]) + oy * TR::to_acc(r[3]) / (A)(2 * p.P);
-                            }
-                            a = w_rec[fu * scp + (sl - s0)].v[0] * w_rec[fu * scp + sc].v[0];
+                        if constexpr (FUSED) {  // everything was parked by phase 0
+                            const Rec4<A> pk = w_rec[fu * scp + (sl - s0)], un = w_rec[fu * scp + sc];
+                            sx = pk.v[1];
+                            sy = pk.v[2];
+                            a = exp_t(pk.v[0] - un.v[0]) * un.v[1];
                         } else {
                             const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
                             sx = TR::to_acc(xy.v[0]);
@@ -367,7 +390,7 @@ __global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
 // backward, part 1: grad_loc and grad_attn.  Same decomposition as the forward; every sample's
 // three results are reduced over the unit's G lanes with DPP moves and written exactly once.
 // ==========================================================================================
-template <typename T, int VEC, int G, int BLOCK, bool STAGE>
+template <typename T, int VEC, int G, int BLOCK, bool STAGE, bool FUSED>
 __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
@@ -382,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
 
     const int scp = p.sc + 1;
     // record in : {dx, dy, a*sx*gx_on, a*sy*gy_on};  record out (same slot): {gA, gX, gY, -}
-    const GatherLds<A> lds(NU, scp);
+    const GatherLds<A> lds(NU, scp, FUSED);
     LevelTab *tab = lds.tab;
 
     const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);
@@ -405,8 +428,12 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
     Rec4<A> *w_rec = lds.s_rec + wave * UPW * scp;
     // per-plane bases (64-bit, uniform) + 32-bit per-sample indices (the host checks Q*H*L*P*2 < 2^31)
     const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
-    const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
-    const T *attn = static_cast<const T *>(p.attn) + plane_s0;
+    const T *loc = static_cast<const T *>(p.loc) + (FUSED ? 3 : 2) * plane_s0;  // FUSED: raw projection (dx, dy, logit)
+    const T *attn = FUSED ? nullptr : static_cast<const T *>(p.attn) + plane_s0;
+    const T *refp = FUSED ? static_cast<const T *>(p.ref) + (size_t)b * p.Q * p.ref_dim : nullptr;
+    A *w_aux = lds.s_aux + wave * UPW * scp * 3;  // FUSED: [slot] = a, [UPW*scp + slot] = ox, [2*UPW*scp + slot] = oy
+    A *w_a = w_aux, *w_ox = w_aux + UPW * scp, *w_oy = w_aux + 2 * UPW * scp;
+    const A half_inv_P = (A)1 / (A)(2 * p.P);
     const int HLP = p.H * p.LP;
     const float inv_P = 1.0f / (float)p.P;
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
@@ -421,6 +448,50 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
             const int sc = min(p.sc, p.LP - s0);
             const float inv_sc = 1.0f / (float)sc;
             wave_lds_sync();
+            if constexpr (FUSED) {
+                // ---- phase 0 (module prologue, frontend.py:253-282; sc == LP), as in the fused forward: one round of
+                // global loads parks {logit, px, py} (and the raw offsets for the box-size gradient), then the unit's
+                // lanes leave max and 1 / sum(exp) of its logits in the padding slot ----
+                for (int f = lane; f < UPW * sc; f += kWave) {
+                    const int fu = div_small(f, sc, inv_sc);
+                    const int sl = f - fu * sc;
+                    const int fq = wq0 + fu;
+                    if (fq < p.Q) {
+                        const int l = div_small(sl, p.P, inv_P);
+                        const int sidx = fq * HLP + sl;
+                        const A ox = TR::to_acc(loc[3 * sidx]), oy = TR::to_acc(loc[3 * sidx + 1]);
+                        const A lg = TR::to_acc(loc[3 * sidx + 2]);
+                        const T *r = refp + (size_t)fq * p.ref_dim;
+                        Rec4<A> w;
+                        w.v[0] = lg;
+                        if (p.ref_dim == 2) {
+                            w.v[1] = TR::to_acc(r[0]) + ox / (A)tab->h[l];  // NB: (x, y) / img_shapes in its stored (h, w) order
+                            w.v[2] = TR::to_acc(r[1]) + oy / (A)tab->w[l];
+                        } else {
+                            w.v[1] = TR::to_acc(r[0]) + ox * TR::to_acc(r[2]) * half_inv_P;
+                            w.v[2] = TR::to_acc(r[1]) + oy * TR::to_acc(r[3]) * half_inv_P;
+                        }
+                        w.v[3] = (A)0;
+                        w_rec[fu * scp + sl] = w;
+                        w_ox[fu * scp + sl] = ox;
+                        w_oy[fu * scp + sl] = oy;
+                    }
+                }
+                wave_lds_sync();
+                if (unit_ok) {
+                    A mx = -__builtin_huge_val();
+                    for (int sl = j; sl < sc; sl += G) mx = fmax_t(mx, w_rec[wunit * scp + sl].v[0]);
+                    mx = group_max<G>(mx);
+                    A sum = (A)0;
+                    for (int sl = j; sl < sc; sl += G) sum += exp_t(w_rec[wunit * scp + sl].v[0] - mx);
+                    sum = group_sum<G>(sum);
+                    if (j == 0) {
+                        w_rec[wunit * scp + sc].v[0] = mx;
+                        w_rec[wunit * scp + sc].v[1] = (A)1 / sum;
+                    }
+                }
+                wave_lds_sync();
+            }
             // ---- phase 1 ----
             for (int f = lane; f < UPW * sc; f += kWave) {
                 const int fu = div_small(f, sc, inv_sc);
@@ -429,12 +500,24 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                 if (fq < p.Q) {
                     const int l = div_small(sl, p.P, inv_P);
                     const int sidx = fq * HLP + sl;
-                    const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
-                    const A a = TR::to_acc(attn[sidx]);
                     const int lh = tab->h[l], lw = tab->w[l];
+                    A px, py, a;
+                    if constexpr (FUSED) {
+                        // everything was parked by phase 0
+                        const int rs_ = fu * scp + (sl - s0);
+                        const Rec4<A> pk = w_rec[rs_], un = w_rec[fu * scp + sc];
+                        px = pk.v[1];
+                        py = pk.v[2];
+                        a = exp_t(pk.v[0] - un.v[0]) * un.v[1];
+                        w_a[rs_] = a;
+                    } else {
+                        const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                        px = TR::to_acc(xy.v[0]);
+                        py = TR::to_acc(xy.v[1]);
+                        a = TR::to_acc(attn[sidx]);
+                    }
                     Taps<A> t;
-                    make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), lh, lw, STAGE ? 0 : tab->start[l], p.zeros, p.align,
-                                 STAGE ? 1u : row_bytes, t);
+                    make_taps<A>(px, py, lh, lw, STAGE ? 0 : tab->start[l], p.zeros, p.align, STAGE ? 1u : row_bytes, t);
                     const A sx = p.align ? (A)(lw - 1) : (A)lw;
                     const A sy = p.align ? (A)(lh - 1) : (A)lh;
                     Rec4<A> r;
@@ -451,6 +534,9 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                 }
             }
             wave_lds_sync();
+            // FUSED: softmax backward needs dot = sum_s a_s * gA_s over the unit; the reference point's gradient is
+            // the sum of the sampling points' (times the offsets, for the box size)
+            A f_dot = (A)0, f_gx = (A)0, f_gy = (A)0, f_gw = (A)0, f_gh = (A)0;
             // ---- phase 2: four dot products with grad_out per sample, reduced over the unit ----
             if (unit_ok) {  // idle lanes of a live unit still join the DPP sums
                 const uint4 *uo = w_off + wunit * scp;
@@ -567,6 +653,40 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                     }
                 }
             }
+            if constexpr (FUSED) {
+                // ---- phase 2b: per-unit sums for the prologue's chain rule, off the gather's critical path: the
+                // unit's lanes stride over its parked results, DPP-reduce ----
+                wave_lds_sync();
+                if (unit_ok) {
+                    for (int sl = j; sl < sc; sl += G) {
+                        const int rs_ = wunit * scp + sl;
+                        const Rec4<A> res = w_rec[rs_];
+                        f_dot = fma_t(w_a[rs_], res.v[0], f_dot);
+                        f_gx += res.v[1];
+                        f_gy += res.v[2];
+                        f_gw = fma_t(res.v[1], w_ox[rs_], f_gw);
+                        f_gh = fma_t(res.v[2], w_oy[rs_], f_gh);
+                    }
+                    f_dot = group_sum<G>(f_dot);
+                    f_gx = group_sum<G>(f_gx);
+                    f_gy = group_sum<G>(f_gy);
+                    if (p.ref_dim == 4) {
+                        f_gw = group_sum<G>(f_gw);
+                        f_gh = group_sum<G>(f_gh);
+                    }
+                }
+                if (unit_ok && j == 0) {
+                    w_a[wunit * scp + sc] = f_dot;  // the unit's padding slot
+                    // per-head partial of grad_reference_points; the caller sums over the heads
+                    T *gr = static_cast<T *>(p.grad_attn) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.ref_dim;
+                    gr[0] = TR::from_acc(f_gx);
+                    gr[1] = TR::from_acc(f_gy);
+                    if (p.ref_dim == 4) {
+                        gr[2] = TR::from_acc(f_gw * half_inv_P);
+                        gr[3] = TR::from_acc(f_gh * half_inv_P);
+                    }
+                }
+            }
             wave_lds_sync();
             // ---- phase 3: coalesced write-out, one sample per lane and trip ----
             for (int f = lane; f < UPW * sc; f += kWave) {
@@ -576,13 +696,52 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                 if (fq < p.Q) {
                     const int sidx = fq * HLP + sl;
                     const Rec4<A> res = w_rec[fu * scp + (sl - s0)];
-                    Pack<T, 1> ga;
-                    ga.v[0] = TR::from_acc(res.v[0]);
-                    store_stream(static_cast<T *>(p.grad_attn) + plane_s0 + sidx, ga);
-                    Pack<T, 2> g;
-                    g.v[0] = TR::from_acc(res.v[1]);
-                    g.v[1] = TR::from_acc(res.v[2]);
-                    store_stream(static_cast<T *>(p.grad_loc) + 2 * (plane_s0 + sidx), g);
+                    if constexpr (FUSED) {
+                        // chain rule through the prologue: softmax (logit), offset scaling (dx, dy)
+                        const int l = div_small(sl, p.P, inv_P);
+                        const int rs_ = fu * scp + (sl - s0);
+                        const A a = w_a[rs_], dot = w_a[fu * scp + sc];
+                        const T *r = refp + (size_t)fq * p.ref_dim;
+                        A kx, ky;
+                        if (p.ref_dim == 2) {
+                            kx = (A)1 / (A)tab->h[l];
+                            ky = (A)1 / (A)tab->w[l];
+                        } else {
+                            kx = TR::to_acc(r[2]) * half_inv_P;
+                            ky = TR::to_acc(r[3]) * half_inv_P;
+                        }
+                        if (p.mat_loc != nullptr) {
+                            // the sampling point and attention weight this kernel derived, for the grad_value passes
+                            // (stored here, at the end of the wave's life, where nothing waits behind the stores)
+                            const A ox = w_ox[rs_], oy = w_oy[rs_];
+                            Pack<T, 2> m;
+                            if (p.ref_dim == 2) {
+                                m.v[0] = TR::from_acc(TR::to_acc(r[0]) + ox / (A)tab->h[l]);
+                                m.v[1] = TR::from_acc(TR::to_acc(r[1]) + oy / (A)tab->w[l]);
+                            } else {
+                                m.v[0] = TR::from_acc(TR::to_acc(r[0]) + ox * TR::to_acc(r[2]) * half_inv_P);
+                                m.v[1] = TR::from_acc(TR::to_acc(r[1]) + oy * TR::to_acc(r[3]) * half_inv_P);
+                            }
+                            *reinterpret_cast<Pack<T, 2> *>(static_cast<T *>(p.mat_loc) + 2 * (plane_s0 + sidx)) = m;
+                            static_cast<T *>(p.mat_attn)[plane_s0 + sidx] = TR::from_acc(a);
+                        }
+                        Pack<T, 1> g0, g1, g2;
+                        g0.v[0] = TR::from_acc(res.v[1] * kx);
+                        g1.v[0] = TR::from_acc(res.v[2] * ky);
+                        g2.v[0] = TR::from_acc(a * (res.v[0] - dot));
+                        T *gp = static_cast<T *>(p.grad_loc) + 3 * (plane_s0 + sidx);
+                        store_stream(gp, g0);
+                        store_stream(gp + 1, g1);
+                        store_stream(gp + 2, g2);
+                    } else {
+                        Pack<T, 1> ga;
+                        ga.v[0] = TR::from_acc(res.v[0]);
+                        store_stream(static_cast<T *>(p.grad_attn) + plane_s0 + sidx, ga);
+                        Pack<T, 2> g;
+                        g.v[0] = TR::from_acc(res.v[1]);
+                        g.v[1] = TR::from_acc(res.v[2]);
+                        store_stream(static_cast<T *>(p.grad_loc) + 2 * (plane_s0 + sidx), g);
+                    }
                 }
             }
         }

@@ -119,9 +119,9 @@ inline int pick_group(int lanes_needed)
 
 // samples of a unit parked in LDS at a time (records), staged-level bytes, total dynamic LDS
 inline void plan_gather(int NU, int LP, size_t acc_bytes, int stage_want, int row_b, int &sc, int &stage_bytes,
-                        size_t &lds)
+                        size_t &lds, bool aux = false)
 {
-    const size_t rec = 16 + 4 * acc_bytes;
+    const size_t rec = 16 + (aux ? 7 : 4) * acc_bytes;  // aux: the fused backward's (a, ox, oy) per slot
     const size_t rec_budget = NU > 64 ? (size_t)96 * 1024 : (size_t)kRecordLdsBudget;
     int cap = (int)(rec_budget / (NU * rec)) - 1;
     if (cap < 1) cap = 1;
@@ -139,8 +139,8 @@ template <typename T, int VEC, int G, int MODE, int BLOCK> inline int launch_gat
     using A = typename Traits<T>::acc;
     constexpr int NU = BLOCK / G;
     size_t lds;
-    const int stage_want = VEC > 1 ? option_stage_kb() * 1024 : 0;
-    plan_gather(NU, p.LP, sizeof(A), stage_want, p.D * (int)sizeof(T), p.sc, p.stage_bytes, lds);
+    const int stage_want = (VEC > 1 && MODE != 3) ? option_stage_kb() * 1024 : 0;
+    plan_gather(NU, p.LP, sizeof(A), stage_want, p.D * (int)sizeof(T), p.sc, p.stage_bytes, lds, MODE == 3);
     p.nqc = (p.Q + NU - 1) / NU;
     const int npairs = p.B * p.H;
     // query chunks per workgroup: amortise the level staging, but keep the chip full
@@ -152,12 +152,20 @@ template <typename T, int VEC, int G, int MODE, int BLOCK> inline int launch_gat
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    if (MODE == 2 && p.sc != p.LP) {
+    if ((MODE == 2 || MODE == 3) && p.sc != p.LP) {
         set_error("fused prologue needs all L*P=%d samples of a unit in LDS at once (limit %d)", p.LP, p.sc);
         return MSDA_ERR_UNSUPPORTED;
     }
-    if (p.stage_bytes > 0) {
-        auto kernel = MODE == 1   ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, true>
+    if constexpr (MODE == 3) {
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, BLOCK, false, true>;
+        static bool big_lds_ok = false;
+        if (!big_lds_ok) {
+            allow_big_lds(kernel);
+            big_lds_ok = true;
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(BLOCK), lds, stream, p);
+    } else if (p.stage_bytes > 0) {
+        auto kernel = MODE == 1   ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, true, false>
                       : MODE == 2 ? msda_fwd_kernel<T, VEC, G, BLOCK, true, true>
                                   : msda_fwd_kernel<T, VEC, G, BLOCK, true, false>;
         static bool big_lds_ok = false;
@@ -167,7 +175,7 @@ template <typename T, int VEC, int G, int MODE, int BLOCK> inline int launch_gat
         }
         hipLaunchKernelGGL(kernel, grid, dim3(BLOCK), lds, stream, p);
     } else {
-        auto kernel = MODE == 1   ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, false>
+        auto kernel = MODE == 1   ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, false, false>
                       : MODE == 2 ? msda_fwd_kernel<T, VEC, G, BLOCK, false, true>
                                   : msda_fwd_kernel<T, VEC, G, BLOCK, false, false>;
         static bool big_lds_ok = false;
@@ -183,7 +191,7 @@ template <typename T, int VEC, int G, int MODE, int BLOCK> inline int launch_gat
 template <typename T, int VEC, int G, int MODE> inline int launch_gather(Params &p, hipStream_t stream)
 {
     // staged levels are shared by a whole workgroup: use the biggest one (16 waves) when staging is on
-    if (VEC > 1 && option_stage_kb() > 0) {
+    if (VEC > 1 && option_stage_kb() > 0 && MODE != 3) {
         const int blk = option_gather_block();
         if (blk == 1024) return launch_gather_block<T, VEC, G, MODE, 1024>(p, stream);
         if (blk == 512) return launch_gather_block<T, VEC, G, MODE, 512>(p, stream);
@@ -433,6 +441,35 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
     return rc;
 }
 
+// grad_value: the sorted-gather pipeline when the caller's workspace allows it, else (or for small problems) the
+// LDS-tile kernel.
+template <typename T>
+inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspace_bytes, hipStream_t stream)
+{
+    using A = typename Traits<T>::acc;
+    const int64_t B = d.B, I = d.I, H = d.H, D = d.D, Q = d.Q, L = d.L, P = d.P;
+    bool sorted = option_value_path() != 1 && workspace != nullptr && aligned_to(workspace, 256) &&
+                  (uint64_t)workspace_bytes >= sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A)).total;
+    if (sorted && option_value_path() == 0) {
+        // Small problems: the sorted pipeline's six launches cost ~50 us before any work is done, while the
+        // LDS-tile kernel is one launch whose time grows with (workgroup rounds) x (samples per plane).
+        // Measured on MI355X (c1/c2/c4 sweeps): tiles ~2.2 ns per plane-sample and round, sorted ~35 ps per sample.
+        const size_t room = kValueLdsBudget - sizeof(LevelTab);
+        int ch = 0;
+        for (int c : {4, 2, 1})
+            if (!ch && (D % c) == 0 && (size_t)I * c * sizeof(TileAcc) <= room) ch = c;
+        if (ch) {
+            const double s_plane = (double)Q * (double)(L * P), planes = (double)(B * H);
+            const double rounds = (double)((int64_t)(planes * (double)(D / ch) + 255) / 256);
+            const double t_tile = rounds * s_plane * 2.2e-3, t_sorted = 50.0 + planes * s_plane * 3.5e-5;
+            if (t_tile < t_sorted) sorted = false;
+        }
+    }
+    const int rc = sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
+    if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
 template <typename T>
 int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, const void *loc, const void *attn,
             void *grad_value, void *grad_loc, void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,
@@ -497,34 +534,101 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
             return rc;
         }
     }
-    if (want_value) {
-        using A = typename Traits<T>::acc;
-        bool sorted = option_value_path() != 1 && workspace != nullptr && aligned_to(workspace, 256) &&
-                      (uint64_t)workspace_bytes >= sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A)).total;
-        if (sorted && option_value_path() == 0) {
-            // Small problems: the sorted pipeline's six launches cost ~50 us before any work is done, while the
-            // LDS-tile kernel is one launch whose time grows with (workgroup rounds) x (samples per plane).
-            // Measured on MI355X (c1/c2/c4 sweeps): tiles ~2.2 ns per plane-sample and round, sorted ~50 ps per sample.
-            const size_t room = kValueLdsBudget - sizeof(LevelTab);
-            int ch = 0;
-            for (int c : {4, 2, 1})
-                if (!ch && (D % c) == 0 && (size_t)I * c * sizeof(TileAcc) <= room) ch = c;
-            if (ch) {
-                const double s_plane = (double)Q * (double)(L * P), planes = (double)(B * H);
-                const double rounds = (double)((int64_t)(planes * (double)(D / ch) + 255) / 256);
-                const double t_tile = rounds * s_plane * 2.2e-3, t_sorted = 50.0 + planes * s_plane * 3.5e-5;
-                if (t_tile < t_sorted) sorted = false;
-            }
-        }
-        rc = sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
-        if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
-    }
+    if (want_value) rc = run_value<T>(p, d, workspace, workspace_bytes, stream);
     if (forked) {
         const int jrc = side_stream_join(stream);
         if (rc == 0 && jrc != 0) {
             set_error("joining the side stream failed: %s", hipGetErrorString((hipError_t)jrc));
             rc = jrc;
         }
+    }
+    return rc;
+}
+
+// Module backward with the prologue's chain rule fused in: from grad_out straight to
+// grad_value, grad_proj [B,Q,H,L,P,3] and per-head partial sums of grad_reference_points [B,Q,H,ref_dim].
+// The first `fused_mat_bytes` of the workspace receive the sampling points / attention weights the kernel
+// derives (the grad_value passes read them); the rest is the sorted pipeline's workspace.
+inline size_t fused_mat_bytes(int64_t B, int64_t H, int64_t Q, int64_t L, int64_t P, size_t elem)
+{
+    return align_up((size_t)(B * Q * H * L * P) * 3 * elem, 256);
+}
+
+template <typename T>
+int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes, const void *proj, const void *ref,
+                  void *grad_value, void *grad_proj, void *grad_ref_part, int64_t B, int64_t I, int64_t H, int64_t D,
+                  int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode, int align_corners, void *workspace,
+                  int64_t workspace_bytes, void *stream_)
+{
+    const Dims d{B, I, H, D, Q, L, P};
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc = check_common<T>(d, padding_mode, nullptr, 0);
+    if (rc) return rc;
+    if (ref_dim != 2 && ref_dim != 4) {
+        set_error("ref_dim must be 2 or 4, got %d", ref_dim);
+        return MSDA_ERR_BAD_ARG;
+    }
+    if (grad_proj == nullptr || grad_ref_part == nullptr) {
+        set_error("the fused backward always produces grad_proj and the grad_reference_points partials");
+        return MSDA_ERR_BAD_ARG;
+    }
+    const size_t gv_bytes = (size_t)(B * I * H * D) * sizeof(T);
+    const size_t ns = (size_t)(B * Q * H * L * P);
+    if (B * Q * H * D == 0 || L * P == 0 || I == 0) {  // no sample touches anything: all gradients are zero
+        hipError_t e = hipSuccess;
+        if (gv_bytes && grad_value) e = hipMemsetAsync(grad_value, 0, gv_bytes, stream);
+        if (e == hipSuccess && ns) e = hipMemsetAsync(grad_proj, 0, ns * 3 * sizeof(T), stream);
+        if (e == hipSuccess && B * Q * H) e = hipMemsetAsync(grad_ref_part, 0, (size_t)(B * Q * H) * ref_dim * sizeof(T), stream);
+        return (int)e;
+    }
+    const void *ptrs[] = {grad_out, value, shapes, proj, ref};
+    rc = check_common<T>(d, padding_mode, ptrs, 5);
+    if (rc) return rc;
+    if (Q * H * L * P * 3 >= ((int64_t)1 << 31)) {
+        set_error("projection too large for 32-bit sample offsets");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    if (!aligned_to(value, sizeof(T)) || !aligned_to(grad_out, sizeof(T)) || !aligned_to(grad_value, sizeof(T)) ||
+        !aligned_to(proj, sizeof(T)) || !aligned_to(grad_proj, sizeof(T)) || !aligned_to(ref, sizeof(T)) ||
+        !aligned_to(grad_ref_part, sizeof(T)) || !aligned_to(shapes, 8)) {
+        set_error("misaligned buffer");
+        return MSDA_ERR_MISALIGNED;
+    }
+    const bool want_value = grad_value != nullptr;
+    const size_t mat = fused_mat_bytes(B, H, Q, L, P, sizeof(T));
+    if (want_value && (workspace == nullptr || !aligned_to(workspace, 256) || (uint64_t)workspace_bytes < mat)) {
+        set_error("the fused backward needs a 256-byte aligned workspace of at least %zu bytes for grad_value", mat);
+        return MSDA_ERR_BAD_ARG;
+    }
+    Params p{};
+    p.value = value;
+    p.shapes = shapes;
+    p.loc = proj;
+    p.attn = nullptr;
+    p.grad_out = grad_out;
+    p.grad_value = grad_value;
+    p.grad_loc = grad_proj;
+    p.grad_attn = grad_ref_part;
+    fill_params(p, d, padding_mode, align_corners);
+    p.ref = ref;
+    p.ref_dim = ref_dim;
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    if (want_value) {
+        p.mat_loc = ws;
+        p.mat_attn = ws + ns * 2 * sizeof(T);
+    }
+    const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
+    rc = dispatch_gather<T, 3>(p, vec_ok, stream);
+    if (rc) {
+        if (rc > 0) set_error("fused backward launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return rc;
+    }
+    if (want_value) {
+        p.loc = p.mat_loc;
+        p.attn = p.mat_attn;
+        p.ref = nullptr;
+        p.ref_dim = 0;
+        rc = run_value<T>(p, d, ws + mat, workspace_bytes - (int64_t)mat, stream);
     }
     return rc;
 }
@@ -555,4 +659,15 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     {                                                                                                            \
         return msda::run_bwd<T>(grad_out, value, shapes, loc, attn, grad_value, grad_loc, grad_attn, B, I, H,   \
                                 D, Q, L, P, padding_mode, align_corners, workspace, workspace_bytes, stream);    \
+    }                                                                                                            \
+    extern "C" int msda_bwd_fused_##SUF(const void *grad_out, const void *value, const int64_t *shapes,         \
+                                        const void *proj, const void *ref, void *grad_value, void *grad_proj,   \
+                                        void *grad_ref_partial, int64_t B, int64_t I, int64_t H, int64_t D,      \
+                                        int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,          \
+                                        int align_corners, void *workspace, int64_t workspace_bytes,             \
+                                        void *stream)                                                            \
+    {                                                                                                            \
+        return msda::run_bwd_fused<T>(grad_out, value, shapes, proj, ref, grad_value, grad_proj,                \
+                                      grad_ref_partial, B, I, H, D, Q, L, P, ref_dim, padding_mode,              \
+                                      align_corners, workspace, workspace_bytes, stream);                        \
     }

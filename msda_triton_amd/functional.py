@@ -295,10 +295,51 @@ def msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, al
     return out
 
 
+def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, padding_mode, align_corners,
+                       need_img: bool = True):
+    """Backward of the module core with the prologue's chain rule done in the kernel: returns
+    ``(img_grad | None, proj_grad, reference_points_grad)``, or None when the library declines (L*P too large
+    for one pass; nothing was launched)."""
+    B, I, H, D = img.shape
+    _, Q, _, L, P, _ = proj.shape
+    ref_dim = reference_points.shape[-1]
+    pad = _padding_code(padding_mode)
+    suf = _SUFFIX[img.dtype]
+    img, proj, reference_points = img.contiguous(), proj.contiguous(), reference_points.contiguous()
+    out_grad = out_grad.contiguous()
+    if out_grad.dtype != img.dtype:
+        out_grad = out_grad.to(img.dtype)
+    shapes = _shapes_i64(img_shapes)
+    kw = dict(dtype=img.dtype, device=img.device)
+    g_img = torch.empty((B, I, H, D), **kw) if need_img else None
+    g_proj = torch.empty((B, Q, H, L, P, 3), **kw)
+    g_ref_part = torch.empty((B, Q, H, ref_dim), **kw)
+    lib = _lib.load()
+    fn = getattr(lib, f"msda_bwd_fused_{suf}")
+    ws, ws_bytes = None, 0
+    if need_img:
+        ws_bytes = int(lib.msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, img.element_size()))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
+
+    def call():
+        return fn(out_grad.data_ptr(), img.data_ptr(), shapes.data_ptr(), proj.data_ptr(), reference_points.data_ptr(),
+                  g_img.data_ptr() if need_img else None, g_proj.data_ptr(), g_ref_part.data_ptr(),
+                  B, I, H, D, Q, L, P, ref_dim, pad, int(bool(align_corners)),
+                  ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(img.device))
+
+    with torch.cuda.device(img.device):
+        timer = KernelTimer.active
+        rc = timer.launch("msda_bwd_fused", img.device, call) if timer else call()
+    if rc == -5:  # MSDA_ERR_UNSUPPORTED
+        return None
+    _lib.check(rc, f"msda_bwd_fused_{suf}")
+    return g_img, g_proj, g_ref_part.sum(dim=2)
+
+
 class _HipFusedModuleCoreFunction(Function):
-    """value, raw projection, reference points -> attended values.  Forward: one fused kernel.  Backward:
-    the prologue is recomputed in PyTorch (cheap elementwise ops), the operator's HIP backward supplies the
-    gradients of the sampling points / attention weights, and autograd chains them to the projection."""
+    """value, raw projection, reference points -> attended values.  Forward and backward are one fused kernel
+    (pipeline) each: the softmax / sampling-point prologue and its chain rule run inside the HIP kernels.  When the
+    library declines (L*P too large for one LDS pass) the prologue is done in PyTorch around the plain operator."""
 
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -317,6 +358,12 @@ class _HipFusedModuleCoreFunction(Function):
     def backward(ctx, out_grad):
         img, img_shapes, proj, reference_points = ctx.saved_tensors
         need_img, _, need_proj, need_ref = ctx.needs_input_grad[:4]
+        if need_proj or need_ref:
+            res = msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, ctx.padding_mode,
+                                     ctx.align_corners, need_img)
+            if res is not None:
+                g_img, g_proj, g_ref = res
+                return g_img, None, (g_proj if need_proj else None), (g_ref if need_ref else None), None, None
         with torch.enable_grad():
             proj_ = proj.detach().requires_grad_(need_proj)
             ref_ = reference_points.detach().requires_grad_(need_ref)

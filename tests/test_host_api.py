@@ -16,9 +16,11 @@ def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "msda_hip.h")).read()
     names = set(re.findall(r"MSDA_API\s+(?:const\s+)?\w+\s*\*?\s*(msda_\w+)\s*\(", text))
     names = {n for n in names if "##" not in n}
+    stems = re.findall(r"MSDA_API\s+int\s+(msda_\w+_)##SUF\s*\(", text)   # the per-dtype entry points of MSDA_DECLARE
+    assert len(stems) >= 4, stems
     for suf in re.findall(r"MSDA_DECLARE\((\w+)\)", text):
         if suf != "SUF":
-            names |= {f"msda_fwd_{suf}", f"msda_bwd_{suf}", f"msda_fwd_fused_{suf}"}
+            names |= {stem + suf for stem in stems}
     return names
 
 
