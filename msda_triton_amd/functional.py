@@ -345,6 +345,7 @@ class _HipFusedModuleCoreFunction(Function):
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, img, img_shapes, proj, reference_points, padding_mode, align_corners):
         out = msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, align_corners)
+        ctx.fused = out is not None  # the backward has the same L*P limit: do not ask twice
         if out is None:
             pts, att = module_sampling_inputs(proj, img_shapes, reference_points)
             out = msda_hip_fwd(img, img_shapes, pts, att, padding_mode, align_corners)
@@ -358,7 +359,7 @@ class _HipFusedModuleCoreFunction(Function):
     def backward(ctx, out_grad):
         img, img_shapes, proj, reference_points = ctx.saved_tensors
         need_img, _, need_proj, need_ref = ctx.needs_input_grad[:4]
-        if need_proj or need_ref:
+        if ctx.fused and (need_proj or need_ref):
             res = msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, ctx.padding_mode,
                                      ctx.align_corners, need_img)
             if res is not None:

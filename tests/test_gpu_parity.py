@@ -656,3 +656,67 @@ def test_fused_module_core_is_the_module_path_and_handles_large_lp():
     want = ops.multiscale_deformable_attention(v, s, pts, att, "border", True)
     torch.testing.assert_close(got, want, atol=2e-5, rtol=1e-4)
     assert _lib.load().msda_abi_version() == _lib.ABI_VERSION
+
+
+@pytest.mark.parametrize("coords", [2, 4])
+@pytest.mark.parametrize("pm,ac", MODES, ids=[mode_key(*m) for m in MODES])
+def test_fused_backward_fp64_matches_autograd_through_the_prologue(coords, pm, ac):
+    """msda_bwd_fused_f64 (softmax / offset chain rule inside the kernel, per-head partials of the reference
+    points' gradient) against PyTorch autograd through module_sampling_inputs + the plain operator, at fp64
+    tolerance; the fused kernels are the ones that ran."""
+    from msda_triton_amd.functional import KernelTimer, fused_module_core, module_sampling_inputs
+    ops = _ops()
+    levels = [(7, 5), (4, 6), (2, 3)]           # non-square: the (h, w) division order matters
+    B, Q, H, D, L, P = 2, 37, 3, 16, len(levels), 4
+    g = torch.Generator(device="cpu").manual_seed(1234 + coords)
+    value = torch.randn(B, sum(h * w for h, w in levels), H, D, generator=g, dtype=torch.float64)
+    proj = torch.randn(B, Q, H, L, P, 3, generator=g, dtype=torch.float64) * 1.5
+    ref = torch.rand(B, Q, coords, generator=g, dtype=torch.float64)
+    gout = torch.rand(B, Q, H, D, generator=g, dtype=torch.float64)
+    s = torch.tensor(levels, device=DEV)
+    res = []
+    for fused in (True, False):
+        v, pr, rf = (t.clone().to(DEV).requires_grad_(True) for t in (value, proj, ref))
+        with KernelTimer() as kt:
+            if fused:
+                out = fused_module_core(v, s, pr, rf, pm, ac)
+            else:
+                pts, att = module_sampling_inputs(pr, s, rf)
+                out = ops.multiscale_deformable_attention(v, s, pts, att, pm, ac)
+            out.backward(gout.to(DEV))
+            torch.cuda.synchronize()
+        if fused:
+            assert set(kt.summary()) == {"msda_fwd_fused", "msda_bwd_fused"}, kt.summary()
+        res.append((out.detach(), v.grad, pr.grad, rf.grad))
+    for name, a, b in zip(("out", "grad_value", "grad_proj", "grad_ref"), res[0], res[1]):
+        torch.testing.assert_close(a, b, atol=1e-9, rtol=1e-8, msg=lambda m, n=name: f"{n}: {m}")
+
+
+def test_fused_backward_partial_needs_and_large_lp_fallback():
+    """value without grad: the fused backward skips the grad_value passes; L*P too large for one LDS pass: the
+    module core still differentiates (PyTorch prologue around the plain operator)."""
+    from msda_triton_amd.functional import KernelTimer, fused_module_core, module_sampling_inputs
+    ops = _ops()
+    torch.manual_seed(11)
+    levels = [(5, 4), (2, 2)]
+    s = torch.tensor(levels, device=DEV)
+    v = torch.randn(2, 24, 2, 8, device=DEV)
+    pr = torch.randn(2, 9, 2, 2, 3, 3, device=DEV, requires_grad=True)
+    rf = torch.rand(2, 9, 4, device=DEV, requires_grad=True)
+    fused_module_core(v, s, pr, rf, "zeros", False).sum().backward()
+    pr2, rf2 = pr.detach().clone().requires_grad_(True), rf.detach().clone().requires_grad_(True)
+    pts, att = module_sampling_inputs(pr2, s, rf2)
+    ops.multiscale_deformable_attention(v, s, pts, att, "zeros", False).sum().backward()
+    torch.testing.assert_close(pr.grad, pr2.grad, atol=1e-4, rtol=1e-3)
+    torch.testing.assert_close(rf.grad, rf2.grad, atol=1e-4, rtol=1e-3)
+    # 1280 samples per unit
+    v = torch.randn(1, 13, 1, 8, device=DEV, requires_grad=True)
+    pr = torch.randn(1, 3, 1, 2, 640, 3, device=DEV, requires_grad=True)
+    rf = torch.rand(1, 3, 2, device=DEV, requires_grad=True)
+    s = torch.tensor([(3, 3), (2, 2)], device=DEV)
+    with KernelTimer() as kt:
+        fused_module_core(v, s, pr, rf, "border", True).sum().backward()
+        torch.cuda.synchronize()
+    assert "msda_bwd_fused" not in kt.summary() and "msda_bwd_sample" in kt.summary()
+    assert pr.grad is not None and rf.grad is not None and v.grad is not None
+    assert torch.isfinite(pr.grad).all()
