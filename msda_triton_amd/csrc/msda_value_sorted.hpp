@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
                         e.dx = dx;
                         e.dy = dy;
                         e.a = TR::to_acc(at);
-                        entries[pos] = e;
+                        entries[pos] = e;  // (plain store: these partial lines must merge in L2 — streaming stores: 57 -> 202 us)
                     }
                 }
             }
