@@ -720,3 +720,26 @@ def test_fused_backward_partial_needs_and_large_lp_fallback():
     assert "msda_bwd_fused" not in kt.summary() and "msda_bwd_sample" in kt.summary()
     assert pr.grad is not None and rf.grad is not None and v.grad is not None
     assert torch.isfinite(pr.grad).all()
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_shapes_against_oracle(oracle, seed):
+    """Differential test over random shapes / modes / coordinate ranges (fixed seeds), with the sorted-gather
+    grad_value pipeline forced so that its cell / work-item bookkeeping sees odd pyramids, empty cells, cells on
+    the border and out-of-range samples."""
+    from msda_triton_amd import _lib
+    rng = np.random.default_rng(9000 + seed)
+    B, Q, H = int(rng.integers(1, 4)), int(rng.integers(1, 160)), int(rng.integers(1, 5))
+    D = int(rng.choice([1, 3, 8, 16, 32, 40, 64]))
+    L, P = int(rng.integers(1, 5)), int(rng.integers(1, 6))
+    levels = [(int(rng.integers(1, 13)), int(rng.integers(1, 13))) for _ in range(L)]
+    lo, hi = [(-0.4, 1.4), (0.0, 1.0), (0.3, 0.6), (-3.0, 4.0)][seed % 4]
+    pm, ac = MODES[int(rng.integers(0, len(MODES)))]
+    f64 = seed % 3 == 0
+    c = rand_case(rng, B, Q, H, D, levels, P, lo=lo, hi=hi, dtype=np.float64 if f64 else np.float32)
+    td = torch.float64 if f64 else torch.float32
+    try:
+        _lib.set_option("value_path", 2)
+        check_against_oracle(oracle, c, pm, ac, FWD_TOL[td], BWD_TOL[td])
+    finally:
+        _lib.set_option("value_path", 0)
