@@ -71,6 +71,7 @@ def cpu_baseline(wl, budget_s=20.0):
             break
     med_all = sorted(t_all)[len(t_all) // 2]
     med_fwd = sorted(t_fwd)[len(t_fwd) // 2]
+    torch_cpu = torch_cpu_fallback(wl)
     return {
         "value": wl.B * q_sample / med_all,
         "unit": "queries/s",
@@ -80,7 +81,32 @@ def cpu_baseline(wl, budget_s=20.0):
                   f"element (B={wl.B}), fp32, median",
         "fwd_ms_scaled_to_full": med_fwd * 1e3 * wl.Q / q_sample,
         "fwd_bwd_ms_scaled_to_full": med_all * 1e3 * wl.Q / q_sample,
+        "torch_cpu_fallback": torch_cpu,
     }
+
+
+def torch_cpu_fallback(wl, budget_s=8.0, q_sample=1000):
+    """The host-tensor path of this package (plain PyTorch, the formulation of the reference's CPU fallback,
+    frontend.py:15-68) timed on the host cores through autograd, on a bounded query sample."""
+    import torch
+    from msda_triton_amd import synth
+    from msda_triton_amd.functional import native_multiscale_deformable_attention
+
+    q_sample = min(wl.Q, q_sample)
+    d = synth.make_inputs_torch(wl, "cpu", seed=0, dtype=torch.float32, q_end=q_sample)
+    v, l, a = (d[k].requires_grad_(True) for k in ("value", "loc", "attn"))
+    times, t_start = [], time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        out = native_multiscale_deformable_attention(v, d["shapes"], l, a, wl.padding_mode, wl.align_corners)
+        out.backward(d["grad_out"])
+        v.grad = l.grad = a.grad = None
+        times.append(time.perf_counter() - t0)
+        if len(times) >= 10:
+            break
+    med = sorted(times)[len(times) // 2]
+    return {"fwd_bwd_ms_scaled_to_full": med * 1e3 * wl.Q / q_sample, "threads": torch.get_num_threads(),
+            "sample": f"{len(times)} fwd+bwd passes on the first {q_sample} queries per batch element, fp32, median"}
 
 
 def main():
