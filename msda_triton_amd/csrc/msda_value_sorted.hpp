@@ -105,8 +105,11 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
     int *part = p.ws_part + (size_t)pair * p.nsplit * p.nc_cap;  // [slice][cell]
     const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
     Entry<A> *entries = static_cast<Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
-    const T *loc = static_cast<const T *>(p.loc);
-    const T *attn = static_cast<const T *>(p.attn);
+    // per-plane bases (64-bit, uniform) + 32-bit per-sample offsets (the host checks Q*H*L*P*2 < 2^31)
+    const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
+    const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
+    const T *attn = static_cast<const T *>(p.attn) + plane_s0;
+    const int HLP = p.H * p.LP;
     const float inv_P = 1.0f / (float)p.P;
     const int tid = threadIdx.x;
     const int dq = kCellBlock / p.LP, dr = kCellBlock - dq * p.LP;
@@ -123,25 +126,27 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
         // software-pipelined walk: the next sample's (x, y, a) are requested before this sample's entry is
         // stored, so the wait for them never has to drain the scattered store behind it (one vmcnt queue)
         int q = qa + tid / p.LP, sl = tid % p.LP;
+        int sidx = q * HLP + sl;  // sample offset inside the plane, advanced incrementally
+        const int d_sidx = dq * HLP + dr;
         Pack<T, 2> xy, xy_n;
         T at = TR::from_acc((A)0), at_n = at;
         xy.v[0] = xy.v[1] = at;
         xy_n = xy;
         if (q < qb) {
-            const size_t sidx = ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.LP + sl;
             xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
             if constexpr (PLACE) at = attn[sidx];
         }
         while (q < qb) {
             int qn = q + dq, sn = sl + dr;
+            sidx += d_sidx;
             if (sn >= p.LP) {
                 sn -= p.LP;
                 ++qn;
+                sidx += HLP - p.LP;
             }
             if (qn < qb) {
-                const size_t sidx_n = ((size_t)(b * (size_t)p.Q + qn) * p.H + h) * p.LP + sn;
-                xy_n = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx_n);
-                if constexpr (PLACE) at_n = attn[sidx_n];
+                xy_n = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                if constexpr (PLACE) at_n = attn[sidx];
             }
             const int l = div_small(sl, p.P, inv_P);
             int cell;
