@@ -587,7 +587,10 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     const size_t pairs = (size_t)(B * H);
     const size_t samples = (size_t)(Q * L * P);  // per plane
     w.nc_cap = (int)(2 * I + 2 * L);             // (w+1)(h+1) <= 2wh + 2 per level
-    w.it_cap = (int)(w.nc_cap + samples / kChunk + 1);  // sum over cells of ceil(n / kChunk)
+    // work items: sum over cells of ceil(n / kChunk) <= cells + samples / kChunk, and never more than the samples
+    size_t items = (size_t)w.nc_cap + samples / kChunk + 1;
+    if (items > samples) items = samples > 0 ? samples : 1;
+    w.it_cap = (int)items;
     // query slices per plane: enough workgroups to fill the chip, at least ~2k samples each
     int64_t ns = pairs ? (int64_t)((256 + pairs - 1) / pairs) : 1;
     const int64_t by_work = (int64_t)((samples + 2047) / 2048);
