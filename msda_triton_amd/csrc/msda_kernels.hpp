@@ -63,6 +63,8 @@ struct Params {
     void *ws_entries;   // [pairs][Q*L*P]     Entry<acc>: sample records sorted by cell
     void *ws_scratch;   // [pairs][it_cap][4][D] acc-typed partial rows: one per work item and cell corner
     int nc_cap, it_cap;
+    int4 *ws_chunks;    // tile path: global chunk list (pair, bin, first record, records | multi flag); ws_itemcnt = its length
+    int nb_cap, ch_cap; // tile path: bins per plane (capacity), chunk list capacity
     int nsplit;         // query slices per plane in the count / place passes
     int cell_cap;       // cells a count / place workgroup holds in LDS at a time
 };

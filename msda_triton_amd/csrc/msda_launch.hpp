@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "msda_value_sorted.hpp"
+#include "msda_value_tiles.hpp"
 #include "msda_value_tile.hpp"
 
 namespace msda {
@@ -14,6 +15,7 @@ int option_xcd_map();
 int option_value_path();  // 0: auto (sorted gather for big problems, LDS tiles for small), 1: tiles, 2: sorted
 int option_stage_kb();    // LDS KiB a gather workgroup may spend on staged pyramid levels (0: off)
 int option_gather_block();  // threads per gather workgroup when staging is on (256 / 512 / 1024)
+int option_tile_path();     // 1: large problems take the tile-binned grad_value path when it applies (default 0 until proven)
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
 int option_debug();         // dev-only ablation mask
 int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream
@@ -441,6 +443,59 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
     return rc;
 }
 
+// ---- tile-binned grad_value (msda_value_tiles.hpp): T1..T4 ----
+template <typename T> inline bool tiles_applicable(const Params &p, const Dims &d, void *workspace, int64_t workspace_bytes)
+{
+    using A = typename Traits<T>::acc;
+    if (sizeof(T) != sizeof(A)) return false;  // fp32 / fp64 only: partial sums are added atomically in the output type
+    constexpr int VECF = 16 / sizeof(T);
+    if (!(aligned_to(p.grad_out, 16) && aligned_to(p.grad_value, 16) && (p.D % VECF) == 0)) return false;
+    if (d.Q >= ((int64_t)1 << kLcellShift)) return false;
+    const TileWsLayout w = tile_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A));
+    if (w.nb_cap > kTileBinCap) return false;
+    return workspace != nullptr && aligned_to(workspace, 256) && (uint64_t)workspace_bytes >= w.total;
+}
+
+template <typename T> inline int run_value_tiles(Params &p, const Dims &d, void *workspace, hipStream_t stream)
+{
+    using A = typename Traits<T>::acc;
+    const TileWsLayout w = tile_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A));
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    p.ws_part = reinterpret_cast<int *>(ws + w.off_part);
+    p.ws_off = reinterpret_cast<int *>(ws + w.off_binoff);
+    p.ws_itemcnt = reinterpret_cast<int *>(ws + w.off_cnt);
+    p.ws_chunks = reinterpret_cast<int4 *>(ws + w.off_chunks);
+    p.ws_entries = ws + w.off_entries;
+    p.nb_cap = w.nb_cap;
+    p.ch_cap = w.ch_cap;
+    p.nsplit = w.nsplit;
+    const int npairs = p.B * p.H;
+    int rc = (int)hipMemsetAsync(p.ws_itemcnt, 0, 256, stream);
+    if (rc) return rc;
+    // every pixel row is either stored whole or accumulated atomically: start from zeros
+    rc = (int)hipMemsetAsync(p.grad_value, 0, (size_t)d.B * d.I * d.H * d.D * sizeof(T), stream);
+    if (rc) return rc;
+    dim3 gcell;
+    if (!plane_grid(p, npairs, p.nsplit, gcell)) {
+        set_error("grid too large");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    hipLaunchKernelGGL((msda_tile_count_kernel<T>), gcell, dim3(kCellBlock), 0, stream, p);
+    hipLaunchKernelGGL((msda_tile_scan_kernel<T>), dim3((unsigned)npairs), dim3(kTileScanBlock), 0, stream, p);
+    constexpr int kRounds = sizeof(A) == 8 ? kTileRound / 2 : kTileRound;
+    const size_t place_lds = (size_t)kRounds * kCellBlock * (sizeof(Entry<A>) + sizeof(int));
+    static bool big_lds_ok = false;
+    if (!big_lds_ok) {
+        allow_big_lds(msda_tile_place_kernel<T>);
+        big_lds_ok = true;
+    }
+    hipLaunchKernelGGL((msda_tile_place_kernel<T>), gcell, dim3(kCellBlock), place_lds, stream, p);
+    constexpr int VECF = 16 / sizeof(T);
+    const unsigned nwg = (unsigned)(p.ch_cap < 2048 ? p.ch_cap : 2048);
+    hipLaunchKernelGGL((msda_tile_gather_kernel<T, VECF>), dim3(nwg), dim3(kTileBlock), 0, stream, p);
+    return (int)hipGetLastError();
+}
+
 // grad_value: the sorted-gather pipeline when the caller's workspace allows it, else (or for small problems) the
 // LDS-tile kernel.
 template <typename T>
@@ -465,7 +520,15 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
             if (t_tile < t_sorted) sorted = false;
         }
     }
-    const int rc = sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
+    int rc;
+    if constexpr (sizeof(T) == sizeof(A)) {
+        const bool tiles = (option_value_path() == 3 || (option_value_path() == 0 && sorted && option_tile_path())) &&
+                           tiles_applicable<T>(p, d, workspace, workspace_bytes);
+        rc = tiles ? run_value_tiles<T>(p, d, workspace, stream)
+                   : sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
+    } else {
+        rc = sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
+    }
     if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

@@ -473,7 +473,7 @@ def test_graph_capture_replays():
 # ------------------------------------------------------------------------------------------
 # backward grad_value: both implementations, and the shapes that stress the sorted gather
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("value_path", [2, 1], ids=["sorted_gather", "lds_tiles"])
+@pytest.mark.parametrize("value_path", [2, 1, 3], ids=["sorted_gather", "lds_tiles", "tile_bins"])
 @pytest.mark.parametrize("pm,ac", MODES, ids=[mode_key(*m) for m in MODES])
 def test_grad_value_both_paths_and_hot_pixels(oracle, value_path, pm, ac):
     """Every query samples the same few pixels (lists far longer than one work-item chunk, so pixels are
@@ -493,7 +493,8 @@ def test_grad_value_both_paths_and_hot_pixels(oracle, value_path, pm, ac):
 @pytest.mark.parametrize("D,Q,td", [(32, 3000, torch.float32), (512, 700, torch.float32), (32, 3000, torch.float64),
                                     (32, 3000, torch.bfloat16)],
                          ids=["f32_d32", "f32_d512_two_channel_chunks", "f64_d32", "bf16_d32"])
-def test_grad_value_cell_flood_spans_gather_workgroups(oracle, D, Q, td):
+@pytest.mark.parametrize("value_path", [2, 3], ids=["sorted_gather", "tile_bins"])
+def test_grad_value_cell_flood_spans_gather_workgroups(oracle, D, Q, td, value_path):
     """A 1x1 level: every sample falls into one of four cells, so a cell's list is cut into far more work items
     than one gather workgroup holds — items are merged inside workgroups, the finish kernel adds one row per
     workgroup, and the cell-scan kernel writes these records with the whole block."""
@@ -506,7 +507,7 @@ def test_grad_value_cell_flood_spans_gather_workgroups(oracle, D, Q, td):
         for k in ("value", "loc", "attn", "grad_out"):
             c[k] = torch.from_numpy(c[k]).to(td).float().numpy()
     try:
-        _lib.set_option("value_path", 2)
+        _lib.set_option("value_path", value_path)
         for pm, ac in (("zeros", False), ("border", True)):
             _, gv, _, _ = run_hip(c["value"], c["shapes"], c["loc"], c["attn"], c["grad_out"], pm, ac, dtype=td)
             r_gv, _, _ = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], pm, ac)
@@ -722,8 +723,9 @@ def test_fused_backward_partial_needs_and_large_lp_fallback():
     assert torch.isfinite(pr.grad).all()
 
 
+@pytest.mark.parametrize("value_path", [2, 3], ids=["sorted_gather", "tile_bins"])
 @pytest.mark.parametrize("seed", list(range(24)))
-def test_random_shapes_against_oracle(oracle, seed):
+def test_random_shapes_against_oracle(oracle, seed, value_path):
     """Differential test over random shapes / modes / coordinate ranges (fixed seeds), with the sorted-gather
     grad_value pipeline forced so that its cell / work-item bookkeeping sees odd pyramids, empty cells, cells on
     the border and out-of-range samples."""
@@ -739,7 +741,7 @@ def test_random_shapes_against_oracle(oracle, seed):
     c = rand_case(rng, B, Q, H, D, levels, P, lo=lo, hi=hi, dtype=np.float64 if f64 else np.float32)
     td = torch.float64 if f64 else torch.float32
     try:
-        _lib.set_option("value_path", 2)
+        _lib.set_option("value_path", value_path)
         check_against_oracle(oracle, c, pm, ac, FWD_TOL[td], BWD_TOL[td])
     finally:
         _lib.set_option("value_path", 0)
