@@ -186,7 +186,7 @@ constexpr size_t kGatherLdsFixed = sizeof(LevelTab) + (sizeof(StagePlan) + 15) /
 // ITS 64/G units, gathers, stores, and moves to its next query chunk without any block barrier.
 // ==========================================================================================
 template <typename T, int VEC, int G, int BLOCK, bool STAGE, bool FUSED>
-__global__ __launch_bounds__(BLOCK) void msda_fwd_kernel(const Params p)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void msda_fwd_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
