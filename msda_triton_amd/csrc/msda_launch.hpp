@@ -296,6 +296,8 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
     p.ws_off = reinterpret_cast<int *>(ws + w.off_off);
     p.ws_cellitem = reinterpret_cast<int *>(ws + w.off_cellitem);
     p.ws_itemcnt = reinterpret_cast<int *>(ws + w.off_itemcnt);
+    p.ws_meta = reinterpret_cast<int *>(ws + w.off_meta);
+    p.ws_blocksum = reinterpret_cast<int2 *>(ws + w.off_blocksum);
     p.ws_items = reinterpret_cast<int2 *>(ws + w.off_items);
     p.ws_entries = ws + w.off_entries;
     p.ws_scratch = ws + w.off_scratch;
@@ -323,13 +325,7 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
         return MSDA_ERR_TOO_LARGE;
     }
     hipLaunchKernelGGL((msda_cell_total_kernel<T>), dim3((unsigned)tot_blocks), dim3(kBlock), 0, stream, p);
-    const size_t scan_lds = (size_t)(p.cell_cap + 1) * sizeof(int);
-    static bool scan_lds_ok = false;
-    if (!scan_lds_ok) {
-        allow_big_lds(msda_cell_scan_kernel<T>);
-        scan_lds_ok = true;
-    }
-    hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)npairs), dim3(kCellBlock), scan_lds, stream, p);
+    hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)tot_blocks), dim3(kBlock), 0, stream, p);
     hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
     int rc = (int)hipGetLastError();
     if (rc) return rc;

@@ -101,6 +101,8 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
     __syncthreads();
     const int ncells = plane_cells(*tab, p.L);
     const int cap = p.cell_cap;
+    if constexpr (!PLACE)
+        if (threadIdx.x == 0) p.ws_meta[0] = ncells;  // (every workgroup writes the same value) for the scan kernels
 
     int *part = p.ws_part + (size_t)pair * p.nsplit * p.nc_cap;  // [slice][cell]
     const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
@@ -182,41 +184,16 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
 }
 
 // ------------------------------------------------------------------------------------------
-// K2a: off[cell] = number of samples in the cell (sum over the query slices), and part[j][cell] becomes
-// the exclusive prefix over the slices (slice j's first slot relative to the start of the cell's list)
+// K2a / K2b: the per-plane scans, as a three-phase parallel scan over blocks of kBlock cells (a plane's cell
+// table is a few thousand to tens of thousands of entries: one workgroup per plane left 240 CUs idle).
+//   K2a  per cell: off[cell] = records in the cell (sum over the query slices) and part[j][cell] becomes slice j's
+//        first slot relative to the start of the cell's list; per block: (records, work items) -> blocksum
+//   K2b  per block: base = sum of the preceding blocks' sums (a few dozen loads), exclusive scan inside the block:
+//        off[cell] = first record, cellitem[cell] = first work item, work-item records of the block's cells
 // ------------------------------------------------------------------------------------------
-template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_total_kernel(const Params p)
-{
-    const int per_plane = (p.nc_cap + kBlock - 1) / kBlock;
-    const int pair = blockIdx.x / per_plane;
-    const int c = (blockIdx.x - pair * per_plane) * kBlock + threadIdx.x;
-    if (c >= p.nc_cap) return;  // cells beyond the plane's real count hold garbage that nobody reads
-    int *part = p.ws_part + (size_t)pair * p.nsplit * p.nc_cap + c;
-    int tot = 0;
-    int j = 0;
-    for (; j + 4 <= p.nsplit; j += 4) {  // four independent loads in flight
-        const int n0 = part[(size_t)(j + 0) * p.nc_cap], n1 = part[(size_t)(j + 1) * p.nc_cap];
-        const int n2 = part[(size_t)(j + 2) * p.nc_cap], n3 = part[(size_t)(j + 3) * p.nc_cap];
-        part[(size_t)(j + 0) * p.nc_cap] = tot;
-        part[(size_t)(j + 1) * p.nc_cap] = tot + n0;
-        part[(size_t)(j + 2) * p.nc_cap] = tot + n0 + n1;
-        part[(size_t)(j + 3) * p.nc_cap] = tot + n0 + n1 + n2;
-        tot += n0 + n1 + n2 + n3;
-    }
-    for (; j < p.nsplit; ++j) {
-        const int n = part[(size_t)j * p.nc_cap];
-        part[(size_t)j * p.nc_cap] = tot;
-        tot += n;
-    }
-    p.ws_off[(size_t)pair * (p.nc_cap + 1) + c] = tot;
-}
-
-// ------------------------------------------------------------------------------------------
-// K2b: per-plane scans (one 1024-thread workgroup per plane), cell offsets staged in LDS when they fit
-// ------------------------------------------------------------------------------------------
+// exclusive scan of one int over the kCellBlock threads of a workgroup (s_wave: kCellBlock / kWave ints of LDS)
 __device__ __forceinline__ int block_exclusive_scan(int v, int *s_wave, int &total)
 {
-    // inclusive scan inside the wave, then across the 16 waves through LDS
     const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
     int inc = v;
 #pragma unroll
@@ -238,91 +215,134 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *s_wave, int &tot
     return base + inc - v;
 }
 
-// The scans proper.  `off` points either at the LDS copy or at global memory; the function is inlined
-// at both call sites so every access has a known address space (a run-time pointer select would turn
-// them all into slow FLAT operations).
-__device__ __forceinline__ void cell_scan_body(int *off, const LevelTab &tab, int *s_wave, const Params &p, int pair,
-                                               int nc, int *goff_copy)
+// exclusive scan of two ints over the kBlock threads of a workgroup (s: 2 * kBlock / kWave ints of LDS)
+__device__ __forceinline__ void block_scan2(int &a, int &b, int *s, int &tot_a, int &tot_b)
 {
-    const int t = threadIdx.x;
-    // ---- A: exclusive scan of the per-cell totals ----
-    {
-        const int seg = (nc + kCellBlock - 1) / kCellBlock;
-        const int lo = min(nc, t * seg), hi = min(nc, lo + seg);
-        int sum = 0;
-        for (int i = lo; i < hi; ++i) sum += off[i];
-        int total;
-        int run = block_exclusive_scan(sum, s_wave, total);
-        for (int i = lo; i < hi; ++i) {
-            const int c = off[i];
-            off[i] = run;
-            run += c;
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    int ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int na = __shfl_up(ia, d, kWave), nb = __shfl_up(ib, d, kWave);
+        if (lane >= d) {
+            ia += na;
+            ib += nb;
         }
-        if (t == 0) off[nc] = total;
     }
-    __threadfence_block();
+    __syncthreads();  // s may still be in use by a previous scan
+    if (lane == kWave - 1) {
+        s[2 * wid] = ia;
+        s[2 * wid + 1] = ib;
+    }
     __syncthreads();
-    if (goff_copy != nullptr)
-        for (int c = t; c <= nc; c += kCellBlock) goff_copy[c] = off[c];
+    int base_a = 0, base_b = 0;
+    tot_a = tot_b = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / kWave; ++i) {
+        const int sa = s[2 * i], sb = s[2 * i + 1];
+        if (i < wid) {
+            base_a += sa;
+            base_b += sb;
+        }
+        tot_a += sa;
+        tot_b += sb;
+    }
+    a = base_a + ia - a;
+    b = base_b + ib - b;
+}
 
-    // ---- B: work items: every non-empty cell list is cut into kChunk-entry windows ----
+template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_total_kernel(const Params p)
+{
+    const int per_plane = (p.nc_cap + kBlock - 1) / kBlock;
+    const int pair = blockIdx.x / per_plane, blk = blockIdx.x - pair * per_plane;
+    const int nc = p.ws_meta[0];  // real cell count of a plane, left by the count pass
+    if (blk * kBlock >= nc) return;  // block-uniform
+    __shared__ int s_scan[2 * kBlock / kWave];
+    const int c = blk * kBlock + threadIdx.x;
+    int tot = 0;
+    if (c < nc) {
+        int *part = p.ws_part + (size_t)pair * p.nsplit * p.nc_cap + c;
+        int j = 0;
+        for (; j + 4 <= p.nsplit; j += 4) {  // four independent loads in flight
+            const int n0 = part[(size_t)(j + 0) * p.nc_cap], n1 = part[(size_t)(j + 1) * p.nc_cap];
+            const int n2 = part[(size_t)(j + 2) * p.nc_cap], n3 = part[(size_t)(j + 3) * p.nc_cap];
+            part[(size_t)(j + 0) * p.nc_cap] = tot;
+            part[(size_t)(j + 1) * p.nc_cap] = tot + n0;
+            part[(size_t)(j + 2) * p.nc_cap] = tot + n0 + n1;
+            part[(size_t)(j + 3) * p.nc_cap] = tot + n0 + n1 + n2;
+            tot += n0 + n1 + n2 + n3;
+        }
+        for (; j < p.nsplit; ++j) {
+            const int n = part[(size_t)j * p.nc_cap];
+            part[(size_t)j * p.nc_cap] = tot;
+            tot += n;
+        }
+        p.ws_off[(size_t)pair * (p.nc_cap + 1) + c] = tot;
+    }
+    int ex_n = tot, ex_c = (tot + kChunk - 1) / kChunk, sum_n, sum_c;
+    block_scan2(ex_n, ex_c, s_scan, sum_n, sum_c);
+    if (threadIdx.x == 0) p.ws_blocksum[(size_t)pair * per_plane + blk] = make_int2(sum_n, sum_c);
+}
+
+template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_scan_kernel(const Params p)
+{
+    const int per_plane = (p.nc_cap + kBlock - 1) / kBlock;
+    const int pair = blockIdx.x / per_plane, blk = blockIdx.x - pair * per_plane;
+    const int nc = p.ws_meta[0];
+    if (blk * kBlock >= nc) return;  // block-uniform
+    __shared__ int s_scan[2 * kBlock / kWave];
+    __shared__ int s_big[1 + 3 * kBigCells];  // [0] = count, then (first item, first record, records) of the cells whose
+                                              // work-item records the whole block writes
+    const int t = threadIdx.x;
+    if (t == 0) s_big[0] = 0;
+    // base of this block: the sums of the blocks before it
+    int base_n = 0, base_c = 0;
+    {
+        int an = 0, ac = 0;
+        for (int i = t; i < blk; i += kBlock) {
+            const int2 v = p.ws_blocksum[(size_t)pair * per_plane + i];
+            an += v.x;
+            ac += v.y;
+        }
+        int tn, tc;
+        block_scan2(an, ac, s_scan, tn, tc);  // (only the totals are used)
+        base_n = tn;
+        base_c = tc;
+    }
+    int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
     int *cellitem = p.ws_cellitem + (size_t)pair * (p.nc_cap + 1);
     int2 *items = p.ws_items + (size_t)pair * p.it_cap;
-    int *s_big = s_wave + kCellBlock / kWave;  // [0] = count, [1..kBigCells] = cells whose records the whole block writes
-    if (t == 0) s_big[0] = 0;
-    const int seg = (nc + kCellBlock - 1) / kCellBlock;
-    const int lo = min(nc, t * seg), hi = min(nc, lo + seg);
-    int sum = 0;
-    for (int c = lo; c < hi; ++c) sum += (off[c + 1] - off[c] + kChunk - 1) / kChunk;
-    int total;
-    int run = block_exclusive_scan(sum, s_wave, total);  // (its barriers also publish s_big[0] = 0)
-    for (int c = lo; c < hi; ++c) {
-        const int beg = off[c], n = off[c + 1] - beg;
-        const int chunks = (n + kChunk - 1) / kChunk;
-        cellitem[c] = run;
+    const int c = blk * kBlock + t;
+    const int n = c < nc ? off[c] : 0;
+    const int chunks = (n + kChunk - 1) / kChunk;
+    int ex_n = n, ex_c = chunks, sum_n, sum_c;
+    block_scan2(ex_n, ex_c, s_scan, sum_n, sum_c);  // (its barriers also publish s_big[0] = 0)
+    const int beg = base_n + ex_n, first = base_c + ex_c;
+    if (c < nc) {
+        off[c] = beg;
+        cellitem[c] = first;
         int slot = kBigCells;
         if (chunks > kBigChunks) slot = atomicAdd(&s_big[0], 1);
         if (chunks <= kBigChunks || slot >= kBigCells) {
             for (int k = 0; k < chunks; ++k)
-                items[run + k] = make_int2(beg + k * kChunk, min(kChunk, n - k * kChunk) | (k ? kContFlag : 0));
+                items[first + k] = make_int2(beg + k * kChunk, min(kChunk, n - k * kChunk) | (k ? kContFlag : 0));
         } else {
-            s_big[1 + slot] = c;
-            s_big[1 + kBigCells + slot] = run;
+            s_big[1 + 3 * slot] = first;
+            s_big[2 + 3 * slot] = beg;
+            s_big[3 + 3 * slot] = n;
         }
-        run += chunks;
-    }
-    if (t == 0) {
-        cellitem[nc] = total;
-        p.ws_itemcnt[pair] = total;
+        if (c == nc - 1) {  // the plane's totals behind the last cell
+            off[nc] = beg + n;
+            cellitem[nc] = first + chunks;
+            p.ws_itemcnt[pair] = first + chunks;
+        }
     }
     __syncthreads();
     const int nbig = min(s_big[0], kBigCells);
     for (int i = 0; i < nbig; ++i) {  // hot cells (coarse levels, clustered samples): records written by all threads
-        const int c = s_big[1 + i], first = s_big[1 + kBigCells + i];
-        const int beg = off[c], n = off[c + 1] - beg;
-        const int chunks = (n + kChunk - 1) / kChunk;
-        for (int k = t; k < chunks; k += kCellBlock)
-            items[first + k] = make_int2(beg + k * kChunk, min(kChunk, n - k * kChunk) | (k ? kContFlag : 0));
-    }
-}
-
-template <typename Tag> __global__ __launch_bounds__(kCellBlock) void msda_cell_scan_kernel(const Params p)
-{
-    const int pair = blockIdx.x;
-    __shared__ LevelTab tab;
-    __shared__ int s_wave[kCellBlock / kWave + 1 + 2 * kBigCells];  // scan scratch + hot-cell list
-    int *s_off = reinterpret_cast<int *>(msda_smem);
-    load_level_table(&tab, p.shapes, p.L);
-    __syncthreads();
-    const int t = threadIdx.x;
-    const int nc = plane_cells(tab, p.L);
-    int *goff = p.ws_off + (size_t)pair * (p.nc_cap + 1);
-    if (nc <= p.cell_cap) {  // the launch sized the dynamic LDS for cell_cap + 1 ints
-        for (int c = t; c < nc; c += kCellBlock) s_off[c] = goff[c];
-        __syncthreads();
-        cell_scan_body(s_off, tab, s_wave, p, pair, nc, goff);
-    } else {
-        cell_scan_body(goff, tab, s_wave, p, pair, nc, nullptr);
+        const int bfirst = s_big[1 + 3 * i], bbeg = s_big[2 + 3 * i], bn = s_big[3 + 3 * i];
+        const int bchunks = (bn + kChunk - 1) / kChunk;
+        for (int k = t; k < bchunks; k += kBlock)
+            items[bfirst + k] = make_int2(bbeg + k * kChunk, min(kChunk, bn - k * kChunk) | (k ? kContFlag : 0));
     }
 }
 
@@ -573,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
 // ------------------------------------------------------------------------------------------
 struct SortedWsLayout {
     int nc_cap, it_cap, nsplit;
-    size_t off_part, off_off, off_cellitem, off_itemcnt, off_items, off_entries, off_scratch, total;
+    size_t off_part, off_off, off_cellitem, off_itemcnt, off_meta, off_blocksum, off_items, off_entries, off_scratch, total;
 };
 
 int option_cell_slices();  // 0: automatic (msda_api.hip)
@@ -606,6 +626,8 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     w.off_off = o;      o = align_up(o + pairs * ((size_t)w.nc_cap + 1) * 4, 256);
     w.off_cellitem = o; o = align_up(o + pairs * ((size_t)w.nc_cap + 1) * 4, 256);
     w.off_itemcnt = o;  o = align_up(o + pairs * 4, 256);
+    w.off_meta = o;     o = align_up(o + 256, 256);
+    w.off_blocksum = o; o = align_up(o + pairs * (((size_t)w.nc_cap + kBlock - 1) / kBlock) * 8, 256);
     w.off_items = o;    o = align_up(o + pairs * (size_t)w.it_cap * 8, 256);
     w.off_entries = o;  o = align_up(o + pairs * samples * entry_bytes, 256);
     w.off_scratch = o;  o = align_up(o + pairs * (size_t)w.it_cap * 4 * (size_t)D * acc_bytes, 256);
