@@ -71,7 +71,10 @@ def cpu_baseline(wl, budget_s=20.0):
             break
     med_all = sorted(t_all)[len(t_all) // 2]
     med_fwd = sorted(t_fwd)[len(t_fwd) // 2]
-    torch_cpu = torch_cpu_fallback(wl)
+    try:
+        torch_cpu = torch_cpu_fallback(wl)
+    except Exception as e:  # the extra line must never cost the bench its JSON line
+        torch_cpu = {"error": repr(e)}
     return {
         "value": wl.B * q_sample / med_all,
         "unit": "queries/s",
