@@ -61,7 +61,7 @@ struct Params {
     int *ws_itemcnt;    // [pairs]            work items of the plane
     int *ws_meta;       // [0] = cells of a plane (written by the count pass for the scan kernels)
     int2 *ws_blocksum;  // [pairs][blocks]    per block of kBlock cells: (records, work items)
-    int2 *ws_items;     // [pairs][it_cap]    per work item: (first record, records) — a window of one cell's list
+    int4 *ws_items;     // [pairs][it_cap]    per work item: (first record, records | flags, cell, -) — a window of one cell's list
     void *ws_entries;   // [pairs][Q*L*P]     Entry<acc>: sample records sorted by cell
     void *ws_scratch;   // [pairs][it_cap][4][D] acc-typed partial rows: one per work item and cell corner
     int nc_cap, it_cap;

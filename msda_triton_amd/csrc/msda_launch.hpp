@@ -298,7 +298,7 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
     p.ws_itemcnt = reinterpret_cast<int *>(ws + w.off_itemcnt);
     p.ws_meta = reinterpret_cast<int *>(ws + w.off_meta);
     p.ws_blocksum = reinterpret_cast<int2 *>(ws + w.off_blocksum);
-    p.ws_items = reinterpret_cast<int2 *>(ws + w.off_items);
+    p.ws_items = reinterpret_cast<int4 *>(ws + w.off_items);
     p.ws_entries = ws + w.off_entries;
     p.ws_scratch = ws + w.off_scratch;
     p.nc_cap = w.nc_cap;

@@ -35,6 +35,9 @@ namespace msda {
 constexpr int kChunk = 64;           // entries per work item
 constexpr int kGatherItemBlock = 256; // threads per workgroup of the gather kernel (no block barriers)
 constexpr int kContFlag = 1 << 30;   // work-item record: this window continues the previous item's cell
+constexpr int kLastFlag = 1 << 29;   // work-item record: last window of its cell (kLastFlag without kContFlag: the
+                                     // cell is ONE item, and may share rows with a neighbouring one-item cell)
+constexpr int kCountMask = kLastFlag - 1;
 constexpr int kBigChunks = 16;       // cells with more work items than this have their records written by the whole block
 constexpr int kBigCells = 64;        // ... at most this many per plane (the rest falls back to the owning thread)
 constexpr int kCellBlock = 1024;     // threads of K1 / K2b / K3
@@ -290,7 +293,7 @@ template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_scan
     const int nc = p.ws_meta[0];
     if (blk * kBlock >= nc) return;  // block-uniform
     __shared__ int s_scan[2 * kBlock / kWave];
-    __shared__ int s_big[1 + 3 * kBigCells];  // [0] = count, then (first item, first record, records) of the cells whose
+    __shared__ int s_big[1 + 4 * kBigCells];  // [0] = count, then (first item, first record, records, cell) of the cells whose
                                               // work-item records the whole block writes
     const int t = threadIdx.x;
     if (t == 0) s_big[0] = 0;
@@ -310,7 +313,7 @@ template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_scan
     }
     int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
     int *cellitem = p.ws_cellitem + (size_t)pair * (p.nc_cap + 1);
-    int2 *items = p.ws_items + (size_t)pair * p.it_cap;
+    int4 *items = p.ws_items + (size_t)pair * p.it_cap;
     const int c = blk * kBlock + t;
     const int n = c < nc ? off[c] : 0;
     const int chunks = (n + kChunk - 1) / kChunk;
@@ -324,11 +327,14 @@ template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_scan
         if (chunks > kBigChunks) slot = atomicAdd(&s_big[0], 1);
         if (chunks <= kBigChunks || slot >= kBigCells) {
             for (int k = 0; k < chunks; ++k)
-                items[first + k] = make_int2(beg + k * kChunk, min(kChunk, n - k * kChunk) | (k ? kContFlag : 0));
+                items[first + k] = make_int4(beg + k * kChunk,
+                                             min(kChunk, n - k * kChunk) | (k ? kContFlag : 0) | (k == chunks - 1 ? kLastFlag : 0),
+                                             c, 0);
         } else {
-            s_big[1 + 3 * slot] = first;
-            s_big[2 + 3 * slot] = beg;
-            s_big[3 + 3 * slot] = n;
+            s_big[1 + 4 * slot] = first;
+            s_big[2 + 4 * slot] = beg;
+            s_big[3 + 4 * slot] = n;
+            s_big[4 + 4 * slot] = c;
         }
         if (c == nc - 1) {  // the plane's totals behind the last cell
             off[nc] = beg + n;
@@ -339,10 +345,12 @@ template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_scan
     __syncthreads();
     const int nbig = min(s_big[0], kBigCells);
     for (int i = 0; i < nbig; ++i) {  // hot cells (coarse levels, clustered samples): records written by all threads
-        const int bfirst = s_big[1 + 3 * i], bbeg = s_big[2 + 3 * i], bn = s_big[3 + 3 * i];
+        const int bfirst = s_big[1 + 4 * i], bbeg = s_big[2 + 4 * i], bn = s_big[3 + 4 * i], bcell = s_big[4 + 4 * i];
         const int bchunks = (bn + kChunk - 1) / kChunk;
         for (int k = t; k < bchunks; k += kBlock)
-            items[bfirst + k] = make_int2(bbeg + k * kChunk, min(kChunk, bn - k * kChunk) | (k ? kContFlag : 0));
+            items[bfirst + k] = make_int4(bbeg + k * kChunk,
+                                          min(kChunk, bn - k * kChunk) | (k ? kContFlag : 0) | (k == bchunks - 1 ? kLastFlag : 0),
+                                          bcell, 0);
     }
 }
 
@@ -388,11 +396,20 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
 
     int start = 0, count = 0;  // valid items: 1 <= count <= kChunk
     bool follower = false;     // this item continues the cell of the previous item of the same workgroup
+    // One-item cells that are neighbours in x AND in this workgroup share rows: the right one takes over the left
+    // one's right-hand corners (its corner 01 is the neighbour's 00, its 11 the neighbour's 10), so a cell then
+    // leaves two rows instead of four.  The finish kernel derives the same predicate from the item indices.
+    bool give_right = false, take_left = false;
     if (valid) {
-        const int2 rec = p.ws_items[(size_t)pair * p.it_cap + item];
+        const int4 *recs = p.ws_items + (size_t)pair * p.it_cap;
+        const int4 rec = recs[item];
+        const int4 rec_l = recs[max(item - 1, 0)], rec_r = recs[min(item + 1, nitems - 1)];  // same round trip
         start = rec.x;
-        count = rec.y & (kContFlag - 1);
+        count = rec.y & kCountMask;
         follower = (rec.y & kContFlag) != 0 && unit != 0;
+        auto single = [](const int4 &r) { return (r.y & (kContFlag | kLastFlag)) == kLastFlag; };
+        give_right = unit + 1 < NU && item + 1 < nitems && single(rec) && single(rec_r) && rec_r.z == rec.z + 1;
+        take_left = unit > 0 && single(rec_l) && single(rec) && rec.z == rec_l.z + 1;
     }
 
     // record v of the window -> (byte offset of the query's grad_out row inside the plane, four corner weights).
@@ -457,13 +474,15 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
         // kernel one row per NU items, not one per item.
         if (cc > 0) __syncthreads();  // the previous channel chunk's rows have been consumed
         if (j == 0) s_cont[unit] = follower ? 1 : 0;
-        if (follower) {
+        if (follower || give_right) {  // (a one-item cell is never a follower: the two cases are disjoint)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                Pack<A, VEC> o;
+                if (follower || (k & 1)) {
+                    Pack<A, VEC> o;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) o.v[v] = acc[k][v];
-                *reinterpret_cast<Pack<A, VEC> *>(&s_rows[((unit * 4 + k) * G + j) * VEC]) = o;
+                    for (int v = 0; v < VEC; ++v) o.v[v] = acc[k][v];
+                    *reinterpret_cast<Pack<A, VEC> *>(&s_rows[((unit * 4 + k) * G + j) * VEC]) = o;
+                }
             }
         }
         __syncthreads();
@@ -476,9 +495,19 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
                     for (int v = 0; v < VEC; ++v) acc[k][v] += r.v[v];
                 }
             }
+            if (take_left) {  // the left neighbour's corners 01 / 11 are this cell's 00 / 10
+#pragma unroll
+                for (int k = 0; k < 4; k += 2) {
+                    const Pack<A, VEC> r =
+                        *reinterpret_cast<const Pack<A, VEC> *>(&s_rows[(((unit - 1) * 4 + k + 1) * G + j) * VEC]);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[k][v] += r.v[v];
+                }
+            }
             if (lane_ok) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
+                    if ((k & 1) && give_right) continue;  // taken over by the right neighbour
                     Pack<A, VEC> o;
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) o.v[v] = acc[k][v];
@@ -545,6 +574,11 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
     const rsrc_t rs = make_rsrc(src, (uint32_t)(use_rsrc ? plane_bytes : 0));
     const uint32_t row_bytes = (uint32_t)p.D * (uint32_t)sizeof(A);
     const bool simple = use_rsrc && (t1 - t0) <= 1 && (t2 - t1) <= 1 && (u1 - u0) <= 1 && (u2 - u1) <= 1;
+    // Two one-item cells that are neighbours in x and sit in the same gather workgroup share rows (see the gather
+    // kernel): the left cell's corners 01 / 11 are already inside the right cell's rows 00 / 10 and were not stored.
+    constexpr int NUG = kGatherItemBlock / G;
+    const bool comb_top = (u1 - u0) == 1 && (u2 - u1) == 1 && (u0 % NUG) != NUG - 1;  // cells (x-1, y) and (x, y)
+    const bool comb_bot = (t1 - t0) == 1 && (t2 - t1) == 1 && (t0 % NUG) != NUG - 1;  // cells (x-1, y-1) and (x, y-1)
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
     for (int cc = 0; cc < nchan_chunks; ++cc) {
         const int c0 = (cc * G + j) * VEC;
@@ -553,9 +587,9 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
         if (simple) {  // at most one work item per cell (fine levels): four independent loads
             const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(A);
             const uint32_t o0 = u2 > u1 ? ((uint32_t)u1 * 4 + 0) * row_bytes + lane_off : 0x80000000u;
-            const uint32_t o1 = u1 > u0 ? ((uint32_t)u0 * 4 + 1) * row_bytes + lane_off : 0x80000000u;
+            const uint32_t o1 = (u1 > u0 && !comb_top) ? ((uint32_t)u0 * 4 + 1) * row_bytes + lane_off : 0x80000000u;
             const uint32_t o2 = t2 > t1 ? ((uint32_t)t1 * 4 + 2) * row_bytes + lane_off : 0x80000000u;
-            const uint32_t o3 = t1 > t0 ? ((uint32_t)t0 * 4 + 3) * row_bytes + lane_off : 0x80000000u;
+            const uint32_t o3 = (t1 > t0 && !comb_bot) ? ((uint32_t)t0 * 4 + 3) * row_bytes + lane_off : 0x80000000u;
             const Pack<A, VEC> r0 = load_acc_pack<A, VEC>(rs, o0);
             const Pack<A, VEC> r1 = load_acc_pack<A, VEC>(rs, o1);
             const Pack<A, VEC> r2 = load_acc_pack<A, VEC>(rs, o2);
@@ -566,7 +600,6 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = (A)0;
             // rows of a cell: its first item, then the first item of every further gather workgroup it extends into
-            constexpr int NUG = kGatherItemBlock / G;
             auto add = [&](int first, int last, int corner) {
                 for (int it = first; it < last; it = (it / NUG + 1) * NUG) {
                     const Pack<A, VEC> r =
@@ -576,9 +609,9 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
                 }
             };
             add(u1, u2, 0);
-            add(u0, u1, 1);
+            if (!comb_top) add(u0, u1, 1);
             add(t1, t2, 2);
-            add(t0, t1, 3);
+            if (!comb_bot) add(t0, t1, 3);
         }
         Pack<T, VEC> o;
 #pragma unroll
@@ -628,7 +661,7 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     w.off_itemcnt = o;  o = align_up(o + pairs * 4, 256);
     w.off_meta = o;     o = align_up(o + 256, 256);
     w.off_blocksum = o; o = align_up(o + pairs * (((size_t)w.nc_cap + kBlock - 1) / kBlock) * 8, 256);
-    w.off_items = o;    o = align_up(o + pairs * (size_t)w.it_cap * 8, 256);
+    w.off_items = o;    o = align_up(o + pairs * (size_t)w.it_cap * 16, 256);
     w.off_entries = o;  o = align_up(o + pairs * samples * entry_bytes, 256);
     w.off_scratch = o;  o = align_up(o + pairs * (size_t)w.it_cap * 4 * (size_t)D * acc_bytes, 256);
     w.total = o;
