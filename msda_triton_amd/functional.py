@@ -60,10 +60,13 @@ def _dims(img: torch.Tensor, sampling_points: torch.Tensor, attention_weights: t
 def _shapes_i64(img_shapes: torch.Tensor) -> torch.Tensor:
     if img_shapes.dtype not in (torch.int64, torch.int32, torch.int16, torch.int8, torch.uint8):
         raise ValueError(f"`img_shapes` should be an integer tensor, but got {img_shapes.dtype}.")
+    if img_shapes.dtype == torch.int64 and img_shapes.is_contiguous():
+        return img_shapes
     return img_shapes.to(torch.int64).contiguous()  # stays on the device: no host sync
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_WS_BYTES: dict = {}  # (B, I, H, D, Q, L, P, elem) -> msda_bwd_workspace_bytes (a pure function of its arguments)
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -186,7 +189,10 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
         fn = getattr(lib, f"msda_bwd_{suf}")
         ws, ws_bytes = None, 0
         if want_value:  # scratch for the inverted index; the caching allocator makes this cheap
-            ws_bytes = int(lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, img.element_size()))
+            key = (B, I, H, D, Q, L, P, img.element_size())
+            ws_bytes = _WS_BYTES.get(key)
+            if ws_bytes is None:
+                ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes(*key))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
         def call(value_part: bool, sample_part: bool):
