@@ -102,8 +102,13 @@ def check(rc: int, what: str) -> None:
         raise MSDALibraryError(f"{what}: HIP error {rc}: {msg}")
 
 
+OPTION_EPOCH = 0  # bumped by set_option: callers that cache option-dependent values (workspace sizes) key on it
+
+
 def set_option(key: str, value: int) -> None:
+    global OPTION_EPOCH
     check(load().msda_set_option(key.encode(), int(value)), f"msda_set_option({key})")
+    OPTION_EPOCH += 1
 
 
 def get_option(key: str) -> int:

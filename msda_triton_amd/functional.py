@@ -66,7 +66,7 @@ def _shapes_i64(img_shapes: torch.Tensor) -> torch.Tensor:
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-_WS_BYTES: dict = {}  # (B, I, H, D, Q, L, P, elem) -> msda_bwd_workspace_bytes (a pure function of its arguments)
+_WS_BYTES: dict = {}  # (B, I, H, D, Q, L, P, elem, option epoch) -> msda_bwd_workspace_bytes
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -189,10 +189,10 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
         fn = getattr(lib, f"msda_bwd_{suf}")
         ws, ws_bytes = None, 0
         if want_value:  # scratch for the inverted index; the caching allocator makes this cheap
-            key = (B, I, H, D, Q, L, P, img.element_size())
+            key = (B, I, H, D, Q, L, P, img.element_size(), _lib.OPTION_EPOCH)
             ws_bytes = _WS_BYTES.get(key)
             if ws_bytes is None:
-                ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes(*key))
+                ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes(*key[:8]))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
         def call(value_part: bool, sample_part: bool):
