@@ -502,17 +502,19 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
     bool sorted = option_value_path() != 1 && workspace != nullptr && aligned_to(workspace, 256) &&
                   (uint64_t)workspace_bytes >= sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A)).total;
     if (sorted && option_value_path() == 0) {
-        // Small problems: the sorted pipeline's six launches cost ~50 us before any work is done, while the
-        // LDS-tile kernel is one launch whose time grows with (workgroup rounds) x (samples per plane).
-        // Measured on MI355X (c1/c2/c4 sweeps): tiles ~2.2 ns per plane-sample and round, sorted ~35 ps per sample.
+        // Small problems: the sorted pipeline's six launches cost ~45 us before any work is done, while the
+        // LDS-tile kernel is one launch whose time grows with (workgroups / 256 CUs) x (samples per plane).
+        // Fitted on MI355X (c1 / c2 at Q = 500..2000 / c4): tiles 20 us + 1.6 ns per plane-sample and chip-load,
+        // sorted 42 us + 24 ps per sample.
         const size_t room = kValueLdsBudget - sizeof(LevelTab);
         int ch = 0;
         for (int c : {4, 2, 1})
             if (!ch && (D % c) == 0 && (size_t)I * c * sizeof(TileAcc) <= room) ch = c;
         if (ch) {
             const double s_plane = (double)Q * (double)(L * P), planes = (double)(B * H);
-            const double rounds = (double)((int64_t)(planes * (double)(D / ch) + 255) / 256);
-            const double t_tile = rounds * s_plane * 2.2e-3, t_sorted = 50.0 + planes * s_plane * 3.5e-5;
+            double load = planes * (double)(D / ch) / 256.0;
+            if (load < 0.25) load = 0.25;
+            const double t_tile = 20.0 + load * s_plane * 1.6e-3, t_sorted = 42.0 + planes * s_plane * 2.4e-5;
             if (t_tile < t_sorted) sorted = false;
         }
     }
