@@ -20,21 +20,33 @@ constexpr uint32_t kMaskedOffset = 0x80000000u;  // >= any buffer size we accept
 template <typename T> struct Traits;
 template <> struct Traits<float> {
     using acc = float;
+    static constexpr bool kDot2 = false;
     static __device__ __forceinline__ float to_acc(float v) { return v; }
     static __device__ __forceinline__ float from_acc(float v) { return v; }
 };
 template <> struct Traits<double> {
     using acc = double;
+    static constexpr bool kDot2 = false;
     static __device__ __forceinline__ double to_acc(double v) { return v; }
     static __device__ __forceinline__ double from_acc(double v) { return v; }
 };
 template <> struct Traits<_Float16> {
     using acc = float;
+    // c + a.x * b.x + a.y * b.y in one instruction (v_dot2c_f32_f16): dot products of two 16-bit rows need no widening
+    static constexpr bool kDot2 = true;
+    typedef _Float16 pair_t __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ float dot2(pair_t a, pair_t b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
     static __device__ __forceinline__ float to_acc(_Float16 v) { return (float)v; }
     static __device__ __forceinline__ _Float16 from_acc(float v) { return (_Float16)v; }
 };
 template <> struct Traits<__bf16> {
     using acc = float;
+    static constexpr bool kDot2 = true;  // v_dot2c_f32_bf16
+    typedef __bf16 pair_t __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ float dot2(pair_t a, pair_t b, float c)
+    {
+        return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false);
+    }
     static __device__ __forceinline__ float to_acc(__bf16 v) { return (float)v; }
     static __device__ __forceinline__ __bf16 from_acc(float v) { return (__bf16)v; }  // v_cvt_pk_bf16_f32, RNE
 };

@@ -571,15 +571,54 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                     const int c0 = j * VEC;
                     const bool lane_in = c0 < p.D;
                     const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
+                    Pack<T, VEC> gp;
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) gp.v[i] = TR::from_acc((A)0);
+                    if (lane_in) gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
+                    if constexpr (TR::kDot2 && !STAGE && (VEC % 2) == 0) {
+                        // 16-bit rows: the four dot products with grad_out straight from the packed pairs
+                        // (v_dot2c_f32_f16 / _bf16: two multiply-adds per instruction, no widening)
+                        using P2 = typename TR::pair_t;
+                        struct Pairs {
+                            P2 p[VEC / 2];
+                        };
+                        const Pairs gq = __builtin_bit_cast(Pairs, gp);
+                        for (int sb = 0; sb < sc; sb += UB) {
+                            uint4 o[UB];
+                            Rec4<A> r[UB];
+                            Pairs v[UB][4];
+#pragma unroll
+                            for (int u = 0; u < UB; ++u) {
+                                const int s = min(sb + u, sc - 1);  // tail: recompute the last sample, its store is skipped
+                                o[u] = uo[s];
+                                r[u] = up[s];
+                            }
+                            using RL = RawLoad<sizeof(T) * VEC>;
+                            const uint32_t lo = lane_in ? lane_off : 0u;
+#pragma unroll
+                            for (int u = 0; u < UB; ++u) {
+                                v[u][0] = __builtin_bit_cast(Pairs, RL::load(rs, o[u].x + lo));
+                                v[u][1] = __builtin_bit_cast(Pairs, RL::load(rs, o[u].y + lo));
+                                v[u][2] = __builtin_bit_cast(Pairs, RL::load(rs, o[u].z + lo));
+                                v[u][3] = __builtin_bit_cast(Pairs, RL::load(rs, o[u].w + lo));
+                            }
+#pragma unroll
+                            for (int u = 0; u < UB; ++u) {
+                                A d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+                                for (int i = 0; i < VEC / 2; ++i) {
+                                    d0 = TR::dot2(gq.p[i], v[u][0].p[i], d0);
+                                    d1 = TR::dot2(gq.p[i], v[u][1].p[i], d1);
+                                    d2 = TR::dot2(gq.p[i], v[u][2].p[i], d2);
+                                    d3 = TR::dot2(gq.p[i], v[u][3].p[i], d3);
+                                }
+                                if (sb + u < sc) finish(sb + u, r[u], d0, d1, d2, d3);  // uniform
+                            }
+                        }
+                    } else {
                     A g[VEC];
-                    {
-                        Pack<T, VEC> gp;
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) gp.v[i] = TR::from_acc((A)0);
-                        if (lane_in) gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) g[i] = TR::to_acc(gp.v[i]);
-                    }
+                    for (int i = 0; i < VEC; ++i) g[i] = TR::to_acc(gp.v[i]);
                     for (int sb = 0; sb < sc; sb += UB) {
                         uint4 o[UB];
                         Rec4<A> r[UB];
@@ -619,6 +658,7 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                             }
                             if (sb + u < sc) finish(sb + u, r[u], d0, d1, d2, d3);  // uniform
                         }
+                    }
                     }
                 } else {
                     for (int s = 0; s < sc; ++s) {
