@@ -88,7 +88,7 @@ extern "C" {
 
 #define MSDA_ERR_BAD_ARG (-1)      /* null pointer, negative size, unknown padding mode */
 #define MSDA_ERR_TOO_MANY_LEVELS (-2) /* L > MSDA_MAX_LEVELS */
-#define MSDA_ERR_TOO_LARGE (-3)    /* I*H*D*sizeof(dtype) >= 2^31 bytes per batch element */
+#define MSDA_ERR_TOO_LARGE (-3)    /* a per-batch-element extent does not fit the 32-bit plane offsets: I*H*D*sizeof, Q*H*D*sizeof or Q*H*L*P*2 >= 2^31, or I, Q >= 2^24 */
 #define MSDA_ERR_MISALIGNED (-4)   /* a buffer is not aligned to its element size */
 #define MSDA_ERR_UNSUPPORTED (-5)  /* valid arguments this entry point cannot serve (use the unfused call) */
 

@@ -56,6 +56,9 @@ __device__ __forceinline__ float fma_t(float a, float b, float c) { return __bui
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 // low 32 bits of the product of two values < 2^24 (v_mul_u32_u24)
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+// the same for non-negative ints below 2^24 (indices: the host checks Q, I < 2^24): v_mul_u32_u24 runs at full rate,
+// v_mul_lo_u32 at a quarter
+__device__ __forceinline__ int imul24(int a, int b) { return (int)__umul24((uint32_t)a, (uint32_t)b); }
 __device__ __forceinline__ float floor_t(float a) { return __builtin_floorf(a); }
 __device__ __forceinline__ double floor_t(double a) { return __builtin_floor(a); }
 __device__ __forceinline__ float fmin_t(float a, float b) { return __builtin_fminf(a, b); }

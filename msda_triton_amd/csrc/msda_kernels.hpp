@@ -256,11 +256,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void
                     // logits (DPP-reduced) and leave them in the unit's padding slot ----
                     for (int f = lane; f < UPW * sc; f += kWave) {
                         const int fu = div_small(f, sc, inv_sc);
-                        const int sl = f - fu * sc;
+                        const int sl = f - imul24(fu, sc);
                         const int fq = wq0 + fu;
                         if (fq < p.Q) {
                             const int l = div_small(sl, p.P, inv_P);
-                            const int sidx = fq * HLP + sl;
+                            const int sidx = imul24(fq, HLP) + sl;
                             const A ox = TR::to_acc(loc[3 * sidx]), oy = TR::to_acc(loc[3 * sidx + 1]);
                             const A lg = TR::to_acc(loc[3 * sidx + 2]);
                             const T *r = refp + (size_t)fq * p.ref_dim;
@@ -275,20 +275,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void
                                 w.v[2] = TR::to_acc(r[1]) + oy * TR::to_acc(r[3]) / (A)(2 * p.P);
                             }
                             w.v[3] = (A)0;
-                            w_rec[fu * scp + sl] = w;
+                            w_rec[imul24(fu, scp) + sl] = w;
                         }
                     }
                     wave_lds_sync();
                     if (unit_ok) {
                         A mx = -__builtin_huge_val();
-                        for (int sl = j; sl < sc; sl += G) mx = fmax_t(mx, w_rec[wunit * scp + sl].v[0]);
+                        for (int sl = j; sl < sc; sl += G) mx = fmax_t(mx, w_rec[imul24(wunit, scp) + sl].v[0]);
                         mx = group_max<G>(mx);
                         A sum = (A)0;
-                        for (int sl = j; sl < sc; sl += G) sum += exp_t(w_rec[wunit * scp + sl].v[0] - mx);
+                        for (int sl = j; sl < sc; sl += G) sum += exp_t(w_rec[imul24(wunit, scp) + sl].v[0] - mx);
                         sum = group_sum<G>(sum);
                         if (j == 0) {
-                            w_rec[wunit * scp + sc].v[0] = mx;
-                            w_rec[wunit * scp + sc].v[1] = (A)1 / sum;
+                            w_rec[imul24(wunit, scp) + sc].v[0] = mx;
+                            w_rec[imul24(wunit, scp) + sc].v[1] = (A)1 / sum;
                         }
                     }
                     wave_lds_sync();
@@ -296,14 +296,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void
                 // ---- phase 1: the wave's UPW * sc samples, one per lane and trip ----
                 for (int f = lane; f < UPW * sc; f += kWave) {
                     const int fu = div_small(f, sc, inv_sc);
-                    const int sl = s0 + (f - fu * sc);
+                    const int sl = s0 + (f - imul24(fu, sc));
                     const int fq = wq0 + fu;
                     if (fq < p.Q) {
                         const int l = div_small(sl, p.P, inv_P);
-                        const int sidx = fq * HLP + sl;
+                        const int sidx = imul24(fq, HLP) + sl;
                         A sx, sy, a;
                         if constexpr (FUSED) {  // everything was parked by phase 0
-                            const Rec4<A> pk = w_rec[fu * scp + (sl - s0)], un = w_rec[fu * scp + sc];
+                            const Rec4<A> pk = w_rec[imul24(fu, scp) + (sl - s0)], un = w_rec[imul24(fu, scp) + sc];
                             sx = pk.v[1];
                             sy = pk.v[2];
                             a = exp_t(pk.v[0] - un.v[0]) * un.v[1];
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void
                         w.v[1] = a * (wy0 * t.dx);
                         w.v[2] = a * (t.dy * wx0);
                         w.v[3] = a * (t.dy * t.dx);
-                        const int rslot = fu * scp + (sl - s0);
+                        const int rslot = imul24(fu, scp) + (sl - s0);
                         if constexpr (STAGE)
                             w_off[rslot] = record_offsets(t, lds.plan->off[l], lds.plan->zero_off, row_b, tab->start[l], row_bytes);
                         else
@@ -333,8 +333,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void
                 wave_lds_sync();
                 // ---- phase 2: gather + blend, one level (run of samples) at a time ----
                 if (lane_ok) {
-                    const uint4 *uo = w_off + wunit * scp;
-                    const Rec4<A> *uw = w_rec + wunit * scp;
+                    const uint4 *uo = w_off + imul24(wunit, scp);
+                    const Rec4<A> *uw = w_rec + imul24(wunit, scp);
                     int s = 0;
                     int l = div_small(s0, p.P, inv_P);  // level of the first sample; later runs are the next levels
                     for (; s < sc; ++l) {
@@ -458,11 +458,11 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                 // lanes leave max and 1 / sum(exp) of its logits in the padding slot ----
                 for (int f = lane; f < UPW * sc; f += kWave) {
                     const int fu = div_small(f, sc, inv_sc);
-                    const int sl = f - fu * sc;
+                    const int sl = f - imul24(fu, sc);
                     const int fq = wq0 + fu;
                     if (fq < p.Q) {
                         const int l = div_small(sl, p.P, inv_P);
-                        const int sidx = fq * HLP + sl;
+                        const int sidx = imul24(fq, HLP) + sl;
                         const A ox = TR::to_acc(loc[3 * sidx]), oy = TR::to_acc(loc[3 * sidx + 1]);
                         const A lg = TR::to_acc(loc[3 * sidx + 2]);
                         const T *r = refp + (size_t)fq * p.ref_dim;
@@ -476,22 +476,22 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                             w.v[2] = TR::to_acc(r[1]) + oy * TR::to_acc(r[3]) * half_inv_P;
                         }
                         w.v[3] = (A)0;
-                        w_rec[fu * scp + sl] = w;
-                        w_ox[fu * scp + sl] = ox;
-                        w_oy[fu * scp + sl] = oy;
+                        w_rec[imul24(fu, scp) + sl] = w;
+                        w_ox[imul24(fu, scp) + sl] = ox;
+                        w_oy[imul24(fu, scp) + sl] = oy;
                     }
                 }
                 wave_lds_sync();
                 if (unit_ok) {
                     A mx = -__builtin_huge_val();
-                    for (int sl = j; sl < sc; sl += G) mx = fmax_t(mx, w_rec[wunit * scp + sl].v[0]);
+                    for (int sl = j; sl < sc; sl += G) mx = fmax_t(mx, w_rec[imul24(wunit, scp) + sl].v[0]);
                     mx = group_max<G>(mx);
                     A sum = (A)0;
-                    for (int sl = j; sl < sc; sl += G) sum += exp_t(w_rec[wunit * scp + sl].v[0] - mx);
+                    for (int sl = j; sl < sc; sl += G) sum += exp_t(w_rec[imul24(wunit, scp) + sl].v[0] - mx);
                     sum = group_sum<G>(sum);
                     if (j == 0) {
-                        w_rec[wunit * scp + sc].v[0] = mx;
-                        w_rec[wunit * scp + sc].v[1] = (A)1 / sum;
+                        w_rec[imul24(wunit, scp) + sc].v[0] = mx;
+                        w_rec[imul24(wunit, scp) + sc].v[1] = (A)1 / sum;
                     }
                 }
                 wave_lds_sync();
@@ -499,17 +499,17 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
             // ---- phase 1 ----
             for (int f = lane; f < UPW * sc; f += kWave) {
                 const int fu = div_small(f, sc, inv_sc);
-                const int sl = s0 + (f - fu * sc);
+                const int sl = s0 + (f - imul24(fu, sc));
                 const int fq = wq0 + fu;
                 if (fq < p.Q) {
                     const int l = div_small(sl, p.P, inv_P);
-                    const int sidx = fq * HLP + sl;
+                    const int sidx = imul24(fq, HLP) + sl;
                     const int lh = tab->h[l], lw = tab->w[l];
                     A px, py, a;
                     if constexpr (FUSED) {
                         // everything was parked by phase 0
-                        const int rs_ = fu * scp + (sl - s0);
-                        const Rec4<A> pk = w_rec[rs_], un = w_rec[fu * scp + sc];
+                        const int rs_ = imul24(fu, scp) + (sl - s0);
+                        const Rec4<A> pk = w_rec[rs_], un = w_rec[imul24(fu, scp) + sc];
                         px = pk.v[1];
                         py = pk.v[2];
                         a = exp_t(pk.v[0] - un.v[0]) * un.v[1];
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                     r.v[1] = t.dy;
                     r.v[2] = t.gx_on ? a * sx : (A)0;
                     r.v[3] = t.gy_on ? a * sy : (A)0;
-                    const int rslot = fu * scp + (sl - s0);
+                    const int rslot = imul24(fu, scp) + (sl - s0);
                     if constexpr (STAGE)
                         w_off[rslot] = record_offsets(t, lds.plan->off[l], lds.plan->zero_off, row_b, tab->start[l], row_bytes);
                     else
@@ -543,8 +543,8 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
             A f_dot = (A)0, f_gx = (A)0, f_gy = (A)0, f_gw = (A)0, f_gh = (A)0;
             // ---- phase 2: four dot products with grad_out per sample, reduced over the unit ----
             if (unit_ok) {  // idle lanes of a live unit still join the DPP sums
-                const uint4 *uo = w_off + wunit * scp;
-                Rec4<A> *up = w_rec + wunit * scp;
+                const uint4 *uo = w_off + imul24(wunit, scp);
+                Rec4<A> *up = w_rec + imul24(wunit, scp);
                 const T *go_row = static_cast<const T *>(p.grad_out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D;
                 // one sample's epilogue: combine the four dot products, reduce over the unit, park the result
                 auto finish = [&](int s, const Rec4<A> &r, A d0, A d1, A d2, A d3) {
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                 wave_lds_sync();
                 if (unit_ok) {
                     for (int sl = j; sl < sc; sl += G) {
-                        const int rs_ = wunit * scp + sl;
+                        const int rs_ = imul24(wunit, scp) + sl;
                         const Rec4<A> res = w_rec[rs_];
                         f_dot = fma_t(w_a[rs_], res.v[0], f_dot);
                         f_gx += res.v[1];
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                     }
                 }
                 if (unit_ok && j == 0) {
-                    w_a[wunit * scp + sc] = f_dot;  // the unit's padding slot
+                    w_a[imul24(wunit, scp) + sc] = f_dot;  // the unit's padding slot
                     // per-head partial of grad_reference_points; the caller sums over the heads
                     T *gr = static_cast<T *>(p.grad_attn) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.ref_dim;
                     gr[0] = TR::from_acc(f_gx);
@@ -735,16 +735,16 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
             // ---- phase 3: coalesced write-out, one sample per lane and trip ----
             for (int f = lane; f < UPW * sc; f += kWave) {
                 const int fu = div_small(f, sc, inv_sc);
-                const int sl = s0 + (f - fu * sc);
+                const int sl = s0 + (f - imul24(fu, sc));
                 const int fq = wq0 + fu;
                 if (fq < p.Q) {
-                    const int sidx = fq * HLP + sl;
-                    const Rec4<A> res = w_rec[fu * scp + (sl - s0)];
+                    const int sidx = imul24(fq, HLP) + sl;
+                    const Rec4<A> res = w_rec[imul24(fu, scp) + (sl - s0)];
                     if constexpr (FUSED) {
                         // chain rule through the prologue: softmax (logit), offset scaling (dx, dy)
                         const int l = div_small(sl, p.P, inv_P);
-                        const int rs_ = fu * scp + (sl - s0);
-                        const A a = w_a[rs_], dot = w_a[fu * scp + sc];
+                        const int rs_ = imul24(fu, scp) + (sl - s0);
+                        const A a = w_a[rs_], dot = w_a[imul24(fu, scp) + sc];
                         const T *r = refp + (size_t)fq * p.ref_dim;
                         A kx, ky;
                         if (p.ref_dim == 2) {

@@ -60,7 +60,7 @@ inline int check_common(const Dims &d, int padding_mode, const void *const *ptrs
     const int64_t lim = (int64_t)1 << 31;
     if (d.I * d.H * d.D * (int64_t)sizeof(T) >= lim || d.B >= lim || d.Q >= lim || d.L * d.P >= (1 << 22) ||
         d.B * d.H >= (1 << 28) || d.Q * d.H * d.L * d.P * 2 >= lim || d.Q * d.H * d.D * (int64_t)sizeof(T) >= lim || d.I >= (1 << 24) ||
-        d.H * d.D * (int64_t)sizeof(T) >= (1 << 24)) {
+        d.Q >= (1 << 24) || d.H * d.L * d.P >= (1 << 24) || d.H * d.D * (int64_t)sizeof(T) >= (1 << 24)) {
         set_error("tensor too large for 32-bit plane offsets (I*H*D*sizeof = %lld bytes)",
                   (long long)(d.I * d.H * d.D * (int64_t)sizeof(T)));
         return MSDA_ERR_TOO_LARGE;
