@@ -1,0 +1,120 @@
+// msda_torch_ext.cpp — optional thin PyTorch binding over the C ABI (include/msda_hip.h).
+//
+// The product boundary is the C ABI; Python reaches it through ctypes (msda_triton_amd/_lib.py).  For
+// Grounding-DINO-sized calls (B*Q ~ 10^3) the kernels take ~60 us while Python's autograd glue, ctypes
+// marshalling and the engine's hop into a Python backward take ~100 us per forward+backward.  This extension is
+// the same glue in C++: one torch::autograd::Function whose forward and backward call msda_fwd_<dtype> /
+// msda_bwd_<dtype> directly.  It contains no kernels and no numerics; the argument validation stays in Python
+// (msda_triton_amd/functional.py) and the same tests cover both routes.
+// Reference counterpart: _TritonMultiscaleDeformableAttentionFunction, src/msda_triton/frontend.py:108-142.
+#include <torch/extension.h>
+
+#include <c10/hip/HIPStream.h>
+
+#include "../../include/msda_hip.h"
+
+namespace {
+
+using FwdFn = int (*)(const void *, const int64_t *, const void *, const void *, void *, int64_t, int64_t, int64_t,
+                      int64_t, int64_t, int64_t, int64_t, int, int, void *);
+using BwdFn = int (*)(const void *, const void *, const int64_t *, const void *, const void *, void *, void *, void *,
+                      int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, void *, int64_t, void *);
+
+struct Fns {
+    FwdFn fwd;
+    BwdFn bwd;
+};
+
+Fns fns_for(at::ScalarType t)
+{
+    switch (t) {
+    case at::kFloat: return {msda_fwd_f32, msda_bwd_f32};
+    case at::kHalf: return {msda_fwd_f16, msda_bwd_f16};
+    case at::kBFloat16: return {msda_fwd_bf16, msda_bwd_bf16};
+    case at::kDouble: return {msda_fwd_f64, msda_bwd_f64};
+    default: TORCH_CHECK_VALUE(false, "unsupported dtype ", t);
+    }
+}
+
+void check_rc(int rc, const char *what)
+{
+    if (rc == 0) return;
+    TORCH_CHECK_VALUE(rc > 0, what, ": rejected arguments (", rc, "): ", msda_last_error());
+    TORCH_CHECK(false, what, ": HIP error ", rc, ": ", msda_last_error());
+}
+
+void *current_stream(const at::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+class MSDAFunction : public torch::autograd::Function<MSDAFunction> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &img_, const at::Tensor &shapes_,
+                              const at::Tensor &pts_, const at::Tensor &att_, int64_t padding_mode, bool align_corners)
+    {
+        const at::Tensor img = img_.contiguous(), pts = pts_.contiguous(), att = att_.contiguous();
+        const at::Tensor shapes = shapes_.to(at::kLong).contiguous();  // stays on the device
+        const int64_t B = img.size(0), I = img.size(1), H = img.size(2), D = img.size(3);
+        const int64_t Q = pts.size(1), L = pts.size(3), P = pts.size(4);
+        at::Tensor out = at::empty({B, Q, H, D}, img.options());
+        const c10::DeviceGuard guard(img.device());
+        check_rc(fns_for(img.scalar_type())
+                     .fwd(img.data_ptr(), shapes.data_ptr<int64_t>(), pts.data_ptr(), att.data_ptr(), out.data_ptr(), B, I,
+                          H, D, Q, L, P, (int)padding_mode, align_corners ? 1 : 0, current_stream(img)),
+                 "msda_fwd");
+        ctx->save_for_backward({img, shapes, pts, att});
+        ctx->saved_data["padding_mode"] = padding_mode;
+        ctx->saved_data["align_corners"] = align_corners;
+        return out;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx,
+                                                   torch::autograd::variable_list grads)
+    {
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor &img = saved[0], &shapes = saved[1], &pts = saved[2], &att = saved[3];
+        const int padding_mode = (int)ctx->saved_data["padding_mode"].toInt();
+        const bool align_corners = ctx->saved_data["align_corners"].toBool();
+        at::Tensor gout = grads[0].contiguous();
+        if (gout.scalar_type() != img.scalar_type()) gout = gout.to(img.scalar_type());
+        const bool want_value = ctx->needs_input_grad(0);
+        const bool want_sample = ctx->needs_input_grad(2) || ctx->needs_input_grad(3);
+        const int64_t B = img.size(0), I = img.size(1), H = img.size(2), D = img.size(3);
+        const int64_t Q = pts.size(1), L = pts.size(3), P = pts.size(4);
+        at::Tensor g_img, g_pts, g_att, ws;
+        int64_t ws_bytes = 0;
+        if (want_value) {
+            g_img = at::empty_like(img);
+            ws_bytes = msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, (int)img.element_size());
+            ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));  // scratch: no initialisation needed
+        }
+        if (want_sample) {
+            g_pts = at::empty_like(pts);
+            g_att = at::empty_like(att);
+        }
+        if (want_value || want_sample) {
+            const c10::DeviceGuard guard(img.device());
+            check_rc(fns_for(img.scalar_type())
+                         .bwd(gout.data_ptr(), img.data_ptr(), shapes.data_ptr<int64_t>(), pts.data_ptr(), att.data_ptr(),
+                              want_value ? g_img.data_ptr() : nullptr, want_sample ? g_pts.data_ptr() : nullptr,
+                              want_sample ? g_att.data_ptr() : nullptr, B, I, H, D, Q, L, P, padding_mode,
+                              align_corners ? 1 : 0, want_value ? ws.data_ptr() : nullptr, ws_bytes, current_stream(img)),
+                     "msda_bwd");
+        }
+        return {g_img, at::Tensor(), ctx->needs_input_grad(2) ? g_pts : at::Tensor(),
+                ctx->needs_input_grad(3) ? g_att : at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
+at::Tensor msda(const at::Tensor &img, const at::Tensor &shapes, const at::Tensor &pts, const at::Tensor &att,
+                int64_t padding_mode, bool align_corners)
+{
+    return MSDAFunction::apply(img, shapes, pts, att, padding_mode, align_corners);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "C++ autograd glue over libmsda_hip.so (same C ABI as the ctypes route)";
+    m.def("msda", &msda, "multi-scale deformable attention (forward; differentiable)");
+    m.def("abi_version", []() { return msda_abi_version(); });
+}

@@ -23,7 +23,7 @@ import torch
 from torch.amp import custom_bwd, custom_fwd
 from torch.autograd.function import Function, once_differentiable
 
-from . import _lib
+from . import _ext, _lib
 
 _SUFFIX = {
     torch.float32: "f32",
@@ -269,6 +269,15 @@ def hip_multiscale_deformable_attention(
         from .compile_op import compiled_multiscale_deformable_attention
         return compiled_multiscale_deformable_attention(
             img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners)
+    # Optional C++ autograd glue over the same C ABI (csrc/msda_torch_ext.cpp): same kernels, a fraction of the host
+    # time per call.  The Python Function below serves autocast (fp32 casting), per-kernel timing and every
+    # installation where the binding was not built.
+    ext = _ext.load()
+    if ext is not None and KernelTimer.active is None and not torch.is_autocast_enabled():
+        _dims(img, sampling_points, attention_weights, img_shapes)
+        _shapes_i64(img_shapes)
+        return ext.msda(img, img_shapes, sampling_points, attention_weights, _padding_code(padding_mode),
+                        bool(align_corners))
     return _HipMultiscaleDeformableAttentionFunction.apply(
         img, img_shapes, sampling_points, attention_weights, padding_mode, bool(align_corners))
 

@@ -165,3 +165,13 @@ def test_synth_shards_are_slices_of_the_whole_and_bytes_match_baseline_md():
     assert (c2.alg_fwd_bytes, c2.alg_fwd_bytes + c2.alg_bwd_bytes) == (124_682_304, 333_086_784)  # 124.68 / 333.09 MB
     assert c2.gather_fwd_bytes == 2_621_440_000
     assert synth.WORKLOADS["c3_ddetr_enc"].I == 17821 and synth.WORKLOADS["c5_stress"].I == 21824
+
+
+def test_optional_cpp_binding_builds_and_matches_the_abi():
+    """csrc/msda_torch_ext.cpp (host-only C++ autograd glue) compiles against the installed PyTorch, loads without a
+    GPU and reports the ABI version of the library it is linked to."""
+    from msda_triton_amd import _ext, _lib
+    path = _ext.build()
+    assert os.path.exists(path)
+    mod = _ext.load()
+    assert mod is not None and int(mod.abi_version()) == _lib.ABI_VERSION
