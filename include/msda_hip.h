@@ -73,7 +73,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 4
+#define MSDA_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define MSDA_API __attribute__((visibility("default")))
@@ -125,6 +125,10 @@ MSDA_API int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64
 /* Bytes of device workspace msda_bwd_fused_<dtype> wants (grad_value != NULL) for these sizes. */
 MSDA_API int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
                                                 int64_t P, int elem_size);
+
+/* Largest L*P the fused entry points accept for head dimension D and this element size (beyond it they return
+ * MSDA_ERR_UNSUPPORTED and the caller composes the prologue around msda_fwd_/msda_bwd_<dtype>). */
+MSDA_API int64_t msda_fused_lp_limit(int64_t D, int elem_size);
 
 /* ABI version of the loaded library (== MSDA_ABI_VERSION it was built with). */
 MSDA_API int msda_abi_version(void);

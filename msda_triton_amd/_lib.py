@@ -15,7 +15,7 @@ LIB_NAME = "libmsda_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PADDING_MODES = {"border": 0, "zeros": 1}
 DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64")
 
@@ -23,7 +23,7 @@ DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64")
 EXPORTED_SYMBOLS = tuple(
     [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused", "bwd_fused") for s in DTYPE_SUFFIXES]
     + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option", "msda_bwd_workspace_bytes",
-       "msda_bwd_fused_workspace_bytes"]
+       "msda_bwd_fused_workspace_bytes", "msda_fused_lp_limit"]
 )
 
 _lib = None
@@ -81,6 +81,8 @@ def load():
         lib.msda_bwd_workspace_bytes.argtypes = [i64] * 7 + [ci]
         lib.msda_bwd_fused_workspace_bytes.restype = i64
         lib.msda_bwd_fused_workspace_bytes.argtypes = [i64] * 7 + [ci]
+        lib.msda_fused_lp_limit.restype = i64
+        lib.msda_fused_lp_limit.argtypes = [i64, ci]
         lib.msda_abi_version.restype = ci
         lib.msda_last_error.restype = ctypes.c_char_p
         lib.msda_set_option.restype = ci

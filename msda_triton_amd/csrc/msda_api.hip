@@ -112,6 +112,10 @@ extern "C" int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t 
     return mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
 }
 
+extern "C" int64_t msda_fused_lp_limit_impl(int64_t, int);
+
+extern "C" int64_t msda_fused_lp_limit(int64_t D, int elem_size) { return msda_fused_lp_limit_impl(D, elem_size); }
+
 extern "C" const char *msda_last_error(void) { return msda::g_err; }
 
 extern "C" int msda_set_option(const char *key, int value)

@@ -9,3 +9,21 @@ extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_byte
 {
     return (int64_t)msda::sorted_ws_layout(B, I, H, D, Q, L, P, elem_size == 8 ? 8 : 4).total;
 }
+
+// largest L*P the fused-prologue kernels (msda_fwd_fused / msda_bwd_fused) take for this head dimension and
+// element size: all records of a unit must sit in LDS at once (plan_gather); the 16-byte vector path and the
+// backward's larger records give the smaller bound
+extern "C" __attribute__((visibility("hidden"))) int64_t msda_fused_lp_limit_impl(int64_t D, int elem_size)
+{
+    if (D <= 0 || elem_size <= 0) return 0;
+    const size_t acc = elem_size == 8 ? 8 : 4;
+    int64_t best = INT64_MAX;
+    for (int vec : {16 / elem_size, 1}) {
+        const int NU = msda::kBlock / msda::pick_group((int)((D + vec - 1) / vec));
+        int sc, stage_bytes;
+        size_t lds;
+        msda::plan_gather(NU, 1 << 22, acc, 0, (int)(D * elem_size), sc, stage_bytes, lds, true);
+        if (sc < best) best = sc;
+    }
+    return best;
+}

@@ -20,18 +20,26 @@ using FwdFn = int (*)(const void *, const int64_t *, const void *, const void *,
 using BwdFn = int (*)(const void *, const void *, const int64_t *, const void *, const void *, void *, void *, void *,
                       int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, void *, int64_t, void *);
 
+using FwdFusedFn = int (*)(const void *, const int64_t *, const void *, const void *, void *, int64_t, int64_t, int64_t,
+                           int64_t, int64_t, int64_t, int64_t, int, int, int, void *);
+using BwdFusedFn = int (*)(const void *, const void *, const int64_t *, const void *, const void *, void *, void *, void *,
+                           int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, void *, int64_t,
+                           void *);
+
 struct Fns {
     FwdFn fwd;
     BwdFn bwd;
+    FwdFusedFn fwd_fused;
+    BwdFusedFn bwd_fused;
 };
 
 Fns fns_for(at::ScalarType t)
 {
     switch (t) {
-    case at::kFloat: return {msda_fwd_f32, msda_bwd_f32};
-    case at::kHalf: return {msda_fwd_f16, msda_bwd_f16};
-    case at::kBFloat16: return {msda_fwd_bf16, msda_bwd_bf16};
-    case at::kDouble: return {msda_fwd_f64, msda_bwd_f64};
+    case at::kFloat: return {msda_fwd_f32, msda_bwd_f32, msda_fwd_fused_f32, msda_bwd_fused_f32};
+    case at::kHalf: return {msda_fwd_f16, msda_bwd_f16, msda_fwd_fused_f16, msda_bwd_fused_f16};
+    case at::kBFloat16: return {msda_fwd_bf16, msda_bwd_bf16, msda_fwd_fused_bf16, msda_bwd_fused_bf16};
+    case at::kDouble: return {msda_fwd_f64, msda_bwd_f64, msda_fwd_fused_f64, msda_bwd_fused_f64};
     default: TORCH_CHECK_VALUE(false, "unsupported dtype ", t);
     }
 }
@@ -104,10 +112,76 @@ public:
     }
 };
 
+// The module core with its prologue fused in (msda_fwd_fused_ / msda_bwd_fused_<dtype>).  The caller has checked
+// L*P <= msda_fused_lp_limit(D, element size): the library then never declines.
+class MSDAFusedFunction : public torch::autograd::Function<MSDAFusedFunction> {
+public:
+    static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &img_, const at::Tensor &shapes_,
+                              const at::Tensor &proj_, const at::Tensor &ref_, int64_t padding_mode, bool align_corners)
+    {
+        const at::Tensor img = img_.contiguous(), proj = proj_.contiguous(), ref = ref_.contiguous();
+        const at::Tensor shapes = shapes_.to(at::kLong).contiguous();
+        const int64_t B = img.size(0), I = img.size(1), H = img.size(2), D = img.size(3);
+        const int64_t Q = proj.size(1), L = proj.size(3), P = proj.size(4);
+        at::Tensor out = at::empty({B, Q, H, D}, img.options());
+        const c10::DeviceGuard guard(img.device());
+        check_rc(fns_for(img.scalar_type())
+                     .fwd_fused(img.data_ptr(), shapes.data_ptr<int64_t>(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(),
+                                B, I, H, D, Q, L, P, (int)ref.size(-1), (int)padding_mode, align_corners ? 1 : 0,
+                                current_stream(img)),
+                 "msda_fwd_fused");
+        ctx->save_for_backward({img, shapes, proj, ref});
+        ctx->saved_data["padding_mode"] = padding_mode;
+        ctx->saved_data["align_corners"] = align_corners;
+        return out;
+    }
+
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext *ctx,
+                                                   torch::autograd::variable_list grads)
+    {
+        const auto saved = ctx->get_saved_variables();
+        const at::Tensor &img = saved[0], &shapes = saved[1], &proj = saved[2], &ref = saved[3];
+        const int padding_mode = (int)ctx->saved_data["padding_mode"].toInt();
+        const bool align_corners = ctx->saved_data["align_corners"].toBool();
+        at::Tensor gout = grads[0].contiguous();
+        if (gout.scalar_type() != img.scalar_type()) gout = gout.to(img.scalar_type());
+        const bool want_value = ctx->needs_input_grad(0);
+        const int64_t B = img.size(0), I = img.size(1), H = img.size(2), D = img.size(3);
+        const int64_t Q = proj.size(1), L = proj.size(3), P = proj.size(4);
+        const int64_t ref_dim = ref.size(-1);
+        at::Tensor g_img, ws;
+        at::Tensor g_proj = at::empty_like(proj), g_ref_part = at::empty({B, Q, H, ref_dim}, img.options());
+        int64_t ws_bytes = 0;
+        if (want_value) {
+            g_img = at::empty_like(img);
+            ws_bytes = msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, (int)img.element_size());
+            ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));
+        }
+        {
+            const c10::DeviceGuard guard(img.device());
+            check_rc(fns_for(img.scalar_type())
+                         .bwd_fused(gout.data_ptr(), img.data_ptr(), shapes.data_ptr<int64_t>(), proj.data_ptr(),
+                                    ref.data_ptr(), want_value ? g_img.data_ptr() : nullptr, g_proj.data_ptr(),
+                                    g_ref_part.data_ptr(), B, I, H, D, Q, L, P, (int)ref_dim, padding_mode,
+                                    align_corners ? 1 : 0, want_value ? ws.data_ptr() : nullptr, ws_bytes,
+                                    current_stream(img)),
+                     "msda_bwd_fused");
+        }
+        return {g_img, at::Tensor(), ctx->needs_input_grad(2) ? g_proj : at::Tensor(),
+                ctx->needs_input_grad(3) ? g_ref_part.sum(2) : at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
 at::Tensor msda(const at::Tensor &img, const at::Tensor &shapes, const at::Tensor &pts, const at::Tensor &att,
                 int64_t padding_mode, bool align_corners)
 {
     return MSDAFunction::apply(img, shapes, pts, att, padding_mode, align_corners);
+}
+
+at::Tensor msda_fused(const at::Tensor &img, const at::Tensor &shapes, const at::Tensor &proj, const at::Tensor &ref,
+                      int64_t padding_mode, bool align_corners)
+{
+    return MSDAFusedFunction::apply(img, shapes, proj, ref, padding_mode, align_corners);
 }
 
 }  // namespace
@@ -116,5 +190,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "C++ autograd glue over libmsda_hip.so (same C ABI as the ctypes route)";
     m.def("msda", &msda, "multi-scale deformable attention (forward; differentiable)");
+    m.def("msda_fused", &msda_fused, "module core with the softmax / sampling-point prologue fused in (differentiable)");
+    m.def("fused_lp_limit", [](int64_t D, int64_t elem_size) { return msda_fused_lp_limit(D, (int)elem_size); });
     m.def("abi_version", []() { return msda_abi_version(); });
 }

@@ -66,6 +66,7 @@ def _shapes_i64(img_shapes: torch.Tensor) -> torch.Tensor:
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_FUSED_LP_LIMIT: dict = {}  # (D, element size) -> msda_fused_lp_limit
 _WS_BYTES: dict = {}  # (B, I, H, D, Q, L, P, elem, option epoch) -> msda_bwd_workspace_bytes
 
 
@@ -430,7 +431,21 @@ def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, ali
     with the prologue fused into the forward kernel; on host tensors exactly that composition."""
     if img.device.type == "cuda" and img.dtype in VALID_DTYPES and proj.dtype == img.dtype and \
             reference_points.dtype == img.dtype and not torch.compiler.is_compiling():
-        _padding_code(padding_mode)
+        pad = _padding_code(padding_mode)
+        ext = _ext.load()
+        if ext is not None and KernelTimer.active is None and not torch.is_autocast_enabled():
+            # C++ autograd glue (see hip_multiscale_deformable_attention); only when the fused kernels take this L*P
+            B, I, H, D = img.shape
+            key = (D, img.element_size())
+            limit = _FUSED_LP_LIMIT.get(key)
+            if limit is None:
+                limit = _FUSED_LP_LIMIT[key] = int(ext.fused_lp_limit(*key))
+            if proj.dim() == 6 and proj.shape[3] * proj.shape[4] <= limit and proj.shape[-1] == 3 \
+                    and reference_points.dim() == 3 and reference_points.shape[-1] in (2, 4) \
+                    and tuple(proj.shape[:3]) == (B, reference_points.shape[1], H) \
+                    and reference_points.shape[0] == B and tuple(img_shapes.shape) == (proj.shape[3], 2):
+                _shapes_i64(img_shapes)
+                return ext.msda_fused(img, img_shapes, proj, reference_points, pad, bool(align_corners))
         return _HipFusedModuleCoreFunction.apply(img, img_shapes, proj, reference_points, padding_mode,
                                                  bool(align_corners))
     pts, att = module_sampling_inputs(proj, img_shapes, reference_points)
