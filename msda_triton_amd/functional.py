@@ -78,6 +78,13 @@ def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def _autocast_on() -> bool:
+    try:
+        return torch.is_autocast_enabled("cuda")
+    except TypeError:  # older signature
+        return torch.is_autocast_enabled()
+
+
 class _OnDevice:
     """``with torch.cuda.device(d)`` only when ``d`` is not already the current device (the context manager costs
     several microseconds per call, which matters for Grounding-DINO-sized problems)."""
@@ -274,7 +281,7 @@ def hip_multiscale_deformable_attention(
     # time per call.  The Python Function below serves autocast (fp32 casting), per-kernel timing and every
     # installation where the binding was not built.
     ext = _ext.load()
-    if ext is not None and KernelTimer.active is None and not torch.is_autocast_enabled():
+    if ext is not None and KernelTimer.active is None and not _autocast_on():
         _dims(img, sampling_points, attention_weights, img_shapes)
         _shapes_i64(img_shapes)
         return ext.msda(img, img_shapes, sampling_points, attention_weights, _padding_code(padding_mode),
@@ -433,7 +440,7 @@ def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, ali
             reference_points.dtype == img.dtype and not torch.compiler.is_compiling():
         pad = _padding_code(padding_mode)
         ext = _ext.load()
-        if ext is not None and KernelTimer.active is None and not torch.is_autocast_enabled():
+        if ext is not None and KernelTimer.active is None and not _autocast_on():
             # C++ autograd glue (see hip_multiscale_deformable_attention); only when the fused kernels take this L*P
             B, I, H, D = img.shape
             key = (D, img.element_size())
