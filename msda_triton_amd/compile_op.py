@@ -83,3 +83,79 @@ def compiled_multiscale_deformable_attention(img, img_shapes, sampling_points, a
             return msda_forward(img.float(), img_shapes, sampling_points.float(), attention_weights.float(),
                                 padding_mode == "zeros", bool(align_corners))
     return msda_forward(img, img_shapes, sampling_points, attention_weights, padding_mode == "zeros", bool(align_corners))
+
+
+# ---------------------------------------------------------------------------------------------
+# the module core with its prologue fused in (msda_fwd_fused_ / msda_bwd_fused_<dtype>) as custom ops, so that a
+# compiled MultiscaleDeformableAttention module keeps the fused kernels
+# ---------------------------------------------------------------------------------------------
+@torch.library.custom_op("msda_amd::fused_forward", mutates_args=(), device_types="cuda")
+def msda_fused_forward(img: torch.Tensor, img_shapes: torch.Tensor, proj: torch.Tensor, reference_points: torch.Tensor,
+                       zeros: bool, align_corners: bool) -> torch.Tensor:
+    out = F.msda_hip_fwd_fused(img, img_shapes, proj, reference_points, _PAD[zeros], align_corners)
+    if out is None:  # (callers check fused_lp_ok first; kept for safety)
+        pts, att = F.module_sampling_inputs(proj, img_shapes, reference_points)
+        out = F.msda_hip_fwd(img, img_shapes, pts, att, _PAD[zeros], align_corners)
+    return out
+
+
+@msda_fused_forward.register_fake
+def _(img, img_shapes, proj, reference_points, zeros, align_corners):
+    B, _, H, D = img.shape
+    return img.new_empty((B, proj.shape[1], H, D))
+
+
+@torch.library.custom_op("msda_amd::fused_backward", mutates_args=(), device_types="cuda")
+def msda_fused_backward(out_grad: torch.Tensor, img: torch.Tensor, img_shapes: torch.Tensor, proj: torch.Tensor,
+                        reference_points: torch.Tensor, zeros: bool, align_corners: bool,
+                        need_value: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    res = F.msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, _PAD[zeros], align_corners, need_value)
+    if res is None:
+        raise RuntimeError("msda_amd::fused_backward: L*P too large for the fused kernels (check fused_lp_ok first)")
+    g_img, g_proj, g_ref = res
+    return (g_img if g_img is not None else img.new_empty(0)), g_proj, g_ref
+
+
+@msda_fused_backward.register_fake
+def _(out_grad, img, img_shapes, proj, reference_points, zeros, align_corners, need_value):
+    return (torch.empty_like(img, memory_format=torch.contiguous_format) if need_value else img.new_empty(0),
+            torch.empty_like(proj, memory_format=torch.contiguous_format),
+            torch.empty_like(reference_points, memory_format=torch.contiguous_format))
+
+
+def _fused_setup_context(ctx, inputs, output):
+    img, img_shapes, proj, reference_points, zeros, align_corners = inputs
+    ctx.save_for_backward(img, img_shapes, proj, reference_points)
+    ctx.zeros, ctx.align_corners = zeros, align_corners
+
+
+def _fused_backward(ctx, out_grad):
+    img, img_shapes, proj, reference_points = ctx.saved_tensors
+    g_img, g_proj, g_ref = msda_fused_backward(out_grad.contiguous(), img, img_shapes, proj, reference_points, ctx.zeros,
+                                               ctx.align_corners, ctx.needs_input_grad[0])
+    return (g_img if ctx.needs_input_grad[0] else None, None, g_proj if ctx.needs_input_grad[2] else None,
+            g_ref if ctx.needs_input_grad[3] else None, None, None)
+
+
+msda_fused_forward.register_autograd(_fused_backward, setup_context=_fused_setup_context)
+
+
+@torch._dynamo.assume_constant_result
+def _fused_lp_limit(head_dim: int, elem_size: int) -> int:
+    from . import _lib
+    return int(_lib.load().msda_fused_lp_limit(int(head_dim), int(elem_size)))
+
+
+def fused_lp_ok(img: torch.Tensor, proj: torch.Tensor) -> bool:
+    """Do the fused kernels take this L*P for this head dimension / dtype?  (Static shapes: decided at trace time.)"""
+    return int(proj.shape[3]) * int(proj.shape[4]) <= _fused_lp_limit(int(img.shape[-1]), img.element_size())
+
+
+def compiled_fused_module_core(img, img_shapes, proj, reference_points, padding_mode, align_corners) -> torch.Tensor:
+    """``fused_module_core`` through the registered custom ops (traceable); fp32 under autocast like the eager path."""
+    F._padding_code(padding_mode)
+    if torch.is_autocast_enabled("cuda"):
+        with torch.autocast("cuda", enabled=False):
+            return msda_fused_forward(img.float(), img_shapes, proj.float(), reference_points.float(),
+                                      padding_mode == "zeros", bool(align_corners))
+    return msda_fused_forward(img, img_shapes, proj, reference_points, padding_mode == "zeros", bool(align_corners))

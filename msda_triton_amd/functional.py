@@ -455,6 +455,12 @@ def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, ali
                 return ext.msda_fused(img, img_shapes, proj, reference_points, pad, bool(align_corners))
         return _HipFusedModuleCoreFunction.apply(img, img_shapes, proj, reference_points, padding_mode,
                                                  bool(align_corners))
+    if img.device.type == "cuda" and torch.compiler.is_compiling() and img.dtype in VALID_DTYPES and \
+            proj.dtype == img.dtype and reference_points.dtype == img.dtype:
+        from . import compile_op  # traced: keep the fused kernels as one custom op per direction
+        if compile_op.fused_lp_ok(img, proj):
+            return compile_op.compiled_fused_module_core(img, img_shapes, proj, reference_points, padding_mode,
+                                                         align_corners)
     pts, att = module_sampling_inputs(proj, img_shapes, reference_points)
     return multiscale_deformable_attention(img, img_shapes, pts, att, padding_mode, align_corners)
 

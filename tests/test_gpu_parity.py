@@ -811,3 +811,31 @@ def test_cpp_binding_and_ctypes_routes_agree():
     assert l.grad is not None and torch.isfinite(l.grad).all()
     with pytest.raises(ValueError):
         ops.multiscale_deformable_attention(v, d["shapes"], l[:, :, :, :1], d["attn"], "zeros", False)
+
+
+def test_torch_compile_module_keeps_the_fused_kernels():
+    """A compiled MultiscaleDeformableAttention traces to torch.ops.msda_amd.fused_forward / fused_backward (the
+    fused kernels stay in the graph as opaque custom ops) and matches the eager module, gradients included."""
+    import msda_triton_amd.compile_op  # noqa: F401
+    ops = _ops()
+    torch.manual_seed(5)
+    m = ops.MultiscaleDeformableAttention(32, 32, 2, 4, 3, "border", True).to(DEV)
+    levels = [(6, 5), (3, 4)]
+    s = torch.tensor(levels, device=DEV)
+    img = torch.randn(2, sum(h * w for h, w in levels), 32, device=DEV)
+    q = torch.randn(2, 21, 32, device=DEV)
+    ref = torch.rand(2, 21, 2, device=DEV)
+    compiled = torch.compile(m, fullgraph=True, backend="aot_eager")
+    res = []
+    for f in (m, compiled):
+        m.zero_grad()
+        i_, q_ = img.clone().requires_grad_(True), q.clone().requires_grad_(True)
+        out = f(i_, s, q_, ref)
+        out.square().sum().backward()
+        res.append((out.detach(), i_.grad, q_.grad, m.query_input_proj.weight.grad.clone()))
+    for a, b in zip(*res):
+        torch.testing.assert_close(a, b, atol=1e-4, rtol=1e-4)
+    v = torch.randn(2, 42, 4, 8, device=DEV)
+    pr = torch.randn(2, 21, 4, 2, 3, 3, device=DEV)
+    torch.library.opcheck(torch.ops.msda_amd.fused_forward.default, (v, s, pr, ref, False, True),
+                          test_utils=("test_schema", "test_faketensor"))
