@@ -145,8 +145,9 @@ MSDA_API const char *msda_last_error(void);
  *   "value_path" 0 (default): grad_value by sorted gather when a workspace is supplied, except for small
  *                   problems where the single-launch LDS-tile kernel is faster
  *                1: always the LDS-tile kernel      2: always the sorted gather (if a workspace is supplied)
- *   "stage_kb"   LDS KiB a gather workgroup may spend on staged pyramid levels (default 0 = off; measured: no gain)
- *   "gather_block", "wg_target", "debug": experiment knobs, see msda_triton_amd/csrc/msda_launch.hpp
+ *   "stage_kb"   LDS KiB a forward workgroup may spend on staged pyramid levels (the smallest levels that fit are
+ *                served from LDS; default 0 = off)
+ *   "cell_slices", "wg_target", "overlap", "debug": experiment knobs, see msda_triton_amd/csrc/msda_launch.hpp
  */
 MSDA_API int msda_set_option(const char *key, int value);
 MSDA_API int msda_get_option(const char *key);

@@ -9,16 +9,13 @@
 // served by G lanes (G * VEC >= D channels, VEC elements = one 16-byte load per lane), i.e.
 // 64/G units per wavefront and 256/G per workgroup.
 //
-// Stage (once per workgroup): the small pyramid levels of the plane — as many, smallest first, as fit
-//   the staging budget — are copied into LDS.  With the usual 2x pyramid the two coarsest levels are
-//   1/16 of the pixels but half of the samples, so half of the row gathers never touch the vector
-//   memory path (L2 -> L1 at 64 B/clk/CU is what bounds these kernels, not HBM).
-// Phase 1 (all 256 threads, one sample each): read (x, y, a), do the coordinate math ONCE per
-//   sample, park {4 row offsets, 4 weights} in LDS.  Loads are coalesced along (l, p).
-// Phase 2 (per unit, G lanes): walk the unit's samples level by level (the level of sample s is the
-//   same for every unit, so the LDS-or-global choice is wave-uniform), broadcast-read the parked
-//   record, fetch the four rows (ds_read_b128 from the staged copy, or range-checked 16-byte buffer
-//   loads), FMA into per-lane accumulators.
+// Phase 1 (per wave, one sample per lane and trip): read (x, y, a), do the coordinate math ONCE per
+//   sample, park {4 row offsets, 4 weights} in the wave's LDS slice.  Loads are coalesced along (l, p).
+// Phase 2 (per unit, G lanes): broadcast-read the parked record, fetch the four rows with range-checked
+//   16-byte buffer loads, FMA into per-lane accumulators.  No block barrier: a wave reads only its own records.
+// Optional (forward only, msda_set_option("stage_kb", n), off by default): the smallest pyramid levels that fit
+//   n KiB are copied into LDS once per workgroup and their rows are served by ds_read_b128 instead of the
+//   vector-memory path (measured on MI355X, c2 @ 10k: level 3 staged, 9 KiB: forward 111 -> 99 us).
 #pragma once
 
 #include "msda_common.hpp"
@@ -87,7 +84,7 @@ struct StagePlan {
 
 // Decide (thread 0) which levels are staged, then copy them (all threads).  Levels are taken from the
 // last to the first (coarse to fine in the usual ordering) while they fit.  Caller syncs before and after.
-template <typename T, int BLOCK>
+template <typename T>
 __device__ __forceinline__ void stage_levels(const LevelTab *tab, StagePlan *plan, unsigned char *stage, rsrc_t rs,
                                              uint32_t row_bytes, int row_b, int budget, int L)
 {
@@ -108,14 +105,14 @@ __device__ __forceinline__ void stage_levels(const LevelTab *tab, StagePlan *pla
     __syncthreads();
     if (budget <= 0) return;
     const int cpr = row_b / 16;  // 16-byte pieces per row
-    for (int i = tid; i < cpr; i += BLOCK) reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < cpr; i += kBlock) reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0, 0, 0, 0);
     const float inv_cpr = 1.0f / (float)cpr;
     for (int l = 0; l < L; ++l) {
         const int so = plan->off[l];
         if (so < 0) continue;  // uniform
         const int pieces = tab->h[l] * tab->w[l] * cpr;
         const uint32_t src0 = (uint32_t)tab->start[l] * row_bytes;
-        for (int c = tid; c < pieces; c += BLOCK) {
+        for (int c = tid; c < pieces; c += kBlock) {
             const int r = div_small(c, cpr, inv_cpr), part = c - r * cpr;
             const auto v = RawLoad<16>::load(rs, src0 + (uint32_t)r * row_bytes + (uint32_t)part * 16u);
             *reinterpret_cast<RawLoad<16>::type *>(stage + so + c * 16) = v;
@@ -187,12 +184,12 @@ constexpr size_t kGatherLdsFixed = sizeof(LevelTab) + (sizeof(StagePlan) + 15) /
 // forward.  After the one-time staging barrier every wave runs on its own: it parks the records of
 // ITS 64/G units, gathers, stores, and moves to its next query chunk without any block barrier.
 // ==========================================================================================
-template <typename T, int VEC, int G, int BLOCK, bool STAGE, bool FUSED>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void msda_fwd_kernel(const Params p)
+template <typename T, int VEC, int G, bool STAGE, bool FUSED>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void msda_fwd_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
-    constexpr int NU = BLOCK / G;      // units per workgroup and query chunk
+    constexpr int NU = kBlock / G;     // units per workgroup and query chunk
     constexpr int UPW = kWave / G;     // units per wave
 
     const int slots = (p.nqc + p.qw - 1) / p.qw;
@@ -213,7 +210,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void
     load_level_table(tab, p.shapes, p.L);
     __syncthreads();
     if constexpr (STAGE) {
-        stage_levels<T, BLOCK>(tab, lds.plan, lds.stage, rs, row_bytes, row_b, p.stage_bytes, p.L);
+        stage_levels<T>(tab, lds.plan, lds.stage, rs, row_bytes, row_b, p.stage_bytes, p.L);
         __syncthreads();
     }
 
@@ -394,12 +391,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5))) void
 // backward, part 1: grad_loc and grad_attn.  Same decomposition as the forward; every sample's
 // three results are reduced over the unit's G lanes with DPP moves and written exactly once.
 // ==========================================================================================
-template <typename T, int VEC, int G, int BLOCK, bool STAGE, bool FUSED>
-__global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
+template <typename T, int VEC, int G, bool FUSED>
+__global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
-    constexpr int NU = BLOCK / G;
+    constexpr int NU = kBlock / G;
     constexpr int UPW = kWave / G;
 
     const int slots = (p.nqc + p.qw - 1) / p.qw;
@@ -413,17 +410,12 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
     LevelTab *tab = lds.tab;
 
     const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);
-    const int row_b = p.D * (int)sizeof(T);
     const T *plane = static_cast<const T *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
     const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(T));
     const rsrc_t rs = make_rsrc(plane, plane_bytes);
 
     load_level_table(tab, p.shapes, p.L);
     __syncthreads();
-    if constexpr (STAGE) {
-        stage_levels<T, BLOCK>(tab, lds.plan, lds.stage, rs, row_bytes, row_b, p.stage_bytes, p.L);
-        __syncthreads();
-    }
 
     const int tid = threadIdx.x;
     const int wave = tid / kWave, lane = tid % kWave;
@@ -521,7 +513,7 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                         a = TR::to_acc(attn[sidx]);
                     }
                     Taps<A> t;
-                    make_taps<A>(px, py, lh, lw, STAGE ? 0 : tab->start[l], p.zeros, p.align, STAGE ? 1u : row_bytes, t);
+                    make_taps<A>(px, py, lh, lw, tab->start[l], p.zeros, p.align, row_bytes, t);
                     const A sx = p.align ? (A)(lw - 1) : (A)lw;
                     const A sy = p.align ? (A)(lh - 1) : (A)lh;
                     Rec4<A> r;
@@ -530,10 +522,7 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                     r.v[2] = t.gx_on ? a * sx : (A)0;
                     r.v[3] = t.gy_on ? a * sy : (A)0;
                     const int rslot = imul24(fu, scp) + (sl - s0);
-                    if constexpr (STAGE)
-                        w_off[rslot] = record_offsets(t, lds.plan->off[l], lds.plan->zero_off, row_b, tab->start[l], row_bytes);
-                    else
-                        w_off[rslot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
+                    w_off[rslot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
                     w_rec[rslot] = r;
                 }
             }
@@ -575,7 +564,7 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) gp.v[i] = TR::from_acc((A)0);
                     if (lane_in) gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
-                    if constexpr (TR::kDot2 && !STAGE && (VEC % 2) == 0) {
+                    if constexpr (TR::kDot2 && (VEC % 2) == 0) {
                         // 16-bit rows: the four dot products with grad_out straight from the packed pairs
                         // (v_dot2c_f32_f16 / _bf16: two multiply-adds per instruction, no widening)
                         using P2 = typename TR::pair_t;
@@ -631,20 +620,11 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                         }
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
-                            const int s = min(sb + u, sc - 1);
-                            const bool staged = STAGE && lds.plan->off[(s0 + s) / p.P] >= 0;  // uniform
                             const uint32_t lo = lane_in ? lane_off : 0u;
-                            if (staged) {
-                                lds_row<T, VEC>(lds.stage, o[u].x + lo, v[u][0]);
-                                lds_row<T, VEC>(lds.stage, o[u].y + lo, v[u][1]);
-                                lds_row<T, VEC>(lds.stage, o[u].z + lo, v[u][2]);
-                                lds_row<T, VEC>(lds.stage, o[u].w + lo, v[u][3]);
-                            } else {
-                                load_row<T, VEC>(rs, o[u].x + lo, v[u][0]);
-                                load_row<T, VEC>(rs, o[u].y + lo, v[u][1]);
-                                load_row<T, VEC>(rs, o[u].z + lo, v[u][2]);
-                                load_row<T, VEC>(rs, o[u].w + lo, v[u][3]);
-                            }
+                            load_row<T, VEC>(rs, o[u].x + lo, v[u][0]);
+                            load_row<T, VEC>(rs, o[u].y + lo, v[u][1]);
+                            load_row<T, VEC>(rs, o[u].z + lo, v[u][2]);
+                            load_row<T, VEC>(rs, o[u].w + lo, v[u][3]);
                         }
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
@@ -662,7 +642,6 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                     }
                 } else {
                     for (int s = 0; s < sc; ++s) {
-                        const bool staged = STAGE && lds.plan->off[(s0 + s) / p.P] >= 0;  // uniform
                         const uint4 o = uo[s];
                         const Rec4<A> r = up[s];
                         A d0 = 0, d1 = 0, d2 = 0, d3 = 0;
@@ -672,17 +651,10 @@ __global__ __launch_bounds__(BLOCK) void msda_bwd_sample_kernel(const Params p)
                                 const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
                                 const Pack<T, VEC> gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
                                 A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-                                if (staged) {
-                                    lds_row<T, VEC>(lds.stage, o.x + lane_off, v0);
-                                    lds_row<T, VEC>(lds.stage, o.y + lane_off, v1);
-                                    lds_row<T, VEC>(lds.stage, o.z + lane_off, v2);
-                                    lds_row<T, VEC>(lds.stage, o.w + lane_off, v3);
-                                } else {
-                                    load_row<T, VEC>(rs, o.x + lane_off, v0);
-                                    load_row<T, VEC>(rs, o.y + lane_off, v1);
-                                    load_row<T, VEC>(rs, o.z + lane_off, v2);
-                                    load_row<T, VEC>(rs, o.w + lane_off, v3);
-                                }
+                                load_row<T, VEC>(rs, o.x + lane_off, v0);
+                                load_row<T, VEC>(rs, o.y + lane_off, v1);
+                                load_row<T, VEC>(rs, o.z + lane_off, v2);
+                                load_row<T, VEC>(rs, o.w + lane_off, v3);
 #pragma unroll
                                 for (int i = 0; i < VEC; ++i) {
                                     const A gg = TR::to_acc(gp.v[i]);

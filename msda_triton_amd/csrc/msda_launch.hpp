@@ -4,18 +4,17 @@
 
 #include <stdio.h>
 
+#include <atomic>
+
 #include "msda_value_sorted.hpp"
-#include "msda_value_tiles.hpp"
 #include "msda_value_tile.hpp"
 
 namespace msda {
 
 // ---- process-wide options and per-thread error text (defined in msda_api.hip) ----
 int option_xcd_map();
-int option_value_path();  // 0: auto (sorted gather for big problems, LDS tiles for small), 1: tiles, 2: sorted
+int option_value_path();  // 0: auto (sorted gather for big problems, LDS tile kernel for small), 1: LDS tile kernel, 2: sorted
 int option_stage_kb();    // LDS KiB a gather workgroup may spend on staged pyramid levels (0: off)
-int option_gather_block();  // threads per gather workgroup when staging is on (256 / 512 / 1024)
-int option_tile_path();     // 1: large problems take the tile-binned grad_value path when it applies (default 0 until proven)
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
 int option_debug();         // dev-only ablation mask
 int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream
@@ -30,12 +29,19 @@ constexpr int kMaxDynLds = 160 * 1024 - 2048;  // leaves room for small static _
 
 inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-template <typename K> inline void allow_big_lds(K kernel)
+// Kernels that may ask for more than 64 KiB of dynamic LDS need the attribute raised once per (kernel, DEVICE): a
+// process that drives several GPUs must not skip it on the second one.  `done` is the caller's per-kernel bitmask
+// of devices already served (idempotent: a lost race only repeats the call).
+template <typename K> inline void allow_big_lds(K kernel, std::atomic<uint64_t> &done)
 {
-    // one attribute call per kernel instantiation (thread-safe enough: idempotent)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (dev < 64 && (done.load(std::memory_order_relaxed) & bit)) return;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kMaxDynLds) != hipSuccess)
         (void)hipGetLastError();  // do not let a refused attribute poison the next launch check
+    if (dev < 64) done.fetch_or(bit, std::memory_order_relaxed);
 }
 
 struct Dims {
@@ -124,8 +130,7 @@ inline void plan_gather(int NU, int LP, size_t acc_bytes, int stage_want, int ro
                         size_t &lds, bool aux = false)
 {
     const size_t rec = 16 + (aux ? 7 : 4) * acc_bytes;  // aux: the fused backward's (a, ox, oy) per slot
-    const size_t rec_budget = NU > 64 ? (size_t)96 * 1024 : (size_t)kRecordLdsBudget;
-    int cap = (int)(rec_budget / (NU * rec)) - 1;
+    int cap = (int)((size_t)kRecordLdsBudget / (NU * rec)) - 1;
     if (cap < 1) cap = 1;
     sc = LP < cap ? LP : cap;
     const size_t base = kGatherLdsFixed + (size_t)NU * (sc + 1) * rec;
@@ -136,12 +141,15 @@ inline void plan_gather(int NU, int LP, size_t acc_bytes, int stage_want, int ro
     lds = base + (size_t)stage_bytes;
 }
 
-template <typename T, int VEC, int G, int MODE, int BLOCK> inline int launch_gather_block(Params &p, hipStream_t stream)
+// MODE 0: forward, 1: grad_loc/grad_attn, 2: fused forward, 3: fused backward (sample half)
+template <typename T, int VEC, int G, int MODE> inline int launch_gather(Params &p, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
-    constexpr int NU = BLOCK / G;
+    constexpr int NU = kBlock / G;
     size_t lds;
-    const int stage_want = (VEC > 1 && MODE != 3) ? option_stage_kb() * 1024 : 0;
+    // level staging serves the plain forward only (the backward's records fill the LDS it would need, and the
+    // fused kernels' L*P limit must not depend on an option)
+    const int stage_want = (VEC > 1 && MODE == 0) ? option_stage_kb() * 1024 : 0;
     plan_gather(NU, p.LP, sizeof(A), stage_want, p.D * (int)sizeof(T), p.sc, p.stage_bytes, lds, MODE == 3);
     p.nqc = (p.Q + NU - 1) / NU;
     const int npairs = p.B * p.H;
@@ -158,47 +166,30 @@ template <typename T, int VEC, int G, int MODE, int BLOCK> inline int launch_gat
         set_error("fused prologue needs all L*P=%d samples of a unit in LDS at once (limit %d)", p.LP, p.sc);
         return MSDA_ERR_UNSUPPORTED;
     }
+    static std::atomic<uint64_t> big_lds_done{0};  // one per template instantiation
     if constexpr (MODE == 3) {
-        auto kernel = msda_bwd_sample_kernel<T, VEC, G, BLOCK, false, true>;
-        static bool big_lds_ok = false;
-        if (!big_lds_ok) {
-            allow_big_lds(kernel);
-            big_lds_ok = true;
-        }
-        hipLaunchKernelGGL(kernel, grid, dim3(BLOCK), lds, stream, p);
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, true>;
+        allow_big_lds(kernel, big_lds_done);
+        hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
+    } else if constexpr (MODE == 1) {
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, false>;
+        allow_big_lds(kernel, big_lds_done);
+        hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
+    } else if constexpr (MODE == 2) {
+        auto kernel = msda_fwd_kernel<T, VEC, G, false, true>;
+        allow_big_lds(kernel, big_lds_done);
+        hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else if (p.stage_bytes > 0) {
-        auto kernel = MODE == 1   ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, true, false>
-                      : MODE == 2 ? msda_fwd_kernel<T, VEC, G, BLOCK, true, true>
-                                  : msda_fwd_kernel<T, VEC, G, BLOCK, true, false>;
-        static bool big_lds_ok = false;
-        if (!big_lds_ok) {
-            allow_big_lds(kernel);
-            big_lds_ok = true;
-        }
-        hipLaunchKernelGGL(kernel, grid, dim3(BLOCK), lds, stream, p);
+        static std::atomic<uint64_t> big_lds_done_staged{0};
+        auto kernel = msda_fwd_kernel<T, VEC, G, true, false>;
+        allow_big_lds(kernel, big_lds_done_staged);
+        hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else {
-        auto kernel = MODE == 1   ? msda_bwd_sample_kernel<T, VEC, G, BLOCK, false, false>
-                      : MODE == 2 ? msda_fwd_kernel<T, VEC, G, BLOCK, false, true>
-                                  : msda_fwd_kernel<T, VEC, G, BLOCK, false, false>;
-        static bool big_lds_ok = false;
-        if (!big_lds_ok) {
-            allow_big_lds(kernel);
-            big_lds_ok = true;
-        }
-        hipLaunchKernelGGL(kernel, grid, dim3(BLOCK), lds, stream, p);
+        auto kernel = msda_fwd_kernel<T, VEC, G, false, false>;
+        allow_big_lds(kernel, big_lds_done);
+        hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     }
     return (int)hipGetLastError();
-}
-
-template <typename T, int VEC, int G, int MODE> inline int launch_gather(Params &p, hipStream_t stream)
-{
-    // staged levels are shared by a whole workgroup: use the biggest one (16 waves) when staging is on
-    if (VEC > 1 && option_stage_kb() > 0 && MODE != 3) {
-        const int blk = option_gather_block();
-        if (blk == 1024) return launch_gather_block<T, VEC, G, MODE, 1024>(p, stream);
-        if (blk == 512) return launch_gather_block<T, VEC, G, MODE, 512>(p, stream);
-    }
-    return launch_gather_block<T, VEC, G, MODE, kBlock>(p, stream);
 }
 
 template <typename T, int VEC, int MODE> inline int dispatch_group(Params &p, hipStream_t stream)
@@ -235,11 +226,8 @@ template <typename T, int CH> inline int launch_value(Params &p, hipStream_t str
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    static bool big_lds_ok = false;
-    if (!big_lds_ok) {
-        allow_big_lds(msda_bwd_value_kernel<T, CH>);
-        big_lds_ok = true;
-    }
+    static std::atomic<uint64_t> big_lds_done{0};
+    allow_big_lds(msda_bwd_value_kernel<T, CH>, big_lds_done);
     hipLaunchKernelGGL((msda_bwd_value_kernel<T, CH>), grid, dim3(kValueBlock), lds, stream, p);
     return (int)hipGetLastError();
 }
@@ -312,12 +300,9 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
         return MSDA_ERR_TOO_LARGE;
     }
     const size_t cell_lds = sizeof(LevelTab) + (size_t)p.cell_cap * sizeof(int);
-    static bool big_lds_ok = false;
-    if (!big_lds_ok) {
-        allow_big_lds(msda_cell_pass_kernel<T, false>);
-        allow_big_lds(msda_cell_pass_kernel<T, true>);
-        big_lds_ok = true;
-    }
+    static std::atomic<uint64_t> big_lds_count{0}, big_lds_place{0};
+    allow_big_lds(msda_cell_pass_kernel<T, false>, big_lds_count);
+    allow_big_lds(msda_cell_pass_kernel<T, true>, big_lds_place);
     hipLaunchKernelGGL((msda_cell_pass_kernel<T, false>), gcell, dim3(kCellBlock), cell_lds, stream, p);
     const int64_t tot_blocks = (int64_t)((p.nc_cap + kBlock - 1) / kBlock) * npairs;
     if (tot_blocks >= ((int64_t)1 << 31)) {
@@ -389,7 +374,7 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
     fill_params(p, d, padding_mode, align_corners);
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
     rc = dispatch_gather<T, 0>(p, vec_ok, stream);
-    if (rc) set_error("forward launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (rc > 0) set_error("forward launch failed: %s", hipGetErrorString((hipError_t)rc));  // negative: message already set
     return rc;
 }
 
@@ -439,59 +424,6 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
     return rc;
 }
 
-// ---- tile-binned grad_value (msda_value_tiles.hpp): T1..T4 ----
-template <typename T> inline bool tiles_applicable(const Params &p, const Dims &d, void *workspace, int64_t workspace_bytes)
-{
-    using A = typename Traits<T>::acc;
-    if (sizeof(T) != sizeof(A)) return false;  // fp32 / fp64 only: partial sums are added atomically in the output type
-    constexpr int VECF = 16 / sizeof(T);
-    if (!(aligned_to(p.grad_out, 16) && aligned_to(p.grad_value, 16) && (p.D % VECF) == 0)) return false;
-    if (d.Q >= ((int64_t)1 << kLcellShift)) return false;
-    const TileWsLayout w = tile_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A));
-    if (w.nb_cap > kTileBinCap) return false;
-    return workspace != nullptr && aligned_to(workspace, 256) && (uint64_t)workspace_bytes >= w.total;
-}
-
-template <typename T> inline int run_value_tiles(Params &p, const Dims &d, void *workspace, hipStream_t stream)
-{
-    using A = typename Traits<T>::acc;
-    const TileWsLayout w = tile_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A));
-    unsigned char *ws = static_cast<unsigned char *>(workspace);
-    p.ws_part = reinterpret_cast<int *>(ws + w.off_part);
-    p.ws_off = reinterpret_cast<int *>(ws + w.off_binoff);
-    p.ws_itemcnt = reinterpret_cast<int *>(ws + w.off_cnt);
-    p.ws_chunks = reinterpret_cast<int4 *>(ws + w.off_chunks);
-    p.ws_entries = ws + w.off_entries;
-    p.nb_cap = w.nb_cap;
-    p.ch_cap = w.ch_cap;
-    p.nsplit = w.nsplit;
-    const int npairs = p.B * p.H;
-    int rc = (int)hipMemsetAsync(p.ws_itemcnt, 0, 256, stream);
-    if (rc) return rc;
-    // every pixel row is either stored whole or accumulated atomically: start from zeros
-    rc = (int)hipMemsetAsync(p.grad_value, 0, (size_t)d.B * d.I * d.H * d.D * sizeof(T), stream);
-    if (rc) return rc;
-    dim3 gcell;
-    if (!plane_grid(p, npairs, p.nsplit, gcell)) {
-        set_error("grid too large");
-        return MSDA_ERR_TOO_LARGE;
-    }
-    hipLaunchKernelGGL((msda_tile_count_kernel<T>), gcell, dim3(kCellBlock), 0, stream, p);
-    hipLaunchKernelGGL((msda_tile_scan_kernel<T>), dim3((unsigned)npairs), dim3(kTileScanBlock), 0, stream, p);
-    constexpr int kRounds = sizeof(A) == 8 ? kTileRound / 2 : kTileRound;
-    const size_t place_lds = (size_t)kRounds * kCellBlock * (sizeof(Entry<A>) + sizeof(int));
-    static bool big_lds_ok = false;
-    if (!big_lds_ok) {
-        allow_big_lds(msda_tile_place_kernel<T>);
-        big_lds_ok = true;
-    }
-    hipLaunchKernelGGL((msda_tile_place_kernel<T>), gcell, dim3(kCellBlock), place_lds, stream, p);
-    constexpr int VECF = 16 / sizeof(T);
-    const unsigned nwg = (unsigned)(p.ch_cap < 2048 ? p.ch_cap : 2048);
-    hipLaunchKernelGGL((msda_tile_gather_kernel<T, VECF>), dim3(nwg), dim3(kTileBlock), 0, stream, p);
-    return (int)hipGetLastError();
-}
-
 // grad_value: the sorted-gather pipeline when the caller's workspace allows it, else (or for small problems) the
 // LDS-tile kernel.
 template <typename T>
@@ -518,15 +450,7 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
             if (t_tile < t_sorted) sorted = false;
         }
     }
-    int rc;
-    if constexpr (sizeof(T) == sizeof(A)) {
-        const bool tiles = (option_value_path() == 3 || (option_value_path() == 0 && sorted && option_tile_path())) &&
-                           tiles_applicable<T>(p, d, workspace, workspace_bytes);
-        rc = tiles ? run_value_tiles<T>(p, d, workspace, stream)
-                   : sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
-    } else {
-        rc = sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
-    }
+    const int rc = sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
     if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }
@@ -590,7 +514,7 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
         const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
         rc = dispatch_gather<T, 1>(p, vec_ok, sample_stream);
         if (rc) {
-            set_error("backward (grad_loc/grad_attn) launch failed: %s", hipGetErrorString((hipError_t)rc));
+            if (rc > 0) set_error("backward (grad_loc/grad_attn) launch failed: %s", hipGetErrorString((hipError_t)rc));
             if (forked) (void)side_stream_join(stream);
             return rc;
         }

@@ -8,6 +8,7 @@
 // (msda_triton_amd/functional.py) and the same tests cover both routes.
 // Reference counterpart: _TritonMultiscaleDeformableAttentionFunction, src/msda_triton/frontend.py:108-142.
 #include <torch/extension.h>
+#include <torch/csrc/autograd/functions/basic_ops.h>
 
 #include <c10/hip/HIPStream.h>
 
@@ -49,6 +50,24 @@ void check_rc(int rc, const char *what)
     if (rc == 0) return;
     TORCH_CHECK_VALUE(rc > 0, what, ": rejected arguments (", rc, "): ", msda_last_error());
     TORCH_CHECK(false, what, ": HIP error ", rc, ": ", msda_last_error());
+}
+
+// torch.autograd.function.once_differentiable (frontend.py:130 of the reference) for a C++ Function: when the
+// backward itself runs under grad mode (create_graph=True) and was handed a differentiable gradient, the results
+// are routed through a DelayedError node, so a second differentiation raises instead of silently treating them as
+// constants.
+torch::autograd::variable_list once_differentiable(const torch::autograd::variable_list &grads_in,
+                                                   torch::autograd::variable_list outs)
+{
+    if (!at::GradMode::is_enabled()) return outs;
+    bool any = false;
+    for (const auto &g : grads_in) any = any || (g.defined() && g.requires_grad());
+    if (!any) return outs;
+    for (auto &o : outs)
+        if (o.defined()) o = o.detach().requires_grad_(true);
+    auto err = std::make_shared<torch::autograd::DelayedError>(
+        "trying to differentiate twice a function that was marked with @once_differentiable", (int64_t)outs.size());
+    return (*err)(std::move(outs));
 }
 
 void *current_stream(const at::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
@@ -107,8 +126,8 @@ public:
                               align_corners ? 1 : 0, want_value ? ws.data_ptr() : nullptr, ws_bytes, current_stream(img)),
                      "msda_bwd");
         }
-        return {g_img, at::Tensor(), ctx->needs_input_grad(2) ? g_pts : at::Tensor(),
-                ctx->needs_input_grad(3) ? g_att : at::Tensor(), at::Tensor(), at::Tensor()};
+        return once_differentiable(grads, {g_img, at::Tensor(), ctx->needs_input_grad(2) ? g_pts : at::Tensor(),
+                                           ctx->needs_input_grad(3) ? g_att : at::Tensor(), at::Tensor(), at::Tensor()});
     }
 };
 
@@ -167,8 +186,9 @@ public:
                                     current_stream(img)),
                      "msda_bwd_fused");
         }
-        return {g_img, at::Tensor(), ctx->needs_input_grad(2) ? g_proj : at::Tensor(),
-                ctx->needs_input_grad(3) ? g_ref_part.sum(2) : at::Tensor(), at::Tensor(), at::Tensor()};
+        return once_differentiable(grads, {g_img, at::Tensor(), ctx->needs_input_grad(2) ? g_proj : at::Tensor(),
+                                           ctx->needs_input_grad(3) ? g_ref_part.sum(2) : at::Tensor(), at::Tensor(),
+                                           at::Tensor()});
     }
 };
 

@@ -9,17 +9,20 @@
 //
 //   K1 count    (plane, query slice j): histogram of the slice's samples over the plane's cells, kept in LDS
 //               (ds_add_u32), written out as part[plane][j][cell]
-//   K2a total   off[cell] = sum_j part[j][cell]                       (all cells of all planes in parallel)
-//   K2b scan    per plane, in LDS: off = exclusive_scan(off); per pixel: the four incident cell lists
-//               (start, length), chunks = max(1, ceil(n / kChunk)); work items (pixel, chunk) by a second scan
-//   K3 place    (plane, j): cursor[cell] = off[cell] + sum_{j'<j} part[j'][cell] in LDS; every sample ->
+//   K2a total   per cell: records in the cell (sum over the slices), part[j][cell] -> slice j's first slot inside
+//               the cell's list; per block of 256 cells: (records, work items)
+//   K2b scan    per block of 256 cells: base = sums of the preceding blocks, exclusive scan inside the block:
+//               off[cell] = first record, cellitem[cell] = first work item; a *work item* is a window of <= kChunk
+//               records of ONE cell (first record, count, continuation / last flags, cell)
+//   K3 place    (plane, j): cursor[cell] = off[cell] + part[j][cell] in LDS; every sample ->
 //               entries[cursor[cell]++] = {q, dx, dy, a}
-//   K4 gather   one G-lane group per work item: walk its window of the pixel's four cell lists (as one
-//               virtual list), G entries at a time: each lane fetches one record and turns it into
-//               (q, a*fx*fy); the group passes these lane to lane, issues the grad_out row loads (16 bytes per
-//               lane, the forward's gather shape) back to back and FMAs into registers; single-chunk pixels
-//               store their grad_value row directly, multi-chunk pixels park a partial row in scratch
-//   K5 finish   pixels with several chunks: sum their partial rows in chunk order, store
+//   K4 gather   one G-lane group per work item, G records at a time: each lane fetches one record and turns it
+//               into (grad_out row offset, four corner weights); the group issues the grad_out row loads (16 bytes
+//               per lane, ONE load per sample) back to back and FMAs each row into four corner accumulators.
+//               Items of one cell inside a workgroup are summed through LDS, x-neighbouring one-item cells share
+//               rows; the leaders store 4 (or 2) partial rows scratch[item][corner]
+//   K5 finish   per pixel: sum the partial rows of its four incident cells (corner 00 of cell (x, y), 01 of
+//               (x-1, y), 10 of (x, y-1), 11 of (x-1, y-1)) in a fixed order, store the grad_value row
 //
 // Every grad_value row is written exactly once by plain stores (no memset); hot pixels of coarse
 // levels are split into kChunk-entry work items so the load stays balanced whatever the sampling
@@ -102,7 +105,9 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
     int *s_cell = reinterpret_cast<int *>(msda_smem + sizeof(LevelTab));
     load_level_table(tab, p.shapes, p.L);
     __syncthreads();
-    const int ncells = plane_cells(*tab, p.L);
+    // the workspace was sized on the host from I alone (nc_cap = 2 I + 2 L); shapes that disagree with I (or
+    // zero-sized levels) must not push the cell tables past it: cells beyond the capacity are dropped
+    const int ncells = min(plane_cells(*tab, p.L), p.nc_cap);
     const int cap = p.cell_cap;
     if constexpr (!PLACE)
         if (threadIdx.x == 0) p.ws_meta[0] = ncells;  // (every workgroup writes the same value) for the scan kernels
@@ -563,9 +568,13 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
     const int y = rel / w, x = rel - y * w;
     const int c11 = tab.cstart[l] + y * cw + x;  // cell (x-1, y-1)
     const int *cellitem = p.ws_cellitem + (size_t)pair * (p.nc_cap + 1);
-    // item ranges of the cells (x-1,y-1), (x,y-1) | (x-1,y), (x,y): consecutive cell ids, consecutive item ranges
-    const int t0 = cellitem[c11], t1 = cellitem[c11 + 1], t2 = cellitem[c11 + 2];
-    const int u0 = cellitem[c11 + cw], u1 = cellitem[c11 + cw + 1], u2 = cellitem[c11 + cw + 2];
+    // item ranges of the cells (x-1,y-1), (x,y-1) | (x-1,y), (x,y): consecutive cell ids, consecutive item ranges.
+    // A pixel the shapes tensor does not describe (sum h*w != I), or one whose cells were dropped for lack of
+    // workspace, has no cells: all ranges empty, the row is stored as zeros.
+    const bool in_tab = y < tab.h[l] && c11 + cw + 2 <= min(plane_cells(tab, p.L), p.nc_cap);
+    const int t0 = in_tab ? cellitem[c11] : 0, t1 = in_tab ? cellitem[c11 + 1] : 0, t2 = in_tab ? cellitem[c11 + 2] : 0;
+    const int u0 = in_tab ? cellitem[c11 + cw] : 0, u1 = in_tab ? cellitem[c11 + cw + 1] : 0,
+              u2 = in_tab ? cellitem[c11 + cw + 2] : 0;
     const A *src = static_cast<const A *>(p.ws_scratch) + (size_t)pair * p.it_cap * 4 * p.D;
     // the plane's partial rows through a buffer descriptor: an offset of 0x80000000 is out of range and reads 0,
     // which is how an empty cell contributes nothing without a branch

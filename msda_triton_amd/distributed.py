@@ -316,6 +316,12 @@ def row_sharded_multiscale_deformable_attention(
                                                   att_rows[at:at + n].unsqueeze(0), padding_mode, align_corners)
             pieces.append(out.reshape(n, H, D))
             at += n
+    if not segs:
+        # empty shard (more ranks than rows): still run the operator on zero rows, so that this rank's graph reaches
+        # `img` and its _ValueGradSync backward joins the grad_value collective the other ranks are waiting in
+        out = multiscale_deformable_attention(img[:1], img_shapes, pts_rows[:0].unsqueeze(0), att_rows[:0].unsqueeze(0),
+                                              padding_mode, align_corners)
+        pieces.append(out.reshape(0, H, D))
     if r1 - r0 < per:  # short / empty trailing shard: pad so the all-gather is regular
         pieces.append(img.new_zeros((per - (r1 - r0), H, D)))
     local = pieces[0] if len(pieces) == 1 else torch.cat(pieces, 0)

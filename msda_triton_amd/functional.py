@@ -65,6 +65,15 @@ def _shapes_i64(img_shapes: torch.Tensor) -> torch.Tensor:
     return img_shapes.to(torch.int64).contiguous()  # stays on the device: no host sync
 
 
+def _check_devices(*tensors: torch.Tensor) -> torch.device:
+    """All tensors must live on ONE gpu (reference: frontend.py:93-95).  Raised before any ``data_ptr()`` is handed
+    to the library: a host or foreign-device pointer would otherwise fault inside the kernel."""
+    devices = [t.device for t in tensors]
+    if any(d.type != "cuda" for d in devices) or any(d != devices[0] for d in devices):
+        raise ValueError(f"Expected all inputs to be on one gpu, but got {devices}.")
+    return devices[0]
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _FUSED_LP_LIMIT: dict = {}  # (D, element size) -> msda_fused_lp_limit
 _WS_BYTES: dict = {}  # (B, I, H, D, Q, L, P, elem, option epoch) -> msda_bwd_workspace_bytes
@@ -150,6 +159,7 @@ class KernelTimer:
 def msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners) -> torch.Tensor:
     """Allocate ``out`` and enqueue the forward kernel on the current stream (no host sync)."""
     B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
+    _check_devices(img, img_shapes, sampling_points, attention_weights)
     pad = _padding_code(padding_mode)
     suf = _SUFFIX[img.dtype]
     img, sampling_points, attention_weights = img.contiguous(), sampling_points.contiguous(), attention_weights.contiguous()
@@ -179,6 +189,7 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
     so they are not pre-zeroed.
     """
     B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
+    _check_devices(img, img_shapes, sampling_points, attention_weights, out_grad)
     pad = _padding_code(padding_mode)
     suf = _SUFFIX[img.dtype]
     img, sampling_points, attention_weights = img.contiguous(), sampling_points.contiguous(), attention_weights.contiguous()
@@ -269,9 +280,7 @@ def hip_multiscale_deformable_attention(
         raise ValueError(
             "`img`, `sampling_points` and `attention_weights` should share one dtype, but got "
             f"{img.dtype}, {sampling_points.dtype}, {attention_weights.dtype}.")
-    devices = [t.device for t in (img, img_shapes, sampling_points, attention_weights)]
-    if any(d.type != "cuda" for d in devices) or any(d != devices[0] for d in devices):
-        raise ValueError(f"Expected all inputs to be on one gpu, but got {devices}.")
+    _check_devices(img, img_shapes, sampling_points, attention_weights)
     _padding_code(padding_mode)
     if torch.compiler.is_compiling():  # traced by torch.compile / export: use the registered custom ops
         from .compile_op import compiled_multiscale_deformable_attention
@@ -325,6 +334,7 @@ def msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, al
         raise ValueError(f"`reference_points` should have the last dim either 2 or 4, but got {ref_dim}.")
     if tuple(img_shapes.shape) != (L, 2):
         raise ValueError(f"`img_shapes` should be [{L}, 2], but got {tuple(img_shapes.shape)}.")
+    _check_devices(img, img_shapes, proj, reference_points)
     pad = _padding_code(padding_mode)
     suf = _SUFFIX[img.dtype]
     img, proj, reference_points = img.contiguous(), proj.contiguous(), reference_points.contiguous()
@@ -353,6 +363,7 @@ def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, paddin
     B, I, H, D = img.shape
     _, Q, _, L, P, _ = proj.shape
     ref_dim = reference_points.shape[-1]
+    _check_devices(img, img_shapes, proj, reference_points, out_grad)
     pad = _padding_code(padding_mode)
     suf = _SUFFIX[img.dtype]
     img, proj, reference_points = img.contiguous(), proj.contiguous(), reference_points.contiguous()
@@ -436,6 +447,12 @@ class _HipFusedModuleCoreFunction(Function):
 def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, align_corners) -> torch.Tensor:
     """``multiscale_deformable_attention(img, img_shapes, *module_sampling_inputs(proj, ...))`` — on GPU tensors
     with the prologue fused into the forward kernel; on host tensors exactly that composition."""
+    if img.device.type == "cuda" and img_shapes.device != img.device:
+        # the level table is a handful of integers: follow `img` (the reference's module accepts a host-resident
+        # img_shapes next to GPU tensors through its fallback, frontend.py:170-172)
+        img_shapes = img_shapes.to(img.device)
+    if img.device.type == "cuda":
+        _check_devices(img, proj, reference_points)
     if img.device.type == "cuda" and img.dtype in VALID_DTYPES and proj.dtype == img.dtype and \
             reference_points.dtype == img.dtype and not torch.compiler.is_compiling():
         pad = _padding_code(padding_mode)

@@ -5,12 +5,13 @@ Imports /root/reference/src/msda_triton/frontend.py:native_multiscale_deformable
 (the reference's CPU path, frontend.py:15-68) and records, for a matrix of small cases
 and every (padding_mode, align_corners) mode: the inputs, the forward output, a grad_out
 and the three gradients PyTorch autograd produces through the reference function.
-Also records digests (sum / abs-sum / 512 strided samples) of the reference's outputs on
-two BASELINE.json-sized workloads whose inputs come from msda_triton_amd.synth.
+Also records digests (sum / abs-sum / 512 strided samples) of the reference's outputs on the
+BASELINE.json-sized workloads (c1, c2 at Q = 1k / 5k / 10k, c4, and the c3 encoder shape in fp32)
+whose inputs come from msda_triton_amd.synth.
 
 The reference never travels to the GPU box; only the .npz files written here do.
 
-    cd /root/repo && python tests/golden/make_golden.py
+    cd /root/repo && python tests/golden/make_golden.py [small] [digests]     (default: both)
 """
 import importlib.metadata as _md
 import os
@@ -95,9 +96,7 @@ def small_cases():
     }, rng
 
 
-def main():
-    torch.manual_seed(0)
-    torch.set_num_threads(8)
+def write_small_cases():
     cases, rng = small_cases()
     for name, (levels, B, Q, H, D, P, gen) in cases.items():
         L = len(levels)
@@ -122,8 +121,17 @@ def main():
             np.savez_compressed(path, **rec)
             print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
+
+# (workload, sampling-point range): c3 runs in fp32 here (the reference's CPU path is numerically broken in
+# bf16 for levels > 2048 px); the bf16 GPU tests compare against these digests with bf16 tolerances.
+DIGEST_CASES = (("c1_readme", (0.0, 1.0)), ("c2_q1k", (0.0, 1.0)), ("c1_readme", (-0.25, 1.25)),
+                ("c2_q5k", (0.0, 1.0)), ("c2_q10k", (0.0, 1.0)), ("c4_gdino_dec", (0.0, 1.0)),
+                ("c4_gdino_dec", (-0.25, 1.25)), ("c3_ddetr_enc", (0.0, 1.0)))
+
+
+def write_digests():
     # full-size digests: inputs are regenerated from synth on the checking side
-    for wl_name, pts_range in (("c1_readme", (0.0, 1.0)), ("c2_q1k", (0.0, 1.0)), ("c1_readme", (-0.25, 1.25))):
+    for wl_name, pts_range in DIGEST_CASES:
         wl = synth.WORKLOADS[wl_name]
         d = synth.make_inputs_torch(wl, "cpu", seed=0, dtype=torch.float32,
                                     loc_lo=pts_range[0], loc_hi=pts_range[1])
@@ -141,6 +149,16 @@ def main():
         path = os.path.join(HERE, f"digest_{wl_name}_{tag}_f32.npz")
         np.savez_compressed(path, **rec)
         print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    what = set(sys.argv[1:]) or {"small", "digests"}
+    if "small" in what:
+        write_small_cases()
+    if "digests" in what:
+        write_digests()
 
 
 if __name__ == "__main__":

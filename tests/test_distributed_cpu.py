@@ -136,6 +136,8 @@ def _row_worker(rank, world, port, batch, q_total, sharded_inputs, value_sync, g
     (2, 3, 5, True, "all_reduce", "slice"),        # rank boundaries inside a batch element
     (2, 3, 4, False, "none", "reduce_scatter"),
     (3, 2, 5, True, "owners", "slice"),            # the middle rank belongs to two owner groups
+    (3, 1, 2, False, "all_reduce", "slice"),       # more ranks than rows: rank 2's shard is EMPTY, it must still join
+    (3, 1, 2, True, "owners", "slice"),            #   the grad_value collective (hang)
 ])
 def test_row_shard_gloo(world, batch, q_total, sharded_inputs, value_sync, grad_sync):
     ret = mp.get_context("spawn").Manager().dict()

@@ -89,6 +89,9 @@ def test_hip_matches_reference_golden(path):
 
 @pytest.mark.parametrize("path", digest_cases(), ids=case_id)
 def test_hip_matches_reference_digest_fullsize(path):
+    """BASELINE-sized workloads (c1, c2 at Q = 1k / 5k / 10k, c4, the c3 shape in fp32) against digests of the
+    REFERENCE's outputs (tests/golden/make_golden.py): 512 strided samples at the small cases' tolerances
+    (out 1e-4, the north-star bar) plus sum / abs-sum of every tensor."""
     from msda_triton_amd import synth
     z = np.load(path)
     wl = synth.WORKLOADS[str(z["workload"])]
@@ -99,8 +102,12 @@ def test_hip_matches_reference_digest_fullsize(path):
         res = run_hip(f32["value"], f32["shapes"], f32["loc"], f32["attn"], f32["grad_out"], pm, ac)
         for nm, arr in zip(("out", "grad_value", "grad_loc", "grad_attn"), res):
             dg = synth.digest(arr)
-            np.testing.assert_allclose(dg["samples"], z[f"{nm}_{k}_samples"],
-                                       atol=2e-3 if nm == "grad_value" else 5e-4, rtol=1e-3, err_msg=f"{nm} {k}")
+            got, want = dg["samples"], z[f"{nm}_{k}_samples"].astype(np.float64)
+            if nm == "grad_loc":  # not comparable where the pixel coordinate sits on a grid kink (conftest.kink_mask)
+                kinks = kink_mask(f32["loc"], f32["shapes"], ac).reshape(-1)[::dg["step"]][:got.size]
+                got, want = np.where(kinks, 0, got), np.where(kinks, 0, want)
+            tol = FWD_TOL[torch.float32] if nm == "out" else BWD_TOL[torch.float32]
+            np.testing.assert_allclose(got, want, err_msg=f"{nm} {k}", **tol)
             scale = max(1.0, float(z[f"{nm}_{k}_abs_sum"]))
             assert abs(dg["sum"] - float(z[f"{nm}_{k}_sum"])) <= 1e-4 * scale, (nm, k)
             assert abs(dg["abs_sum"] - float(z[f"{nm}_{k}_abs_sum"])) <= 1e-4 * scale, (nm, k)
@@ -390,6 +397,40 @@ def test_errors_match_reference_contract():
                                             "zeros", False)
 
 
+def test_launchers_and_module_core_validate_devices():
+    """A host or foreign-device pointer must never reach a kernel: the launcher pair and the fused
+    module core raise ValueError for host tensors (reference: frontend.py:93-95), and the nn.Module accepts a
+    host-resident img_shapes next to GPU tensors (reference: works through its fallback)."""
+    from msda_triton_amd.functional import (fused_module_core, msda_hip_bwd, msda_hip_bwd_fused, msda_hip_fwd,
+                                            msda_hip_fwd_fused)
+    ops = _ops()
+    c = rand_case(np.random.default_rng(8), 1, 6, 2, 8, [(4, 3), (2, 2)], 2)
+    v, l, a, g = (torch.from_numpy(c[k]).to(DEV) for k in ("value", "loc", "attn", "grad_out"))
+    s = torch.from_numpy(c["shapes"]).to(DEV)
+    proj = torch.randn(1, 6, 2, 2, 2, 3, device=DEV)
+    ref = torch.rand(1, 6, 2, device=DEV)
+    with pytest.raises(ValueError):
+        msda_hip_fwd(v, s.cpu(), l, a, "zeros", False)
+    with pytest.raises(ValueError):
+        msda_hip_fwd(v, s, l.cpu(), a, "zeros", False)
+    with pytest.raises(ValueError):
+        msda_hip_bwd(g.cpu(), v, s, l, a, "zeros", False)
+    with pytest.raises(ValueError):
+        msda_hip_fwd_fused(v, s.cpu(), proj, ref, "zeros", False)
+    with pytest.raises(ValueError):
+        msda_hip_bwd_fused(g, v, s, proj, ref.cpu(), "zeros", False)
+    with pytest.raises(ValueError):
+        fused_module_core(v, s, proj.cpu(), ref, "zeros", False)
+    want = fused_module_core(v, s, proj, ref, "zeros", False)
+    torch.testing.assert_close(fused_module_core(v, s.cpu(), proj, ref, "zeros", False), want, atol=0, rtol=0)
+    torch.manual_seed(1)
+    m = ops.MultiscaleDeformableAttention(16, 16, 2, 2, 2, "border", True).to(DEV)
+    img, q = torch.randn(1, 16, 16, device=DEV), torch.randn(1, 5, 16, device=DEV)
+    for coords in (2, 4):
+        r = torch.rand(1, 5, coords, device=DEV)
+        torch.testing.assert_close(m(img, s.cpu(), q, r), m(img, s, q, r), atol=0, rtol=0)
+
+
 @pytest.mark.parametrize("td", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 def test_autocast_runs_in_fp32(td):
     """Reference: custom_fwd(cast_inputs=float32) (frontend.py:111) and tests/test_msda.py:171-182."""
@@ -473,7 +514,7 @@ def test_graph_capture_replays():
 # ------------------------------------------------------------------------------------------
 # backward grad_value: both implementations, and the shapes that stress the sorted gather
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("value_path", [2, 1, 3], ids=["sorted_gather", "lds_tiles", "tile_bins"])
+@pytest.mark.parametrize("value_path", [2, 1], ids=["sorted_gather", "lds_tiles"])
 @pytest.mark.parametrize("pm,ac", MODES, ids=[mode_key(*m) for m in MODES])
 def test_grad_value_both_paths_and_hot_pixels(oracle, value_path, pm, ac):
     """Every query samples the same few pixels (lists far longer than one work-item chunk, so pixels are
@@ -493,7 +534,7 @@ def test_grad_value_both_paths_and_hot_pixels(oracle, value_path, pm, ac):
 @pytest.mark.parametrize("D,Q,td", [(32, 3000, torch.float32), (512, 700, torch.float32), (32, 3000, torch.float64),
                                     (32, 3000, torch.bfloat16)],
                          ids=["f32_d32", "f32_d512_two_channel_chunks", "f64_d32", "bf16_d32"])
-@pytest.mark.parametrize("value_path", [2, 3], ids=["sorted_gather", "tile_bins"])
+@pytest.mark.parametrize("value_path", [2], ids=["sorted_gather"])
 def test_grad_value_cell_flood_spans_gather_workgroups(oracle, D, Q, td, value_path):
     """A 1x1 level: every sample falls into one of four cells, so a cell's list is cut into far more work items
     than one gather workgroup holds — items are merged inside workgroups, the finish kernel adds one row per
@@ -543,7 +584,7 @@ def test_level_staging_option_gives_same_results():
     d = synth.make_inputs_torch(synth.WORKLOADS["c1_readme"], DEV, seed=6, loc_lo=-0.1, loc_hi=1.1)
     res = []
     try:
-        for kb in (0, 48):
+        for kb in (0, 9, 48):   # 9 KiB: the coarsest level only; 48 KiB: the two coarsest
             _lib.set_option("stage_kb", kb)
             v, l, a = (d[k].clone().requires_grad_(True) for k in ("value", "loc", "attn"))
             o = ops.multiscale_deformable_attention(v, d["shapes"], l, a, "zeros", False)
@@ -551,8 +592,9 @@ def test_level_staging_option_gives_same_results():
             res.append((o.detach(), l.grad, a.grad))
     finally:
         _lib.set_option("stage_kb", 0)
-    for x, y in zip(res[0], res[1]):
-        torch.testing.assert_close(x, y, atol=1e-6, rtol=1e-6)
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            torch.testing.assert_close(x, y, atol=1e-6, rtol=1e-6)
 
 
 def test_c_abi_rejects_bad_arguments_without_launching():
@@ -723,7 +765,7 @@ def test_fused_backward_partial_needs_and_large_lp_fallback():
     assert torch.isfinite(pr.grad).all()
 
 
-@pytest.mark.parametrize("value_path", [2, 3], ids=["sorted_gather", "tile_bins"])
+@pytest.mark.parametrize("value_path", [2, 1], ids=["sorted_gather", "lds_tiles"])
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_random_shapes_against_oracle(oracle, seed, value_path):
     """Differential test over random shapes / modes / coordinate ranges (fixed seeds), with the sorted-gather

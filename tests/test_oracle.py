@@ -41,8 +41,13 @@ def test_oracle_matches_reference_digest_fullsize(oracle, path):
         for nm, arr in (("out", out), ("grad_value", gv), ("grad_loc", gl), ("grad_attn", ga)):
             dg = synth.digest(arr)
             assert dg["step"] == int(z[f"{nm}_{k}_step"])
-            np.testing.assert_allclose(dg["samples"], z[f"{nm}_{k}_samples"], atol=2e-3 if nm == "grad_value" else 5e-4,
-                                       rtol=1e-3, err_msg=f"{nm} {k} samples")
+            got, want = dg["samples"], z[f"{nm}_{k}_samples"].astype(np.float64)
+            if nm == "grad_loc":
+                kinks = kink_mask(f32["loc"], f32["shapes"], ac).reshape(-1)[::dg["step"]][:got.size]
+                got, want = np.where(kinks, 0, got), np.where(kinks, 0, want)
+            # out at the north-star bar (1e-4 fp32); gradients at the reference's test tolerance (test_msda.py:19-26)
+            tol = dict(atol=1e-4, rtol=1e-3) if nm == "out" else dict(atol=1e-3, rtol=1e-2)
+            np.testing.assert_allclose(got, want, err_msg=f"{nm} {k} samples", **tol)
             scale = max(1.0, float(z[f"{nm}_{k}_abs_sum"]))
             assert abs(dg["sum"] - float(z[f"{nm}_{k}_sum"])) <= 1e-4 * scale, (nm, k)
             assert abs(dg["abs_sum"] - float(z[f"{nm}_{k}_abs_sum"])) <= 1e-4 * scale, (nm, k)
