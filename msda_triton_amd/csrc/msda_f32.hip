@@ -7,7 +7,7 @@ MSDA_DEFINE_ENTRY_POINTS(f32, float)
 extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_bytes_impl(
     int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int elem_size)
 {
-    return (int64_t)msda::sorted_ws_layout(B, I, H, D, Q, L, P, elem_size == 8 ? 8 : 4).total;
+    return (int64_t)msda::sorted_ws_layout(B, I, H, D, Q, L, P, elem_size == 8 ? 8 : 4, (size_t)elem_size).total;
 }
 
 // largest L*P the fused-prologue kernels (msda_fwd_fused / msda_bwd_fused) take for this head dimension and

@@ -52,18 +52,15 @@ struct Params {
     int nranges;   // pixel ranges
     int range_px;  // pixels per range
     // sorted (gather-formulated) grad_value path: caller-provided workspace, see msda_value_sorted.hpp
-    int *ws_part;       // [pairs][nsplit][nc_cap]  per-slice cell counts, then each slice's first slot per cell
-    int *ws_off;        // [pairs][nc_cap+1]  exclusive offsets of the cell lists
-    int *ws_cellitem;   // [pairs][nc_cap+1]  first work item of every cell (and the plane's total behind the last cell)
-    int *ws_itemcnt;    // [pairs]            work items of the plane
-    int *ws_meta;       // [0] = cells of a plane (written by the count pass for the scan kernels)
-    int2 *ws_blocksum;  // [pairs][blocks]    per block of kBlock cells: (records, work items)
-    int4 *ws_items;     // [pairs][it_cap]    per work item: (first record, records | flags, cell, -) — a window of one cell's list
+    int *ws_part;       // [pairs][nsplit][nc_cap]   per-slice cell counts, then each slice's first slot per cell
+    int *ws_blocktot;   // [pairs][nsplit][nblk_cap] per slice and block of 256 cells: records
+    int *ws_off;        // [pairs][nc_cap+1]  first record of every cell's list (and the plane's total behind the last)
+    int *ws_total;      // [pairs]            records of the plane
+    int *ws_meta;       // [0] = cells of a plane (written by the count pass for the scan kernel)
     void *ws_entries;   // [pairs][Q*L*P]     Entry<acc>: sample records sorted by cell
-    void *ws_scratch;   // [pairs][it_cap][4][D] acc-typed partial rows: one per work item and cell corner
-    int nc_cap, it_cap;
-    int4 *ws_chunks;    // tile path: global chunk list (pair, bin, first record, records | multi flag); ws_itemcnt = its length
-    int nb_cap, ch_cap; // tile path: bins per plane (capacity), chunk list capacity
+    void *ws_scratch;   // [pairs][I][4][D]   acc-typed partial rows: slot k of a pixel = what the cell having it as corner k left
+    void *ws_cont;      // [pairs][cont_cap][4][D] acc-typed continuation rows: one set per gather workgroup
+    int nc_cap, nblk_cap, win_cap, cont_cap;
     int nsplit;         // query slices per plane in the count / place passes
     int cell_cap;       // cells a count / place workgroup holds in LDS at a time
 };

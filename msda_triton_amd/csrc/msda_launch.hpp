@@ -16,6 +16,7 @@ int option_xcd_map();
 int option_value_path();  // 0: auto (sorted gather for big problems, LDS tile kernel for small), 1: LDS tile kernel, 2: sorted
 int option_stage_kb();    // LDS KiB a gather workgroup may spend on staged pyramid levels (0: off)
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
+int option_gather_wg();     // threads per workgroup of the grad_value gather kernel (64 / 128 / 256)
 int option_debug();         // dev-only ablation mask
 int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream
 // fork-join helpers around a lazily created per-device side stream (msda_api.hip)
@@ -245,22 +246,32 @@ template <typename T> inline int dispatch_value(Params &p, hipStream_t stream)
 }
 
 // ---- sorted (gather-formulated) grad_value: K1..K5 of msda_value_sorted.hpp ----
-template <typename T, int VEC, int G> inline int launch_value_gather(Params &p, hipStream_t stream)
+template <typename T, int VEC, int G, int GB> inline int launch_value_gather_block(Params &p, hipStream_t stream)
 {
-    constexpr int NU = kBlock / G, NUG = kGatherItemBlock / G;
+    constexpr int NU = kBlock / G, NUG = GB / G;
     const int npairs = p.B * p.H;
     dim3 g4, g5;
-    if (!plane_grid(p, npairs, (p.it_cap + NUG - 1) / NUG, g4)) {
+    if (!plane_grid(p, npairs, (p.win_cap + NUG - 1) / NUG, g4)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G>), g4, dim3(kGatherItemBlock), 0, stream, p);
-    if (!plane_grid(p, npairs, (p.I + NU - 1) / NU, g5)) {
+    hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G, GB>), g4, dim3(GB), 0, stream, p);
+    if (!plane_grid(p, npairs, (p.I + NU * kFinishPix - 1) / (NU * kFinishPix), g5)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    hipLaunchKernelGGL((msda_value_finish_kernel<T, VEC, G>), g5, dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((msda_value_finish_kernel<T, VEC, G, GB>), g5, dim3(kBlock), 0, stream, p);
     return (int)hipGetLastError();
+}
+
+template <typename T, int VEC, int G> inline int launch_value_gather(Params &p, hipStream_t stream)
+{
+    const int want = option_gather_wg();
+    if constexpr (G <= 64)
+        if (want == 64) return launch_value_gather_block<T, VEC, G, 64>(p, stream);
+    if constexpr (G <= 128)
+        if (want == 128) return launch_value_gather_block<T, VEC, G, 128>(p, stream);
+    return launch_value_gather_block<T, VEC, G, 256>(p, stream);
 }
 
 template <typename T, int VEC> inline int dispatch_value_gather_group(Params &p, hipStream_t stream)
@@ -275,47 +286,66 @@ template <typename T, int VEC> inline int dispatch_value_gather_group(Params &p,
     }
 }
 
+// can the gather kernels use 16-byte row pieces for this call?
+template <typename T> inline bool value_vec_ok(const Params &p)
+{
+    constexpr int VECF = 16 / sizeof(T);
+    return aligned_to(p.grad_out, 16) && aligned_to(p.grad_value, 16) && (p.D % VECF) == 0;
+}
+
 template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void *workspace, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
-    const SortedWsLayout w = sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A));
+    const bool vec_ok = value_vec_ok<T>(p);
+    const SortedWsLayout w = sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), sizeof(T), vec_ok);
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     p.ws_part = reinterpret_cast<int *>(ws + w.off_part);
+    p.ws_blocktot = reinterpret_cast<int *>(ws + w.off_blocktot);
     p.ws_off = reinterpret_cast<int *>(ws + w.off_off);
-    p.ws_cellitem = reinterpret_cast<int *>(ws + w.off_cellitem);
-    p.ws_itemcnt = reinterpret_cast<int *>(ws + w.off_itemcnt);
+    p.ws_total = reinterpret_cast<int *>(ws + w.off_total);
     p.ws_meta = reinterpret_cast<int *>(ws + w.off_meta);
-    p.ws_blocksum = reinterpret_cast<int2 *>(ws + w.off_blocksum);
-    p.ws_items = reinterpret_cast<int4 *>(ws + w.off_items);
     p.ws_entries = ws + w.off_entries;
     p.ws_scratch = ws + w.off_scratch;
+    p.ws_cont = ws + w.off_cont;
     p.nc_cap = w.nc_cap;
-    p.it_cap = w.it_cap;
+    p.nblk_cap = w.nblk_cap;
+    p.win_cap = w.win_cap;
+    p.cont_cap = w.cont_cap;
     p.nsplit = w.nsplit;
-    p.cell_cap = w.nc_cap < kCellLdsInts ? w.nc_cap : kCellLdsInts;
+    // cells a count / place workgroup keeps in LDS at a time: what the LDS holds next to the level table and the
+    // per-block totals
+    {
+        const long long room = ((long long)kMaxDynLds - (long long)sizeof(LevelTab)) / 4 - w.nblk_cap;
+        long long cap = room < kCellLdsInts ? room : kCellLdsInts;
+        cap = cap / kScanCells * kScanCells;
+        if (cap < kScanCells) {
+            set_error("plane too large for the sorted grad_value pipeline");
+            return MSDA_ERR_TOO_LARGE;
+        }
+        p.cell_cap = w.nc_cap < cap ? w.nc_cap : (int)cap;
+    }
     const int npairs = p.B * p.H;
     dim3 gcell;
     if (!plane_grid(p, npairs, p.nsplit, gcell)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    const size_t cell_lds = sizeof(LevelTab) + (size_t)p.cell_cap * sizeof(int);
+    // (the count pass keeps its per-block totals behind the cell table)
+    const size_t cell_lds = sizeof(LevelTab) + ((size_t)p.cell_cap + (size_t)p.nblk_cap) * sizeof(int);
     static std::atomic<uint64_t> big_lds_count{0}, big_lds_place{0};
     allow_big_lds(msda_cell_pass_kernel<T, false>, big_lds_count);
     allow_big_lds(msda_cell_pass_kernel<T, true>, big_lds_place);
     hipLaunchKernelGGL((msda_cell_pass_kernel<T, false>), gcell, dim3(kCellBlock), cell_lds, stream, p);
-    const int64_t tot_blocks = (int64_t)((p.nc_cap + kBlock - 1) / kBlock) * npairs;
-    if (tot_blocks >= ((int64_t)1 << 31)) {
+    const int64_t scan_blocks = (int64_t)p.nblk_cap * npairs;
+    if (scan_blocks >= ((int64_t)1 << 31)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    hipLaunchKernelGGL((msda_cell_total_kernel<T>), dim3((unsigned)tot_blocks), dim3(kBlock), 0, stream, p);
-    hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)tot_blocks), dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)scan_blocks), dim3(kScanCells), 0, stream, p);
     hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     constexpr int VECF = 16 / sizeof(T);
-    const bool vec_ok = aligned_to(p.grad_out, 16) && aligned_to(p.grad_value, 16) && (p.D % VECF) == 0;
     return vec_ok ? dispatch_value_gather_group<T, VECF>(p, stream) : dispatch_value_gather_group<T, 1>(p, stream);
 }
 
@@ -431,8 +461,12 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
 {
     using A = typename Traits<T>::acc;
     const int64_t B = d.B, I = d.I, H = d.H, D = d.D, Q = d.Q, L = d.L, P = d.P;
-    bool sorted = option_value_path() != 1 && workspace != nullptr && aligned_to(workspace, 256) &&
-                  (uint64_t)workspace_bytes >= sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A)).total;
+    // the sorted pipeline's record format: 4 level bits, 24-bit biased pixel index, 32-bit slot offsets
+    const bool fits = L <= kSortedMaxLevels && I < (int64_t)kPixBias && 16 * D * (int64_t)sizeof(A) < ((int64_t)1 << 24) &&
+                      I * 4 * D * (int64_t)sizeof(A) < ((int64_t)1 << 31);
+    bool sorted = fits && option_value_path() != 1 && workspace != nullptr && aligned_to(workspace, 256) &&
+                  (uint64_t)workspace_bytes >=
+                      sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p)).total;
     if (sorted && option_value_path() == 0) {
         // Small problems: the sorted pipeline's six launches cost ~45 us before any work is done, while the
         // LDS-tile kernel is one launch whose time grows with (workgroups / 256 CUs) x (samples per plane).

@@ -8,53 +8,101 @@
 //   A sample lives in exactly one cell and touches only that cell's (up to) four corner pixels.
 //
 //   K1 count    (plane, query slice j): histogram of the slice's samples over the plane's cells, kept in LDS
-//               (ds_add_u32), written out as part[plane][j][cell]
-//   K2a total   per cell: records in the cell (sum over the slices), part[j][cell] -> slice j's first slot inside
-//               the cell's list; per block of 256 cells: (records, work items)
-//   K2b scan    per block of 256 cells: base = sums of the preceding blocks, exclusive scan inside the block:
-//               off[cell] = first record, cellitem[cell] = first work item; a *work item* is a window of <= kChunk
-//               records of ONE cell (first record, count, continuation / last flags, cell)
+//               (ds_add_u32), written out as part[plane][j][cell]; per block of 256 cells the slice's total
+//   K2 scan     per block of 256 cells, ONE launch: records per cell (sum over the slices; part[j][cell] becomes
+//               slice j's first slot inside the cell's list), base = the block totals before it, exclusive scan:
+//               off[cell] = first record of the cell's list
 //   K3 place    (plane, j): cursor[cell] = off[cell] + part[j][cell] in LDS; every sample ->
-//               entries[cursor[cell]++] = {q, dx, dy, a}
-//   K4 gather   one G-lane group per work item, G records at a time: each lane fetches one record and turns it
-//               into (grad_out row offset, four corner weights); the group issues the grad_out row loads (16 bytes
-//               per lane, ONE load per sample) back to back and FMAs each row into four corner accumulators.
-//               Items of one cell inside a workgroup are summed through LDS, x-neighbouring one-item cells share
-//               rows; the leaders store 4 (or 2) partial rows scratch[item][corner]
-//   K5 finish   per pixel: sum the partial rows of its four incident cells (corner 00 of cell (x, y), 01 of
-//               (x-1, y), 10 of (x, y-1), 11 of (x-1, y-1)) in a fixed order, store the grad_value row
+//               entries[cursor[cell]++] = {q, cell, a, dx, dy} (16 bytes, packed)
+//   K4 gather   the sorted record array is cut into WINDOWS of 64 records; one G-lane group walks one window, G
+//               records at a time: each lane fetches one record and turns it into (grad_out row offset, four corner
+//               weights, segment flags); the group issues the G grad_out row loads back to back — ONE load per
+//               sample — and FMAs each row into four corner accumulators.  A *segment* is a run of records of one
+//               cell inside one window.  When a segment ends its corner rows go to the pixels' slots
+//               scratch[pixel][corner] (streaming stores); if the next cell is the x-neighbour, the right-hand
+//               corners are carried over in registers instead (they are the neighbour's left-hand corners).
+//               Segments that continue a cell from the previous window are summed through LDS into the segment
+//               they continue (same workgroup) or leave as one "continuation" row set per workgroup.
+//   K5 finish   per pixel: its four slots (written by the cells (x,y), (x-1,y), (x,y-1), (x-1,y-1)) are 4 contiguous
+//               rows; which of them were written follows from off[] alone; plus the continuation row sets of cells
+//               longer than a workgroup's windows.  Sum in a fixed order, store the grad_value row.
 //
-// Every grad_value row is written exactly once by plain stores (no memset); hot pixels of coarse
-// levels are split into kChunk-entry work items so the load stays balanced whatever the sampling
-// distribution.  Padding semantics: "zeros" drops samples/corners outside the image; "border" clips
-// the pixel coordinate to [0, size-1] first (grid_sample), which puts the whole weight on the edge
-// pixel exactly as the reference's clamped corners do.
+// Every grad_value row is written exactly once by plain stores (no memset); the work per lane group is 64
+// records whatever the sampling distribution.  Padding semantics: "zeros" drops samples/corners outside the
+// image; "border" clips the pixel coordinate to [0, size-1] first (grid_sample), which puts the whole weight on
+// the edge pixel exactly as the reference's clamped corners do.
 #pragma once
 
 #include "msda_kernels.hpp"
 
 namespace msda {
 
-constexpr int kChunk = 64;           // entries per work item
-constexpr int kGatherItemBlock = 256; // threads per workgroup of the gather kernel (no block barriers)
-constexpr int kContFlag = 1 << 30;   // work-item record: this window continues the previous item's cell
-constexpr int kLastFlag = 1 << 29;   // work-item record: last window of its cell (kLastFlag without kContFlag: the
-                                     // cell is ONE item, and may share rows with a neighbouring one-item cell)
-constexpr int kCountMask = kLastFlag - 1;
-constexpr int kBigChunks = 16;       // cells with more work items than this have their records written by the whole block
-constexpr int kBigCells = 64;        // ... at most this many per plane (the rest falls back to the owning thread)
-constexpr int kCellBlock = 1024;     // threads of K1 / K2b / K3
-constexpr int kCellLdsInts = 36864;  // cells a workgroup keeps in LDS at a time (144 KiB)
+constexpr int kWin = 64;              // records per gather window
+constexpr int kGatherMinBlock = 64;   // smallest gather workgroup (sizes the continuation rows)
+constexpr int kCellBlock = 1024;      // threads of K1 / K3
+constexpr int kScanCells = 256;       // cells per K2 workgroup (= its thread count)
+constexpr int kCellLdsInts = 36864;   // cells a K1 / K3 workgroup keeps in LDS at a time (144 KiB)
+// record cell word: where the cell's rows go, decoded once by the place pass (the gather needs no division):
+//   bits 0-23  index of the cell's corner-00 pixel (x0, y0) inside the plane + kPixBias (virtual — possibly
+//              negative before the bias — when x0 or y0 is -1);  24-27 level;  28-31 which corners are pixels of the image
+// Two records belong to the same cell iff their words are equal (cells that alias one virtual index differ in the
+// validity bits).
+constexpr uint32_t kPixBias = 1u << 23;
+constexpr int kSortedMaxLevels = 16;  // 4 level bits (more levels: the LDS-tile kernel)
 
-template <typename A> struct alignas(16) Entry {
-    uint32_t q;
-    A dx, dy, a;
+// ------------------------------------------------------------------------------------------
+// sorted sample records.  float accumulate type: 16 bytes, the fractional offsets carried with 20 fractional bits
+// (the fp32 pixel coordinate they come from has fewer at every level wider than 8 px); double: 32 bytes, exact.
+// ------------------------------------------------------------------------------------------
+template <typename A> struct Entry;
+template <> struct alignas(16) Entry<float> {
+    uint32_t w0, w1, w2, w3;  // q | dxq[7:0] << 24,  cell word (kPixBias),  bits(a),  dxq[19:8] | dyq << 12
+    static __device__ __forceinline__ Entry pack(uint32_t q, uint32_t cellflag, float a, float dx, float dy)
+    {
+        const uint32_t dxq = min((uint32_t)(dx * 1048576.0f + 0.5f), 0xFFFFFu);
+        const uint32_t dyq = min((uint32_t)(dy * 1048576.0f + 0.5f), 0xFFFFFu);
+        Entry e;
+        e.w0 = q | (dxq << 24);
+        e.w1 = cellflag;
+        e.w2 = __builtin_bit_cast(uint32_t, a);
+        e.w3 = (dxq >> 8) | (dyq << 12);
+        return e;
+    }
+    __device__ __forceinline__ uint32_t q() const { return w0 & 0xFFFFFFu; }
+    __device__ __forceinline__ uint32_t cellflag() const { return w1; }
+    __device__ __forceinline__ float a() const { return __builtin_bit_cast(float, w2); }
+    __device__ __forceinline__ float dx() const { return (float)((w0 >> 24) | ((w3 & 0xFFFu) << 8)) * (1.0f / 1048576.0f); }
+    __device__ __forceinline__ float dy() const { return (float)(w3 >> 12) * (1.0f / 1048576.0f); }
+};
+template <> struct alignas(16) Entry<double> {
+    uint32_t qq, cf;
+    double aa, ddx, ddy;
+    static __device__ __forceinline__ Entry pack(uint32_t q, uint32_t cellflag, double a, double dx, double dy)
+    {
+        Entry e;
+        e.qq = q;
+        e.cf = cellflag;
+        e.aa = a;
+        e.ddx = dx;
+        e.ddy = dy;
+        return e;
+    }
+    __device__ __forceinline__ uint32_t q() const { return qq; }
+    __device__ __forceinline__ uint32_t cellflag() const { return cf; }
+    __device__ __forceinline__ double a() const { return aa; }
+    __device__ __forceinline__ double dx() const { return ddx; }
+    __device__ __forceinline__ double dy() const { return ddy; }
 };
 
-// sample -> (cell id inside the plane, fractional offsets).  false: the sample touches no pixel.
+__device__ __forceinline__ int plane_cells(const LevelTab &tab, int L)
+{
+    return tab.cstart[L - 1] + (tab.h[L - 1] + 1) * (tab.w[L - 1] + 1);
+}
+
+// sample -> (cell id inside the plane, record cell word, fractional offsets).  false: the sample touches no pixel.
 template <typename A>
-__device__ __forceinline__ bool sample_cell(A x, A y, int h, int w, int cstart, bool zeros, bool align, int &cell,
-                                            A &dx, A &dy)
+__device__ __forceinline__ bool sample_cell(A x, A y, int h, int w, int cstart, int start, int level, bool zeros,
+                                            bool align, int &cell, uint32_t &cellw, A &dx, A &dy)
 {
     const A W = (A)w, Hh = (A)h;
     A px, py;
@@ -78,17 +126,21 @@ __device__ __forceinline__ bool sample_cell(A x, A y, int h, int w, int cstart, 
     }
     dx = px - x0;
     dy = py - y0;
-    cell = cstart + (int)mul24((uint32_t)((int)y0 + 1), (uint32_t)(w + 1)) + ((int)x0 + 1);
+    const int ix = (int)x0, iy = (int)y0;
+    cell = cstart + (int)mul24((uint32_t)(iy + 1), (uint32_t)(w + 1)) + (ix + 1);
+    const bool xv0 = ix >= 0, xv1 = ix + 1 < w, yv0 = iy >= 0, yv1 = iy + 1 < h;
+    const uint32_t valid = (uint32_t)(xv0 && yv0) | ((uint32_t)(xv1 && yv0) << 1) | ((uint32_t)(xv0 && yv1) << 2) |
+                           ((uint32_t)(xv1 && yv1) << 3);
+    // start + iy * w + ix, biased: (iy + 1) * w is non-negative, so the 24-bit multiply applies
+    const uint32_t pixq = (uint32_t)((int)kPixBias + start + (int)mul24((uint32_t)(iy + 1), (uint32_t)w) - w + ix);
+    cellw = (pixq & 0xFFFFFFu) | ((uint32_t)level << 24) | (valid << 28);
     return true;
-}
-
-__device__ __forceinline__ int plane_cells(const LevelTab &tab, int L)
-{
-    return tab.cstart[L - 1] + (tab.h[L - 1] + 1) * (tab.w[L - 1] + 1);
 }
 
 // ------------------------------------------------------------------------------------------
 // K1 / K3: one pass over the samples of a (plane, query slice).  PLACE=false counts, true places.
+// A thread keeps ONE (level, point) slot for its whole walk (the active threads are a multiple of L*P), so the
+// level's constants sit in registers and the loop body is the coordinate math, one LDS atomic and (K3) one store.
 // ------------------------------------------------------------------------------------------
 template <typename T, bool PLACE>
 __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params p)
@@ -110,9 +162,10 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
     const int ncells = min(plane_cells(*tab, p.L), p.nc_cap);
     const int cap = p.cell_cap;
     if constexpr (!PLACE)
-        if (threadIdx.x == 0) p.ws_meta[0] = ncells;  // (every workgroup writes the same value) for the scan kernels
+        if (threadIdx.x == 0) p.ws_meta[0] = ncells;  // (every workgroup writes the same value) for K2
 
-    int *part = p.ws_part + (size_t)pair * p.nsplit * p.nc_cap;  // [slice][cell]
+    int *part = p.ws_part + ((size_t)pair * p.nsplit + slice) * p.nc_cap;  // [cell] of this slice
+    int *blocktot = p.ws_blocktot + ((size_t)pair * p.nsplit + slice) * p.nblk_cap;
     const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
     Entry<A> *entries = static_cast<Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
     // per-plane bases (64-bit, uniform) + 32-bit per-sample offsets (the host checks Q*H*L*P*2 < 2^31)
@@ -120,152 +173,158 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
     const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
     const T *attn = static_cast<const T *>(p.attn) + plane_s0;
     const int HLP = p.H * p.LP;
-    const float inv_P = 1.0f / (float)p.P;
     const int tid = threadIdx.x;
-    const int dq = kCellBlock / p.LP, dr = kCellBlock - dq * p.LP;
+
+    // fixed slot per thread: threads [0, dq * LP) are active; thread t serves slot t % LP of the queries
+    // qa + t / LP + k * dq.  (More slots than threads: each thread strides over the slots of one query at a time.)
+    const bool fixed = p.LP <= kCellBlock;
+    const int dq = fixed ? kCellBlock / p.LP : 1;
+    const int sl0 = fixed ? tid % p.LP : 0, tq = fixed ? tid / p.LP : 0;
+    const bool active = fixed && tq < dq;
 
     for (int c0 = 0; c0 < ncells; c0 += cap) {  // one trip unless the plane has more cells than fit in LDS
         const int n = min(cap, ncells - c0);
         for (int i = tid; i < n; i += kCellBlock) {
             int v = 0;
             if constexpr (PLACE)  // this slice's first slot in every cell list
-                v = off[c0 + i] + part[(size_t)slice * p.nc_cap + c0 + i];
+                v = off[c0 + i] + part[c0 + i];
             s_cell[i] = v;
         }
         __syncthreads();
-        // software-pipelined walk: the next sample's (x, y, a) are requested before this sample's entry is
-        // stored, so the wait for them never has to drain the scattered store behind it (one vmcnt queue)
-        int q = qa + tid / p.LP, sl = tid % p.LP;
-        int sidx = q * HLP + sl;  // sample offset inside the plane, advanced incrementally
-        const int d_sidx = dq * HLP + dr;
-        Pack<T, 2> xy, xy_n;
-        T at = TR::from_acc((A)0), at_n = at;
-        xy.v[0] = xy.v[1] = at;
-        xy_n = xy;
-        if (q < qb) {
-            xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
-            if constexpr (PLACE) at = attn[sidx];
-        }
-        while (q < qb) {
-            int qn = q + dq, sn = sl + dr;
-            sidx += d_sidx;
-            if (sn >= p.LP) {
-                sn -= p.LP;
-                ++qn;
-                sidx += HLP - p.LP;
-            }
-            if (qn < qb) {
-                xy_n = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
-                if constexpr (PLACE) at_n = attn[sidx];
-            }
-            const int l = div_small(sl, p.P, inv_P);
-            int cell;
-            A dx, dy;
-            if (sample_cell<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], tab->cstart[l], p.zeros,
-                               p.align, cell, dx, dy)) {
-                const unsigned rel = (unsigned)(cell - c0);
-                if (rel < (unsigned)n) {
-                    if constexpr (!PLACE) {
-                        atomicAdd(&s_cell[rel], 1);
-                    } else {
-                        const int pos = atomicAdd(&s_cell[rel], 1);
-                        Entry<A> e;
-                        e.q = (uint32_t)q;
-                        e.dx = dx;
-                        e.dy = dy;
-                        e.a = TR::to_acc(at);
-                        entries[pos] = e;  // (plain store: these partial lines must merge in L2 — streaming stores: 57 -> 202 us)
-                    }
+        auto visit = [&](int q, int cell, uint32_t cellw, A dx, A dy, A at) {
+            const unsigned rel = (unsigned)(cell - c0);
+            if (rel < (unsigned)n) {
+                if constexpr (!PLACE) {
+                    atomicAdd(&s_cell[rel], 1);
+                } else {
+                    const int pos = atomicAdd(&s_cell[rel], 1);
+                    // (plain store: these partial lines must merge in L2 — streaming stores: 57 -> 202 us)
+                    entries[pos] = Entry<A>::pack((uint32_t)q, cellw, at, dx, dy);
                 }
             }
-            q = qn;
-            sl = sn;
-            xy = xy_n;
-            at = at_n;
+        };
+        if (active) {
+            const int l = sl0 / p.P;
+            const int lw = tab->w[l], lh = tab->h[l], cs = tab->cstart[l], ps = tab->start[l];
+            int q = qa + tq;
+            int sidx = q * HLP + sl0;
+            const int d_sidx = dq * HLP;
+            if constexpr (!PLACE) {
+                // four samples in flight per thread (static ring): the walk is latency-bound, nothing is stored here
+                constexpr int RING = 4;
+                Pack<T, 2> ring[RING];
+#pragma unroll
+                for (int k = 0; k < RING; ++k) {
+                    ring[k].v[0] = ring[k].v[1] = TR::from_acc((A)0);
+                    if (q + k * dq < qb) ring[k] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * (sidx + k * d_sidx));
+                }
+                while (q < qb) {
+#pragma unroll
+                    for (int k = 0; k < RING; ++k) {
+                        const Pack<T, 2> xy = ring[k];
+                        const int qk = q + k * dq;
+                        if (qk + RING * dq < qb)
+                            ring[k] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * (sidx + (k + RING) * d_sidx));
+                        int cell;
+                        uint32_t cellw;
+                        A dx, dy;
+                        if (qk < qb && sample_cell<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), lh, lw, cs, ps, l, p.zeros,
+                                                      p.align, cell, cellw, dx, dy))
+                            visit(qk, cell, cellw, dx, dy, (A)0);
+                    }
+                    q += RING * dq;
+                    sidx += RING * d_sidx;
+                }
+            } else {
+            // software-pipelined walk: the next sample's (x, y, a) are requested before this sample's record is
+            // stored, so the wait for them never has to drain the scattered store behind it (one vmcnt queue)
+            Pack<T, 2> xy, xy_n;
+            T at = TR::from_acc((A)0), at_n = at;
+            xy.v[0] = xy.v[1] = at;
+            xy_n = xy;
+            if (q < qb) {
+                xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                at = attn[sidx];
+            }
+            while (q < qb) {
+                const int qn = q + dq;
+                sidx += d_sidx;
+                if (qn < qb) {
+                    xy_n = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                    at_n = attn[sidx];
+                }
+                int cell;
+                uint32_t cellw;
+                A dx, dy;
+                if (sample_cell<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), lh, lw, cs, ps, l, p.zeros, p.align, cell, cellw,
+                                   dx, dy))
+                    visit(q, cell, cellw, dx, dy, TR::to_acc(at));
+                q = qn;
+                xy = xy_n;
+                at = at_n;
+            }
+            }
+        } else if (!fixed) {
+            for (int q = qa; q < qb; ++q) {
+                for (int sl = tid; sl < p.LP; sl += kCellBlock) {
+                    const int l = sl / p.P;
+                    const int sidx = q * HLP + sl;
+                    const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                    int cell;
+                    uint32_t cellw;
+                    A dx, dy;
+                    if (sample_cell<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], tab->cstart[l],
+                                       tab->start[l], l, p.zeros, p.align, cell, cellw, dx, dy))
+                        visit(q, cell, cellw, dx, dy, PLACE ? TR::to_acc(attn[sidx]) : (A)0);
+                }
+            }
         }
         __syncthreads();
         if constexpr (!PLACE) {
-            for (int i = tid; i < n; i += kCellBlock) part[(size_t)slice * p.nc_cap + c0 + i] = s_cell[i];
+            // counts out; and per block of kScanCells cells this slice's total (K2 derives every block's base from
+            // them): wave sums, added into a small LDS table behind the cell table
+            int *s_blk = s_cell + cap;
+            for (int i = tid; i < p.nblk_cap; i += kCellBlock)
+                if (c0 == 0) s_blk[i] = 0;
             __syncthreads();
+            for (int i0 = 0; i0 < n; i0 += kCellBlock) {
+                const int i = i0 + tid;
+                int v = i < n ? s_cell[i] : 0;
+                if (i < n) part[c0 + i] = v;
+#pragma unroll
+                for (int m = 1; m < kWave; m <<= 1) v += __shfl_xor(v, m, kWave);
+                if ((tid & (kWave - 1)) == 0 && i < n && v != 0) atomicAdd(&s_blk[(c0 + i) / kScanCells], v);
+            }
+            __syncthreads();
+            if (c0 + cap >= ncells)  // last trip: every block of cells has its total
+                for (int i = tid; i < p.nblk_cap; i += kCellBlock) blocktot[i] = s_blk[i];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K2a / K2b: the per-plane scans, as a three-phase parallel scan over blocks of kBlock cells (a plane's cell
-// table is a few thousand to tens of thousands of entries: one workgroup per plane left 240 CUs idle).
-//   K2a  per cell: off[cell] = records in the cell (sum over the query slices) and part[j][cell] becomes slice j's
-//        first slot relative to the start of the cell's list; per block: (records, work items) -> blocksum
-//   K2b  per block: base = sum of the preceding blocks' sums (a few dozen loads), exclusive scan inside the block:
-//        off[cell] = first record, cellitem[cell] = first work item, work-item records of the block's cells
+// K2: cell lists' first records, one launch.  The base of a block of kScanCells cells is the sum of the per-slice
+// block totals K1 left (a few hundred loads), so no pass over the preceding cells and no look-back is needed.
 // ------------------------------------------------------------------------------------------
-// exclusive scan of one int over the kCellBlock threads of a workgroup (s_wave: kCellBlock / kWave ints of LDS)
-__device__ __forceinline__ int block_exclusive_scan(int v, int *s_wave, int &total)
+template <typename Tag> __global__ __launch_bounds__(kScanCells) void msda_cell_scan_kernel(const Params p)
 {
-    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const int n = __shfl_up(inc, d, kWave);
-        if (lane >= d) inc += n;
-    }
-    __syncthreads();  // s_wave may still be in use by a previous scan
-    if (lane == kWave - 1) s_wave[wid] = inc;
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < kCellBlock / kWave; ++i) {
-        const int s = s_wave[i];
-        if (i < wid) base += s;
-        tot += s;
-    }
-    total = tot;
-    return base + inc - v;
-}
-
-// exclusive scan of two ints over the kBlock threads of a workgroup (s: 2 * kBlock / kWave ints of LDS)
-__device__ __forceinline__ void block_scan2(int &a, int &b, int *s, int &tot_a, int &tot_b)
-{
-    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-    int ia = a, ib = b;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const int na = __shfl_up(ia, d, kWave), nb = __shfl_up(ib, d, kWave);
-        if (lane >= d) {
-            ia += na;
-            ib += nb;
-        }
-    }
-    __syncthreads();  // s may still be in use by a previous scan
-    if (lane == kWave - 1) {
-        s[2 * wid] = ia;
-        s[2 * wid + 1] = ib;
-    }
-    __syncthreads();
-    int base_a = 0, base_b = 0;
-    tot_a = tot_b = 0;
-#pragma unroll
-    for (int i = 0; i < kBlock / kWave; ++i) {
-        const int sa = s[2 * i], sb = s[2 * i + 1];
-        if (i < wid) {
-            base_a += sa;
-            base_b += sb;
-        }
-        tot_a += sa;
-        tot_b += sb;
-    }
-    a = base_a + ia - a;
-    b = base_b + ib - b;
-}
-
-template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_total_kernel(const Params p)
-{
-    const int per_plane = (p.nc_cap + kBlock - 1) / kBlock;
-    const int pair = blockIdx.x / per_plane, blk = blockIdx.x - pair * per_plane;
+    const int pair = blockIdx.x / p.nblk_cap, blk = blockIdx.x - pair * p.nblk_cap;
     const int nc = p.ws_meta[0];  // real cell count of a plane, left by the count pass
-    if (blk * kBlock >= nc) return;  // block-uniform
-    __shared__ int s_scan[2 * kBlock / kWave];
-    const int c = blk * kBlock + threadIdx.x;
+    if (blk * kScanCells >= nc) return;  // block-uniform
+    __shared__ int s_red[kScanCells / kWave];
+    __shared__ int s_wave[kScanCells / kWave];
+    const int t = threadIdx.x;
+    const int lane = t & (kWave - 1), wid = t / kWave;
+    // base: records in the blocks before this one (all slices)
+    int acc = 0;
+    for (int i = t; i < p.nsplit * blk; i += kScanCells) {
+        const int jj = i / blk, bb = i - jj * blk;
+        acc += p.ws_blocktot[((size_t)pair * p.nsplit + jj) * p.nblk_cap + bb];
+    }
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) acc += __shfl_xor(acc, m, kWave);
+    if (lane == 0) s_red[wid] = acc;
+    const int c = blk * kScanCells + t;
     int tot = 0;
     if (c < nc) {
         int *part = p.ws_part + (size_t)pair * p.nsplit * p.nc_cap + c;
@@ -284,113 +343,108 @@ template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_tota
             part[(size_t)j * p.nc_cap] = tot;
             tot += n;
         }
-        p.ws_off[(size_t)pair * (p.nc_cap + 1) + c] = tot;
     }
-    int ex_n = tot, ex_c = (tot + kChunk - 1) / kChunk, sum_n, sum_c;
-    block_scan2(ex_n, ex_c, s_scan, sum_n, sum_c);
-    if (threadIdx.x == 0) p.ws_blocksum[(size_t)pair * per_plane + blk] = make_int2(sum_n, sum_c);
-}
-
-template <typename Tag> __global__ __launch_bounds__(kBlock) void msda_cell_scan_kernel(const Params p)
-{
-    const int per_plane = (p.nc_cap + kBlock - 1) / kBlock;
-    const int pair = blockIdx.x / per_plane, blk = blockIdx.x - pair * per_plane;
-    const int nc = p.ws_meta[0];
-    if (blk * kBlock >= nc) return;  // block-uniform
-    __shared__ int s_scan[2 * kBlock / kWave];
-    __shared__ int s_big[1 + 4 * kBigCells];  // [0] = count, then (first item, first record, records, cell) of the cells whose
-                                              // work-item records the whole block writes
-    const int t = threadIdx.x;
-    if (t == 0) s_big[0] = 0;
-    // base of this block: the sums of the blocks before it
-    int base_n = 0, base_c = 0;
-    {
-        int an = 0, ac = 0;
-        for (int i = t; i < blk; i += kBlock) {
-            const int2 v = p.ws_blocksum[(size_t)pair * per_plane + i];
-            an += v.x;
-            ac += v.y;
-        }
-        int tn, tc;
-        block_scan2(an, ac, s_scan, tn, tc);  // (only the totals are used)
-        base_n = tn;
-        base_c = tc;
+    // exclusive scan of tot over the block
+    int inc = tot;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int nn = __shfl_up(inc, d, kWave);
+        if (lane >= d) inc += nn;
     }
-    int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
-    int *cellitem = p.ws_cellitem + (size_t)pair * (p.nc_cap + 1);
-    int4 *items = p.ws_items + (size_t)pair * p.it_cap;
-    const int c = blk * kBlock + t;
-    const int n = c < nc ? off[c] : 0;
-    const int chunks = (n + kChunk - 1) / kChunk;
-    int ex_n = n, ex_c = chunks, sum_n, sum_c;
-    block_scan2(ex_n, ex_c, s_scan, sum_n, sum_c);  // (its barriers also publish s_big[0] = 0)
-    const int beg = base_n + ex_n, first = base_c + ex_c;
-    if (c < nc) {
-        off[c] = beg;
-        cellitem[c] = first;
-        int slot = kBigCells;
-        if (chunks > kBigChunks) slot = atomicAdd(&s_big[0], 1);
-        if (chunks <= kBigChunks || slot >= kBigCells) {
-            for (int k = 0; k < chunks; ++k)
-                items[first + k] = make_int4(beg + k * kChunk,
-                                             min(kChunk, n - k * kChunk) | (k ? kContFlag : 0) | (k == chunks - 1 ? kLastFlag : 0),
-                                             c, 0);
-        } else {
-            s_big[1 + 4 * slot] = first;
-            s_big[2 + 4 * slot] = beg;
-            s_big[3 + 4 * slot] = n;
-            s_big[4 + 4 * slot] = c;
-        }
-        if (c == nc - 1) {  // the plane's totals behind the last cell
-            off[nc] = beg + n;
-            cellitem[nc] = first + chunks;
-            p.ws_itemcnt[pair] = first + chunks;
-        }
-    }
+    if (lane == kWave - 1) s_wave[wid] = inc;
     __syncthreads();
-    const int nbig = min(s_big[0], kBigCells);
-    for (int i = 0; i < nbig; ++i) {  // hot cells (coarse levels, clustered samples): records written by all threads
-        const int bfirst = s_big[1 + 4 * i], bbeg = s_big[2 + 4 * i], bn = s_big[3 + 4 * i], bcell = s_big[4 + 4 * i];
-        const int bchunks = (bn + kChunk - 1) / kChunk;
-        for (int k = t; k < bchunks; k += kBlock)
-            items[bfirst + k] = make_int4(bbeg + k * kChunk,
-                                          min(kChunk, bn - k * kChunk) | (k ? kContFlag : 0) | (k == bchunks - 1 ? kLastFlag : 0),
-                                          bcell, 0);
+    int beg = inc - tot;
+#pragma unroll
+    for (int i = 0; i < kScanCells / kWave; ++i) {
+        beg += s_red[i];
+        if (i < wid) beg += s_wave[i];
+    }
+    if (c < nc) {
+        int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
+        off[c] = beg;
+        if (c == nc - 1) {  // the plane's total behind the last cell
+            off[nc] = beg + tot;
+            p.ws_total[pair] = beg + tot;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// K4: gather.  One G-lane group per work item (a window of <= kChunk records of ONE cell), VEC channels per lane.
-// A sample's grad_out row is loaded once and blended into the cell's four corner rows; the four partial rows
-// go to scratch[item][corner].
+// K4: gather.  One G-lane group per window of kWin sorted records, VEC channels per lane.
 // ------------------------------------------------------------------------------------------
 template <typename A> struct alignas(16) CornerW {
     A w[4];  // a * {(1-dx)(1-dy), dx(1-dy), (1-dx)dy, dx dy}: corners 00, 01, 10, 11
 };
 
-template <typename T, int VEC, int G>
-__global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(const Params p)
+// streaming (nontemporal) range-checked store of VEC accumulators at a 32-bit byte offset
+template <typename A, int VEC> __device__ __forceinline__ void store_acc_pack(rsrc_t r, uint32_t off, const Pack<A, VEC> &v)
+{
+    constexpr int BYTES = (int)sizeof(A) * VEC;
+    constexpr int kNt = 2;  // aux: nt
+    if constexpr (BYTES == 16) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(RawLoad<16>::type, v), r, off, 0, kNt);
+    } else if constexpr (BYTES == 8) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(RawLoad<8>::type, v), r, off, 0, kNt);
+    } else if constexpr (BYTES == 4) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0, kNt);
+    } else {
+        static_assert(BYTES % 16 == 0, "accumulator pack must be 4, 8 or a multiple of 16 bytes");
+        struct Pieces {
+            RawLoad<16>::type p[BYTES / 16];
+        };
+        const Pieces ps = __builtin_bit_cast(Pieces, v);
+#pragma unroll
+        for (int i = 0; i < BYTES / 16; ++i) __builtin_amdgcn_raw_buffer_store_b128(ps.p[i], r, off + 16u * i, 0, kNt);
+    }
+}
+
+// N consecutive 32-bit LDS words (N = 4 or 8, 16-byte aligned) with 16-byte reads
+template <int N> __device__ __forceinline__ void lds_read_u32s(const uint32_t *src, uint32_t (&dst)[N])
+{
+    static_assert(N == 4 || N == 8, "4 or 8 words");
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + 4 * i);
+        dst[4 * i] = v.x;
+        dst[4 * i + 1] = v.y;
+        dst[4 * i + 2] = v.z;
+        dst[4 * i + 3] = v.w;
+    }
+}
+
+constexpr uint32_t kSegStart = 1u;  // first record of a segment (a new cell, or the window's first record)
+constexpr uint32_t kSegCarry = 2u;  // ... and the cell is the right-hand x-neighbour of the previous record's cell
+
+template <typename T, int VEC, int G, int GB>
+__global__ __launch_bounds__(GB) void msda_value_gather_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
+    constexpr int kGatherItemBlock = GB;  // threads per workgroup
     constexpr int NU = kGatherItemBlock / G;
     constexpr int UB = G < 8 ? G : 8;  // row loads in flight per lane
-    const int slots = (p.it_cap + NU - 1) / NU;
+    const int slots = (p.win_cap + NU - 1) / NU;
     int pair, slot;
     if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
-    const int nitems = p.ws_itemcnt[pair];
-    if (slot * NU >= nitems) return;  // block-uniform
+    const int N = p.ws_total[pair];  // records of the plane
+    if ((long long)slot * NU * kWin >= N) return;  // block-uniform
     const int tid = threadIdx.x;
     const int unit = tid / G, j = tid % G;
-    const int item = slot * NU + unit;
-    const bool valid = item < nitems;  // idle groups still take part in the block barriers below
+    const int win = slot * NU + unit;
+    const int r0 = win * kWin;
+    const int count = max(0, min(kWin, N - r0));  // idle groups (count == 0) still take part in the block barriers
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int gbase = tid - j;
 
+    __shared__ LevelTab tab;
+    __shared__ uint32_t s_wstep[kSortedMaxLevels];  // bytes between the slots of vertically adjacent pixels, per level
     __shared__ CornerW<A> s_w[kGatherItemBlock];
-    __shared__ uint32_t s_q[kGatherItemBlock];
-    __shared__ __attribute__((aligned(32))) A s_rows[kGatherItemBlock * 4 * VEC];  // [unit][corner][G * VEC]: partial rows of continuation items
-    __shared__ int s_cont[NU];
+    __shared__ __attribute__((aligned(32))) uint32_t s_q[kGatherItemBlock];     // grad_out row byte offset (0x80000000: past the end, reads 0)
+    __shared__ __attribute__((aligned(32))) uint32_t s_flag[kGatherItemBlock];  // kSegStart | kSegCarry
+    __shared__ uint32_t s_cellw[kGatherItemBlock];  // cell word of the record
+    __shared__ __attribute__((aligned(32))) A s_rows[kGatherItemBlock * 4 * VEC];  // [unit][corner][G * VEC]: parked continuation rows
+    __shared__ int s_cont[NU];   // the unit's first segment continues the previous window's cell
+    __shared__ int s_pure[NU];   // ... and is the unit's only segment
 
     const Entry<A> *entries = static_cast<const Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
     const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
@@ -399,39 +453,28 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
     const rsrc_t rs_go = make_rsrc(gout, (uint32_t)(((size_t)p.Q * p.H * p.D - (size_t)h * p.D) * sizeof(T)));
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
 
-    int start = 0, count = 0;  // valid items: 1 <= count <= kChunk
-    bool follower = false;     // this item continues the cell of the previous item of the same workgroup
-    // One-item cells that are neighbours in x AND in this workgroup share rows: the right one takes over the left
-    // one's right-hand corners (its corner 01 is the neighbour's 00, its 11 the neighbour's 10), so a cell then
-    // leaves two rows instead of four.  The finish kernel derives the same predicate from the item indices.
-    bool give_right = false, take_left = false;
-    if (valid) {
-        const int4 *recs = p.ws_items + (size_t)pair * p.it_cap;
-        const int4 rec = recs[item];
-        const int4 rec_l = recs[max(item - 1, 0)], rec_r = recs[min(item + 1, nitems - 1)];  // same round trip
-        start = rec.x;
-        count = rec.y & kCountMask;
-        follower = (rec.y & kContFlag) != 0 && unit != 0;
-        auto single = [](const int4 &r) { return (r.y & (kContFlag | kLastFlag)) == kLastFlag; };
-        give_right = unit + 1 < NU && item + 1 < nitems && single(rec) && single(rec_r) && rec_r.z == rec.z + 1;
-        take_left = unit > 0 && single(rec_l) && single(rec) && rec.z == rec_l.z + 1;
-    }
+    // first requests: the window's first batch of records and the record in front of the window (idle groups: the
+    // plane's record 0, unused)
+    const int first_idx = count > 0 ? r0 + min(j, count - 1) : 0;
+    const Entry<A> e_first = entries[first_idx];
+    const uint32_t prev_cellw = (win > 0 && count > 0) ? entries[r0 - 1].cellflag() : 0xFFFFFFFFu;
+    load_level_table(&tab, p.shapes, p.L);
+    __syncthreads();
+    const uint32_t rowstep = 4u * (uint32_t)p.D * (uint32_t)sizeof(A);  // bytes per pixel: four slots of D accumulators
+    if (tid < p.L) s_wstep[tid] = (uint32_t)tab.w[tid] * rowstep;
+    __syncthreads();
+    // the window's first segment continues the cell of the record in front of it (decided by lane 0 of the group:
+    // it holds record r0)
+    const bool cont_here = count > 0 && win > 0 && j == 0 && prev_cellw == e_first.cellflag();
+    const bool first_cont = __shfl(cont_here ? 1 : 0, gbase & (kWave - 1), kWave) != 0;
 
-    // record v of the window -> (byte offset of the query's grad_out row inside the plane, four corner weights).
-    // Positions past the end get weight 0 and an out-of-range offset (the buffer load then returns 0 without
-    // touching memory), so the unrolled batches need no tail loop.
-    auto convert = [&](const Entry<A> &e, int v, uint32_t &q, CornerW<A> &cw) {
-        const bool ok = v < count;
-        const A a = ok ? e.a : (A)0;
-        const A ax1 = a * e.dx, ax0 = a - ax1;
-        q = ok ? e.q * q_stride : 0x80000000u;
-        cw.w[3] = ax1 * e.dy;
-        cw.w[2] = ax0 * e.dy;
-        cw.w[1] = ax1 - cw.w[3];
-        cw.w[0] = ax0 - cw.w[2];
-    };
+    // the plane's slots [pixel][corner][D] through a buffer descriptor: 32-bit byte offsets, and a corner outside the
+    // image gets an out-of-range offset, so the hardware drops its store (no branch)
+    const size_t plane_slots = (size_t)p.I * rowstep;
+    const rsrc_t rs_sc = make_rsrc(static_cast<unsigned char *>(p.ws_scratch) + (size_t)pair * plane_slots, (uint32_t)plane_slots);
+    const uint32_t bias_off = kPixBias * rowstep;  // (mod 2^32, like the products it is subtracted from)
+    A *controw = static_cast<A *>(p.ws_cont) + ((size_t)pair * p.cont_cap + slot) * 4 * p.D;
 
-    A *scratch = static_cast<A *>(p.ws_scratch) + ((size_t)pair * p.it_cap + item) * 4 * p.D;
     for (int cc = 0; cc < nchan_chunks; ++cc) {
         const int c0 = (cc * G + j) * VEC;
         const bool lane_ok = c0 < p.D;
@@ -442,29 +485,130 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[k][i] = (A)0;
 
-        Entry<A> e_cur = entries[start + max(min(j, count - 1), 0)];  // (idle groups: count == 0, record 0 of the plane, unused)
-        for (int v0 = 0; v0 < count; v0 += G) {
-            uint32_t cur_q;
-            CornerW<A> cur_w;
-            convert(e_cur, v0 + j, cur_q, cur_w);
-            wave_lds_sync();  // the previous batch's records have been read
-            s_q[tid] = cur_q;
-            s_w[tid] = cur_w;
-            // the next batch's record (clamped: always a valid address) is in flight while this batch is consumed
-            e_cur = entries[start + min(v0 + G + j, count - 1)];
-            wave_lds_sync();
-            const int cnt = min(G, count - v0);
+        // state of the segment being accumulated (uniform inside the group)
+        int nseg = 0;              // segments started so far in this window
+        bool seg_cont = false;     // the current segment is the window's first AND continues the previous window's cell
+        uint32_t cur_cellw = 0;    // cell word of the current segment
+        uint32_t last_cellw = prev_cellw;  // cell word of the record before the current batch
+
+        // one segment's rows -> the pixels' slots.  skip_right: the right-hand corners were carried over.
+        auto flush = [&](bool skip_right) {
+            if (!lane_ok) return;
+            const uint32_t base = mul24(cur_cellw & 0xFFFFFFu, rowstep) - bias_off + (uint32_t)c0 * (uint32_t)sizeof(A);
+            const uint32_t wstep = s_wstep[(cur_cellw >> 24) & 15u];
+            const uint32_t dstep = (uint32_t)p.D * (uint32_t)sizeof(A);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool on = ((cur_cellw >> (28 + k)) & 1u) && !(skip_right && (k & 1));
+                const uint32_t o = on ? base + ((k & 1) ? rowstep : 0u) + ((k & 2) ? wstep : 0u) + (uint32_t)k * dstep : 0x80000000u;
+                Pack<A, VEC> v;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) v.v[i] = acc[k][i];
+                // written once, read once by the finish kernel: streaming, so it does not displace grad_out rows in L2
+                store_acc_pack<A, VEC>(rs_sc, o, v);
+            }
+        };
+        auto park = [&]() {  // a continuation segment's rows -> LDS, for the segment it continues
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Pack<A, VEC> o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o.v[v] = acc[k][v];
+                *reinterpret_cast<Pack<A, VEC> *>(&s_rows[((unit * 4 + k) * G + j) * VEC]) = o;
+            }
+        };
+        auto to_cont = [&]() {  // ... or, for the workgroup's first window, global memory (one row set per workgroup)
+            if (!lane_ok) return;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Pack<A, VEC> o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o.v[v] = acc[k][v];
+                store_stream(controw + (size_t)k * p.D + c0, o);
+            }
+        };
+
+        // one batch: lane j converts record v0 + j, the group gathers and accumulates G rows
+        auto batch = [&](const Entry<A> &e_cur, int v0) {
+            // ---- convert ----
+            {
+                const int v = v0 + j;
+                const bool ok = v < count;
+                const A a = ok ? e_cur.a() : (A)0;
+                const A dx = e_cur.dx(), dy = e_cur.dy();
+                const A ax1 = a * dx, ax0 = a - ax1;
+                CornerW<A> cw;
+                cw.w[3] = ax1 * dy;
+                cw.w[2] = ax0 * dy;
+                cw.w[1] = ax1 - cw.w[3];
+                cw.w[0] = ax0 - cw.w[2];
+                const uint32_t cellw = ok ? e_cur.cellflag() : 0xFFFFFFFEu;
+                // the previous record's cell: the lane to the left, or (lane 0) the record before this batch
+                uint32_t left = __shfl_up(cellw, 1, kWave);
+                if (j == 0) left = last_cellw;
+                // a segment starts at the window's first record and wherever the cell changes; it takes over the ended
+                // cell's right-hand corners when it is the right-hand x-neighbour in the same row: next pixel index,
+                // same level, and the shared column's pixels exist on either side (left cell: corners 01 / 11, this
+                // cell: 00 / 10)
+                const bool start = ok && (v == 0 || cellw != left);
+                const bool carry = start && v != 0 && (cellw & 0x0FFFFFFFu) == (left & 0x0FFFFFFFu) + 1u &&
+                                   (left & 0xA0000000u) != 0 && (cellw & 0x50000000u) != 0;
+                const uint32_t flag = (start ? kSegStart : 0u) | (carry ? kSegCarry : 0u);
+                wave_lds_sync();  // the previous batch's hand-off has been read
+                s_q[tid] = ok ? mul24(e_cur.q(), q_stride) : 0x80000000u;  // both < 2^24 (host check)
+                s_w[tid] = cw;
+                s_flag[tid] = flag;
+                s_cellw[tid] = cellw;
+                wave_lds_sync();
+                last_cellw = s_cellw[gbase + G - 1];
+            }
+            // ---- gather + accumulate ----
 #pragma unroll
             for (int jj = 0; jj < G; jj += UB) {  // UB row loads issued back to back, then consumed
-                if (jj < cnt) {                   // uniform per group; G == UB: always true
+                if (v0 + jj < count) {            // uniform per group; G == UB: always true
                     Pack<T, VEC> g[UB];
+                    uint32_t qs[UB], fl[UB];
+                    lds_read_u32s<UB>(&s_q[gbase + jj], qs);   // one or two 16-byte LDS reads each
+                    lds_read_u32s<UB>(&s_flag[gbase + jj], fl);
 #pragma unroll
                     for (int u = 0; u < UB; ++u)
                         g[u] = __builtin_bit_cast(Pack<T, VEC>,
-                                                  RawLoad<sizeof(T) * VEC>::load(rs_go, s_q[gbase + jj + u] + lane_elem));
+                                                  RawLoad<sizeof(T) * VEC>::load(rs_go, qs[u] + lane_elem));
                     __builtin_amdgcn_sched_barrier(0);  // keep the UB loads together: hipcc otherwise serialises some
 #pragma unroll
                     for (int u = 0; u < UB; ++u) {
+                        const uint32_t flag = fl[u];
+                        if (flag & kSegStart) {  // uniform inside the group, divergent across the wave's groups
+                            bool carry = false;
+                            if (nseg > 0) {
+                                carry = (flag & kSegCarry) != 0 && !seg_cont;
+                                if (seg_cont) {
+                                    if (unit == 0)
+                                        to_cont();
+                                    else
+                                        park();
+                                } else {
+                                    flush(carry);
+                                }
+                            }
+                            if (carry) {  // the ended cell's right-hand corners are this cell's left-hand ones
+#pragma unroll
+                                for (int v = 0; v < VEC; ++v) {
+                                    acc[0][v] = acc[1][v];
+                                    acc[2][v] = acc[3][v];
+                                    acc[1][v] = (A)0;
+                                    acc[3][v] = (A)0;
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                                    for (int v = 0; v < VEC; ++v) acc[k][v] = (A)0;
+                            }
+                            seg_cont = nseg == 0 && first_cont;
+                            ++nseg;
+                            cur_cellw = s_cellw[gbase + jj + u];
+                        }
                         const CornerW<A> w = s_w[gbase + jj + u];
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
@@ -473,25 +617,24 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
                     }
                 }
             }
+        };
+        Entry<A> e_cur = cc == 0 ? e_first : entries[first_idx];
+        for (int v0 = 0; v0 < count; v0 += G) {
+            // the next batch's record (clamped: always a valid address) is in flight while this batch is consumed
+            const Entry<A> e_next = entries[r0 + min(v0 + G + j, count - 1)];
+            batch(e_cur, v0);
+            e_cur = e_next;
         }
-        // Items of one cell that sit in the same workgroup are summed here (in item order) and leave as ONE set of
-        // four rows, stored at the first of them: hot cells (coarse levels, clustered samples) then cost the finish
-        // kernel one row per NU items, not one per item.
-        if (cc > 0) __syncthreads();  // the previous channel chunk's rows have been consumed
-        if (j == 0) s_cont[unit] = follower ? 1 : 0;
-        if (follower || give_right) {  // (a one-item cell is never a follower: the two cases are disjoint)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (follower || (k & 1)) {
-                    Pack<A, VEC> o;
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) o.v[v] = acc[k][v];
-                    *reinterpret_cast<Pack<A, VEC> *>(&s_rows[((unit * 4 + k) * G + j) * VEC]) = o;
-                }
-            }
+        // ---- the window's open last segment.  A continuation that fills its whole window ("pure") is handed to the
+        // segment it continues; a segment that started at a cell start collects the continuations behind it. ----
+        const bool pure = count > 0 && nseg == 1 && seg_cont;
+        if (j == 0) {
+            s_cont[unit] = (count > 0 && first_cont && unit > 0) ? 1 : 0;
+            s_pure[unit] = pure ? 1 : 0;
         }
+        if (pure && unit > 0) park();
         __syncthreads();
-        if (valid && !follower) {
+        if (count > 0 && !(pure && unit > 0)) {
             for (int u = unit + 1; u < NU && s_cont[u]; ++u) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -499,31 +642,23 @@ __global__ __launch_bounds__(kGatherItemBlock) void msda_value_gather_kernel(con
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) acc[k][v] += r.v[v];
                 }
+                if (!s_pure[u]) break;  // that window goes on with other cells
             }
-            if (take_left) {  // the left neighbour's corners 01 / 11 are this cell's 00 / 10
-#pragma unroll
-                for (int k = 0; k < 4; k += 2) {
-                    const Pack<A, VEC> r =
-                        *reinterpret_cast<const Pack<A, VEC> *>(&s_rows[(((unit - 1) * 4 + k + 1) * G + j) * VEC]);
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[k][v] += r.v[v];
-                }
-            }
-            if (lane_ok) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if ((k & 1) && give_right) continue;  // taken over by the right neighbour
-                    Pack<A, VEC> o;
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) o.v[v] = acc[k][v];
-                    // written once, read once by the finish kernel: keep it from displacing grad_out rows in L2
-                    store_stream(scratch + (size_t)k * p.D + c0, o);
-                }
-            }
+            if (pure)
+                to_cont();
+            else
+                flush(false);
         }
+        if (cc + 1 < nchan_chunks) __syncthreads();  // the parked rows have been consumed before the next chunk parks
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K5: per pixel.  Slot k of a pixel was written by: 0 cell (x, y) [its corner 00], 1 cell (x-1, y) [01],
+// 2 cell (x, y-1) [10], 3 cell (x-1, y-1) [11] — iff that cell has records, and, for the odd slots, unless the
+// cell's right-hand corners were carried into its x-neighbour (both start in the same window).  Cells longer than a
+// gather workgroup's windows add one continuation row set per further workgroup.
+// ------------------------------------------------------------------------------------------
 template <typename A, int VEC> __device__ __forceinline__ Pack<A, VEC> load_acc_pack(rsrc_t r, uint32_t off)
 {
     constexpr int BYTES = (int)sizeof(A) * VEC;
@@ -542,17 +677,17 @@ template <typename A, int VEC> __device__ __forceinline__ Pack<A, VEC> load_acc_
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// K5: per pixel: sum the partial rows of its four incident cells (the pixel is corner 00 of cell (x, y), 01 of
-// (x-1, y), 10 of (x, y-1), 11 of (x-1, y-1)), in cell and chunk order; every grad_value row is stored here.
-// ------------------------------------------------------------------------------------------
-template <typename T, int VEC, int G>
+constexpr int kFinishPix = 1;  // pixels per lane group of the finish kernel: their loads are issued together
+
+template <typename T, int VEC, int G, int GB>
 __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     constexpr int NU = kBlock / G;
-    const int slots = (p.I + NU - 1) / NU;
+    constexpr int NUG = GB / G;  // windows per gather workgroup
+    constexpr int PP = kFinishPix;
+    const int slots = (p.I + NU * PP - 1) / (NU * PP);
     int pair, slot;
     if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
     __shared__ LevelTab tab;
@@ -560,73 +695,82 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
     __syncthreads();
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int unit = threadIdx.x / G, j = threadIdx.x % G;
-    const int pix = slot * NU + unit;
-    if (pix >= p.I) return;
-    int l = 0;
-    while (l < p.L - 1 && pix >= tab.start[l + 1]) ++l;
-    const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
-    const int y = rel / w, x = rel - y * w;
-    const int c11 = tab.cstart[l] + y * cw + x;  // cell (x-1, y-1)
-    const int *cellitem = p.ws_cellitem + (size_t)pair * (p.nc_cap + 1);
-    // item ranges of the cells (x-1,y-1), (x,y-1) | (x-1,y), (x,y): consecutive cell ids, consecutive item ranges.
-    // A pixel the shapes tensor does not describe (sum h*w != I), or one whose cells were dropped for lack of
-    // workspace, has no cells: all ranges empty, the row is stored as zeros.
-    const bool in_tab = y < tab.h[l] && c11 + cw + 2 <= min(plane_cells(tab, p.L), p.nc_cap);
-    const int t0 = in_tab ? cellitem[c11] : 0, t1 = in_tab ? cellitem[c11 + 1] : 0, t2 = in_tab ? cellitem[c11 + 2] : 0;
-    const int u0 = in_tab ? cellitem[c11 + cw] : 0, u1 = in_tab ? cellitem[c11 + cw + 1] : 0,
-              u2 = in_tab ? cellitem[c11 + cw + 2] : 0;
-    const A *src = static_cast<const A *>(p.ws_scratch) + (size_t)pair * p.it_cap * 4 * p.D;
-    // the plane's partial rows through a buffer descriptor: an offset of 0x80000000 is out of range and reads 0,
-    // which is how an empty cell contributes nothing without a branch
-    const size_t plane_bytes = (size_t)p.it_cap * 4 * p.D * sizeof(A);
-    const bool use_rsrc = plane_bytes < ((size_t)1 << 31);
-    const rsrc_t rs = make_rsrc(src, (uint32_t)(use_rsrc ? plane_bytes : 0));
-    const uint32_t row_bytes = (uint32_t)p.D * (uint32_t)sizeof(A);
-    const bool simple = use_rsrc && (t1 - t0) <= 1 && (t2 - t1) <= 1 && (u1 - u0) <= 1 && (u2 - u1) <= 1;
-    // Two one-item cells that are neighbours in x and sit in the same gather workgroup share rows (see the gather
-    // kernel): the left cell's corners 01 / 11 are already inside the right cell's rows 00 / 10 and were not stored.
-    constexpr int NUG = kGatherItemBlock / G;
-    const bool comb_top = (u1 - u0) == 1 && (u2 - u1) == 1 && (u0 % NUG) != NUG - 1;  // cells (x-1, y) and (x, y)
-    const bool comb_bot = (t1 - t0) == 1 && (t2 - t1) == 1 && (t0 % NUG) != NUG - 1;  // cells (x-1, y-1) and (x, y-1)
+    const int pix0 = (slot * NU + unit) * PP;
+    if (pix0 >= p.I) return;
+    const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
+    const int ncells = min(plane_cells(tab, p.L), p.nc_cap);
+    // record ranges of the cells (x-1,y-1), (x,y-1) | (x-1,y), (x,y) of every pixel: consecutive cell ids, consecutive
+    // ranges.  A pixel the shapes tensor does not describe (sum h*w != I), or one whose cells were dropped for lack
+    // of workspace, has no cells: all ranges empty, the row is stored as zeros.
+    int tt[PP][3], uu[PP][3];
+#pragma unroll
+    for (int t = 0; t < PP; ++t) {
+        const int pix = min(pix0 + t, p.I - 1);
+        int l = 0;
+        while (l < p.L - 1 && pix >= tab.start[l + 1]) ++l;
+        const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
+        const int y = rel / max(w, 1), x = rel - y * w;
+        const int c11 = tab.cstart[l] + y * cw + x;  // cell (x-1, y-1)
+        const bool in_tab = w > 0 && y < tab.h[l] && c11 + cw + 2 <= ncells;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            tt[t][k] = in_tab ? off[c11 + k] : 0;
+            uu[t][k] = in_tab ? off[c11 + cw + k] : 0;
+        }
+    }
+    auto carried = [](int a0, int a1, int a2) { return a1 > a0 && a2 > a1 && (a0 / kWin) == (a1 / kWin); };
+    // continuation row sets: gather-workgroup boundaries strictly inside a cell's window range
+    auto nconts = [](int beg, int end) { return end > beg ? ((end - 1) / kWin) / NUG - (beg / kWin) / NUG : 0; };
+    const A *cont = static_cast<const A *>(p.ws_cont) + (size_t)pair * p.cont_cap * 4 * p.D;
+    const size_t plane_slots = (size_t)p.I * 4 * p.D * sizeof(A);  // < 2^31 (host check)
+    const rsrc_t rs_sc = make_rsrc(static_cast<const unsigned char *>(p.ws_scratch) + (size_t)pair * plane_slots, (uint32_t)plane_slots);
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
     for (int cc = 0; cc < nchan_chunks; ++cc) {
         const int c0 = (cc * G + j) * VEC;
         if (c0 >= p.D) continue;
-        A acc[VEC];
-        if (simple) {  // at most one work item per cell (fine levels): four independent loads
-            const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(A);
-            const uint32_t o0 = u2 > u1 ? ((uint32_t)u1 * 4 + 0) * row_bytes + lane_off : 0x80000000u;
-            const uint32_t o1 = (u1 > u0 && !comb_top) ? ((uint32_t)u0 * 4 + 1) * row_bytes + lane_off : 0x80000000u;
-            const uint32_t o2 = t2 > t1 ? ((uint32_t)t1 * 4 + 2) * row_bytes + lane_off : 0x80000000u;
-            const uint32_t o3 = (t1 > t0 && !comb_bot) ? ((uint32_t)t0 * 4 + 3) * row_bytes + lane_off : 0x80000000u;
-            const Pack<A, VEC> r0 = load_acc_pack<A, VEC>(rs, o0);
-            const Pack<A, VEC> r1 = load_acc_pack<A, VEC>(rs, o1);
-            const Pack<A, VEC> r2 = load_acc_pack<A, VEC>(rs, o2);
-            const Pack<A, VEC> r3 = load_acc_pack<A, VEC>(rs, o3);
+        // the pixels' four slots each: independent range-checked loads through a buffer descriptor; a slot nobody
+        // wrote gets an out-of-range offset and reads 0 without touching memory (no branch)
+        Pack<A, VEC> r[PP][4];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] = ((r0.v[v] + r1.v[v]) + r2.v[v]) + r3.v[v];
-        } else {
+        for (int t = 0; t < PP; ++t) {
+            const int pix = min(pix0 + t, p.I - 1);
+            const uint32_t base = ((uint32_t)pix * 4u * (uint32_t)p.D + (uint32_t)c0) * (uint32_t)sizeof(A);
+            const int t0 = tt[t][0], t1 = tt[t][1], t2 = tt[t][2], u0 = uu[t][0], u1 = uu[t][1], u2 = uu[t][2];
+            const bool on[4] = {u2 > u1, u1 > u0 && !carried(u0, u1, u2), t2 > t1, t1 > t0 && !carried(t0, t1, t2)};
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] = (A)0;
-            // rows of a cell: its first item, then the first item of every further gather workgroup it extends into
-            auto add = [&](int first, int last, int corner) {
-                for (int it = first; it < last; it = (it / NUG + 1) * NUG) {
-                    const Pack<A, VEC> r =
-                        *reinterpret_cast<const Pack<A, VEC> *>(src + ((size_t)it * 4 + corner) * p.D + c0);
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[v] += r.v[v];
-                }
-            };
-            add(u1, u2, 0);
-            if (!comb_top) add(u0, u1, 1);
-            add(t1, t2, 2);
-            if (!comb_bot) add(t0, t1, 3);
+            for (int k = 0; k < 4; ++k)
+                r[t][k] = load_acc_pack<A, VEC>(rs_sc, on[k] ? base + (uint32_t)k * (uint32_t)p.D * (uint32_t)sizeof(A) : 0x80000000u);
         }
-        Pack<T, VEC> o;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
-        T *dst = static_cast<T *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
-        store_stream(dst, o);
+        for (int t = 0; t < PP; ++t) {
+            const int pix = pix0 + t;
+            if (pix >= p.I) break;
+            const int t0 = tt[t][0], t1 = tt[t][1], t2 = tt[t][2], u0 = uu[t][0], u1 = uu[t][1], u2 = uu[t][2];
+            A acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = ((r[t][0].v[v] + r[t][1].v[v]) + r[t][2].v[v]) + r[t][3].v[v];
+            if (nconts(u1, u2) + nconts(u0, u1) + nconts(t1, t2) + nconts(t0, t1) != 0) {
+                auto add = [&](int beg, int end, int corner) {
+                    if (end <= beg) return;
+                    const int g1 = ((end - 1) / kWin) / NUG;
+                    for (int g = (beg / kWin) / NUG + 1; g <= g1; ++g) {
+                        const Pack<A, VEC> rr =
+                            *reinterpret_cast<const Pack<A, VEC> *>(cont + ((size_t)g * 4 + corner) * p.D + c0);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[v] += rr.v[v];
+                    }
+                };
+                add(u1, u2, 0);
+                add(u0, u1, 1);
+                add(t1, t2, 2);
+                add(t0, t1, 3);
+            }
+            Pack<T, VEC> o;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
+            T *dst = static_cast<T *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
+            store_stream(dst, o);
+        }
     }
 }
 
@@ -634,25 +778,37 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
 // workspace layout (host + device agree through these helpers)
 // ------------------------------------------------------------------------------------------
 struct SortedWsLayout {
-    int nc_cap, it_cap, nsplit;
-    size_t off_part, off_off, off_cellitem, off_itemcnt, off_meta, off_blocksum, off_items, off_entries, off_scratch, total;
+    int nc_cap, nblk_cap, win_cap, cont_cap, nsplit;
+    size_t off_part, off_blocktot, off_off, off_total, off_meta, off_entries, off_scratch, off_cont, total;
 };
 
 int option_cell_slices();  // 0: automatic (msda_api.hip)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// lanes per row the gather kernel will use (the same choice as dispatch_value_gather_group)
+inline int gather_group_lanes(int64_t D, size_t elem_bytes, bool vec)
+{
+    const int vecf = (int)(16 / elem_bytes);
+    const int64_t lanes = vec && (D % vecf) == 0 ? D / vecf : D;
+    return lanes <= 4 ? 4 : lanes <= 8 ? 8 : lanes <= 16 ? 16 : lanes <= 32 ? 32 : 64;
+}
+
+// `vec`: size for the 16-byte vector path (aligned grad_out / grad_value, D a multiple of 16 bytes of elements);
+// the scalar path has fewer windows per workgroup, needs more continuation rows and falls back to the LDS-tile
+// kernel when the caller's workspace does not hold them
 inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P,
-                                       size_t acc_bytes)
+                                       size_t acc_bytes, size_t elem_bytes, bool vec = true)
 {
     SortedWsLayout w;
     const size_t pairs = (size_t)(B * H);
     const size_t samples = (size_t)(Q * L * P);  // per plane
     w.nc_cap = (int)(2 * I + 2 * L);             // (w+1)(h+1) <= 2wh + 2 per level
-    // work items: sum over cells of ceil(n / kChunk) <= cells + samples / kChunk, and never more than the samples
-    size_t items = (size_t)w.nc_cap + samples / kChunk + 1;
-    if (items > samples) items = samples > 0 ? samples : 1;
-    w.it_cap = (int)items;
+    w.nblk_cap = (w.nc_cap + kScanCells - 1) / kScanCells;
+    w.win_cap = (int)((samples + kWin - 1) / kWin);
+    const int gl = gather_group_lanes(D, elem_bytes, vec);
+    const int nug = gl >= kGatherMinBlock ? 1 : kGatherMinBlock / gl;
+    w.cont_cap = (w.win_cap + nug - 1) / nug + 1;
     // query slices per plane: enough workgroups to fill the chip, at least ~2k samples each
     int64_t ns = pairs ? (int64_t)((256 + pairs - 1) / pairs) : 1;
     const int64_t by_work = (int64_t)((samples + 2047) / 2048);
@@ -665,14 +821,13 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     const size_t entry_bytes = acc_bytes == 8 ? 32 : 16;
     size_t o = 0;
     w.off_part = o;     o = align_up(o + pairs * w.nsplit * (size_t)w.nc_cap * 4, 256);
+    w.off_blocktot = o; o = align_up(o + pairs * w.nsplit * (size_t)w.nblk_cap * 4, 256);
     w.off_off = o;      o = align_up(o + pairs * ((size_t)w.nc_cap + 1) * 4, 256);
-    w.off_cellitem = o; o = align_up(o + pairs * ((size_t)w.nc_cap + 1) * 4, 256);
-    w.off_itemcnt = o;  o = align_up(o + pairs * 4, 256);
+    w.off_total = o;    o = align_up(o + pairs * 4, 256);
     w.off_meta = o;     o = align_up(o + 256, 256);
-    w.off_blocksum = o; o = align_up(o + pairs * (((size_t)w.nc_cap + kBlock - 1) / kBlock) * 8, 256);
-    w.off_items = o;    o = align_up(o + pairs * (size_t)w.it_cap * 16, 256);
     w.off_entries = o;  o = align_up(o + pairs * samples * entry_bytes, 256);
-    w.off_scratch = o;  o = align_up(o + pairs * (size_t)w.it_cap * 4 * (size_t)D * acc_bytes, 256);
+    w.off_scratch = o;  o = align_up(o + pairs * (size_t)I * 4 * (size_t)D * acc_bytes, 256);
+    w.off_cont = o;     o = align_up(o + pairs * (size_t)w.cont_cap * 4 * (size_t)D * acc_bytes, 256);
     w.total = o;
     return w;
 }
