@@ -7,6 +7,10 @@ MSDA_DEFINE_ENTRY_POINTS(f32, float)
 extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_bytes_impl(
     int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int elem_size)
 {
+    // problems the single-launch kernel takes need no workspace at all
+    const msda::Dims d{B, I, H, D, Q, L, P};
+    const bool small = elem_size == 8 ? msda::small_path_chosen<double>(d) : msda::small_path_chosen<float>(d);
+    if (small) return 0;
     return (int64_t)msda::sorted_ws_layout(B, I, H, D, Q, L, P, elem_size == 8 ? 8 : 4, (size_t)elem_size).total;
 }
 

@@ -63,6 +63,9 @@ struct Params {
     int nc_cap, nblk_cap, win_cap, cont_cap;
     int nsplit;         // query slices per plane in the count / place passes
     int cell_cap;       // cells a count / place workgroup holds in LDS at a time
+    int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
+    int small_ns;       // ... workgroups per (plane, level)
+    int small_extra;    // ... plus this many for the level with the most pixels
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char msda_smem[];

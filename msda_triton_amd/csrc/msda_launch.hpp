@@ -7,18 +7,20 @@
 #include <atomic>
 
 #include "msda_value_sorted.hpp"
+#include "msda_value_small.hpp"
 #include "msda_value_tile.hpp"
 
 namespace msda {
 
 // ---- process-wide options and per-thread error text (defined in msda_api.hip) ----
 int option_xcd_map();
-int option_value_path();  // 0: auto (sorted gather for big problems, LDS tile kernel for small), 1: LDS tile kernel, 2: sorted
+int option_value_path();  // 0: auto (single-launch LDS kernel when a plane-level fits, else sorted gather), 1: LDS tile kernel, 2: sorted, 3: single-launch
 int option_stage_kb();    // LDS KiB a gather workgroup may spend on staged pyramid levels (0: off)
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
 int option_gather_wg();     // threads per workgroup of the grad_value gather kernel (64 / 128 / 256)
+int option_small_ns();      // workgroups per (plane, level) of the single-launch grad_value kernel (0: automatic)
 int option_debug();         // dev-only ablation mask
-int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream
+int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream; 0: never; -1: automatic
 // fork-join helpers around a lazily created per-device side stream (msda_api.hip)
 hipStream_t side_stream_fork(hipStream_t user);   // side stream that waits for everything queued on `user`
 int side_stream_join(hipStream_t user);            // `user` waits for everything queued on the side stream
@@ -454,6 +456,75 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
     return rc;
 }
 
+// ---- single-launch grad_value for small problems (msda_value_small.hpp) ----
+template <typename T> inline size_t small_need_bytes(const Dims &d, bool vec)
+{
+    using A = typename Traits<T>::acc;
+    const size_t vecw = vec ? 16 / sizeof(T) : 1;
+    return small_lds_bytes((size_t)(2 * d.I + 2 * d.L), (size_t)(d.Q * d.P), sizeof(A), vecw);
+}
+
+template <typename T, int VEC, int G> inline int launch_value_small(Params &p, size_t lds, hipStream_t stream)
+{
+    dim3 grid;
+    if (!plane_grid(p, p.B * p.H, (int64_t)p.L * p.small_ns + p.small_extra, grid)) {
+        set_error("grid too large");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    static std::atomic<uint64_t> big_lds_done{0};
+    allow_big_lds(msda_value_small_kernel<T, VEC, G>, big_lds_done);
+    hipLaunchKernelGGL((msda_value_small_kernel<T, VEC, G>), grid, dim3(kSmallBlock), lds, stream, p);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int VEC> inline int dispatch_value_small_group(Params &p, size_t lds, hipStream_t stream)
+{
+    const int lanes = (p.D + VEC - 1) / VEC;
+    switch (pick_group(lanes)) {
+    case 4: return launch_value_small<T, VEC, 4>(p, lds, stream);
+    case 8: return launch_value_small<T, VEC, 8>(p, lds, stream);
+    case 16: return launch_value_small<T, VEC, 16>(p, lds, stream);
+    case 32: return launch_value_small<T, VEC, 32>(p, lds, stream);
+    default: return launch_value_small<T, VEC, 64>(p, lds, stream);
+    }
+}
+
+template <typename T> inline int run_value_small(Params &p, const Dims &d, hipStream_t stream)
+{
+    constexpr int VECF = 16 / sizeof(T);
+    const bool vec_ok = value_vec_ok<T>(p);
+    p.small_cells = (int)(2 * d.I + 2 * d.L);
+    // workgroups per (plane, level): fill the 256 CUs when there are few planes; two when the planes just fill them
+    // (a level's workgroups then finish at different times and the busiest level no longer sets the pace)
+    const int64_t wgs = d.B * d.H * d.L;
+    p.small_ns = option_small_ns() > 0 ? option_small_ns() % 100 : wgs <= 64 ? 4 : wgs <= 128 ? 2 : 1;
+    p.small_extra = option_small_ns() / 100;  // (experiment knob: an extra workgroup for the largest level — measured: no gain)
+    const size_t lds = small_need_bytes<T>(d, vec_ok);
+    return vec_ok ? dispatch_value_small_group<T, VECF>(p, lds, stream) : dispatch_value_small_group<T, 1>(p, lds, stream);
+}
+
+// the sorted pipeline's record format: 4 level bits, 24-bit biased pixel index, 32-bit slot offsets
+template <typename T> inline bool sorted_fits(const Dims &d)
+{
+    using A = typename Traits<T>::acc;
+    return d.L <= kSortedMaxLevels && d.I < (int64_t)kPixBias && 16 * d.D * (int64_t)sizeof(A) < ((int64_t)1 << 24) &&
+           d.I * 4 * d.D * (int64_t)sizeof(A) < ((int64_t)1 << 31);
+}
+
+// Small problems: when all samples of a (plane, level) and the level's cell table fit one workgroup's LDS, the
+// single-launch kernel does the whole job without workspace.  Measured on MI355X (grad_value alone): c4 (B=8, Q=900)
+// 91 -> 55 us, c1 35 -> 26 us, c2 at Q=1000 66 -> 36 us.  It serves one (plane, level) per workgroup on one CU, so it is
+// chosen only while a level holds at most 4096 samples.
+template <typename T> inline bool small_fits(const Dims &d)
+{
+    return d.L >= 1 && 2 * d.I + 2 * d.L < ((int64_t)1 << 24) && d.Q < ((int64_t)1 << 24) &&
+           small_need_bytes<T>(d, true) <= (size_t)kMaxDynLds;
+}
+template <typename T> inline bool small_path_chosen(const Dims &d)
+{
+    return small_fits<T>(d) && (option_value_path() == 3 || (option_value_path() == 0 && d.Q * d.P <= 4096));
+}
+
 // grad_value: the sorted-gather pipeline when the caller's workspace allows it, else (or for small problems) the
 // LDS-tile kernel.
 template <typename T>
@@ -461,30 +532,14 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
 {
     using A = typename Traits<T>::acc;
     const int64_t B = d.B, I = d.I, H = d.H, D = d.D, Q = d.Q, L = d.L, P = d.P;
-    // the sorted pipeline's record format: 4 level bits, 24-bit biased pixel index, 32-bit slot offsets
-    const bool fits = L <= kSortedMaxLevels && I < (int64_t)kPixBias && 16 * D * (int64_t)sizeof(A) < ((int64_t)1 << 24) &&
-                      I * 4 * D * (int64_t)sizeof(A) < ((int64_t)1 << 31);
-    bool sorted = fits && option_value_path() != 1 && workspace != nullptr && aligned_to(workspace, 256) &&
-                  (uint64_t)workspace_bytes >=
-                      sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p)).total;
-    if (sorted && option_value_path() == 0) {
-        // Small problems: the sorted pipeline's six launches cost ~45 us before any work is done, while the
-        // LDS-tile kernel is one launch whose time grows with (workgroups / 256 CUs) x (samples per plane).
-        // Fitted on MI355X (c1 / c2 at Q = 500..2000 / c4): tiles 20 us + 1.6 ns per plane-sample and chip-load,
-        // sorted 42 us + 24 ps per sample.
-        const size_t room = kValueLdsBudget - sizeof(LevelTab);
-        int ch = 0;
-        for (int c : {4, 2, 1})
-            if (!ch && (D % c) == 0 && (size_t)I * c * sizeof(TileAcc) <= room) ch = c;
-        if (ch) {
-            const double s_plane = (double)Q * (double)(L * P), planes = (double)(B * H);
-            double load = planes * (double)(D / ch) / 256.0;
-            if (load < 0.25) load = 0.25;
-            const double t_tile = 20.0 + load * s_plane * 1.6e-3, t_sorted = 42.0 + planes * s_plane * 2.4e-5;
-            if (t_tile < t_sorted) sorted = false;
-        }
-    }
-    const int rc = sorted ? run_value_sorted<T>(p, d, workspace, stream) : dispatch_value<T>(p, stream);
+    const bool sorted = sorted_fits<T>(d) && option_value_path() != 1 && workspace != nullptr && aligned_to(workspace, 256) &&
+                        (uint64_t)workspace_bytes >=
+                            sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p)).total;
+    const bool small_path = small_path_chosen<T>(d) || (option_value_path() == 0 && !sorted && small_fits<T>(d));
+    // (no workspace: the single-launch kernel is still better than the LDS-tile kernel whenever it fits)
+    const int rc = small_path ? run_value_small<T>(p, d, stream)
+                   : sorted   ? run_value_sorted<T>(p, d, workspace, stream)
+                              : dispatch_value<T>(p, stream);
     if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }
@@ -537,7 +592,10 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     // forked side stream next to the grad_value pipeline (fork/join with events: still graph-capturable).
     hipStream_t sample_stream = stream;
     bool forked = false;
-    if (want_sample && want_value && option_overlap()) {
+    // ... by default only next to the single-launch grad_value kernel, which leaves most CUs idle most of its time
+    // (c4: fwd+bwd 0.130 -> 0.117 ms); next to the sorted pipeline the two halves want the same pipes (~1 %)
+    const int ov = option_overlap();
+    if (want_sample && want_value && (ov == 1 || (ov < 0 && small_path_chosen<T>(d)))) {
         hipStream_t side = side_stream_fork(stream);
         if (side != nullptr) {
             sample_stream = side;

@@ -1,0 +1,335 @@
+// msda_value_small.hpp — grad_value for SMALL problems in ONE launch, no workspace, no atomics on floating-point data.
+//
+// Grounding-DINO / Deformable-DETR decoder shapes (a few hundred queries per batch element) put only a few thousand
+// samples on each (batch, head) plane and level; the sorted pipeline's five launches (msda_value_sorted.hpp) then
+// cost more than the work.  Here one 1024-thread workgroup owns ONE (plane, level) and keeps everything in LDS:
+//
+//   1 count    every sample of the level -> its bilinear cell (msda_value_sorted.hpp: sample_cell); LDS histogram
+//   2 scan     exclusive scan of the histogram in place: first record of every cell's list; the longest list
+//   3 place    samples again -> records {q, dx, dy, a} at their cell list's cursor (LDS)
+//   4 gather   PIXEL-major: a G-lane group owns a pixel (or 1/S of a busy pixel's records), walks the lists of the
+//              pixel's four incident cells, loads each record's grad_out row (16 bytes per lane) and FMAs it with the
+//              corner weight into ONE accumulator row; S > 1: the S partial rows are summed through LDS.  The pixel's
+//              grad_value row is stored once — complete, so there are no partial rows in memory and no finish pass.
+//
+// Every grad_value row of the level is written exactly once by plain stores (rows nobody samples: zeros).
+// Replaces tl.atomic_add of the reference (kernels.py:543-553) for these shapes.
+#pragma once
+
+#include "msda_value_sorted.hpp"
+
+namespace msda {
+
+constexpr int kSmallBlock = 1024;
+
+template <typename A> struct alignas(16) SmallRec {
+    uint32_t q;
+    A dx, dy, a;
+};
+
+// dynamic LDS of the kernel for a level of at most `cells` cells and `samples` samples (host + device agree)
+inline size_t small_lds_bytes(size_t cells, size_t samples, size_t acc_bytes, size_t vec)
+{
+    const size_t rec = acc_bytes == 8 ? 32 : 16;
+    size_t o = sizeof(LevelTab);
+    o = (o + 15) / 16 * 16 + (cells + 1) * 4;              // counters / cell list starts
+    o = (o + 15) / 16 * 16 + samples * rec;                // records sorted by cell
+    o = (o + 15) / 16 * 16 + (size_t)kSmallBlock * (4 + 4 * acc_bytes);  // converted (row offset, four weights) hand-off
+    (void)vec;
+    return o + 64;
+}
+
+template <typename T, int VEC, int G>
+__global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Params p)
+{
+    using A = typename Traits<T>::acc;
+    using TR = Traits<T>;
+    constexpr int NG = kSmallBlock / G;  // lane groups per workgroup
+    constexpr int UB = G < 8 ? G : 8;    // row loads in flight per lane
+    // p.small_ns workgroups per (plane, level): each builds the level's sorted records for itself (cheap) and takes
+    // every small_ns-th round of the gather, so few planes still fill the chip and busy levels get more CUs' time
+    int pair, slot;
+    if (!decode_block(p.grid3d, p.B * p.H, p.L * p.small_ns + p.small_extra, p.xcd_map, pair, slot)) return;
+    const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
+    const int tid = threadIdx.x;
+
+    unsigned char *sm = msda_smem;
+    LevelTab *tab = reinterpret_cast<LevelTab *>(sm);
+    size_t o = (sizeof(LevelTab) + 15) / 16 * 16;
+    int *s_off = reinterpret_cast<int *>(sm + o);  // [ncl + 1]
+    load_level_table(tab, p.shapes, p.L);
+    __syncthreads();
+    // slot -> (level, share of the level's gather rounds).  With small_extra the level with the most pixels gets one
+    // more workgroup than the others, and its workgroups come first in dispatch order: on a pyramid the finest level
+    // holds 3/4 of the pixels and would otherwise set the pace of the whole launch.
+    int lvl, share, nshare;
+    {
+        int big = 0;
+        for (int l = 1; l < p.L; ++l)
+            if (tab->h[l] * tab->w[l] > tab->h[big] * tab->w[big]) big = l;
+        const int nbig = p.small_ns + p.small_extra;
+        if (slot < nbig) {
+            lvl = big;
+            share = slot;
+            nshare = nbig;
+        } else {
+            const int k = (slot - nbig) / p.small_ns;  // k-th of the other levels
+            lvl = k < big ? k : k + 1;
+            share = (slot - nbig) - k * p.small_ns;
+            nshare = p.small_ns;
+        }
+    }
+    const int lw = tab->w[lvl], lh = tab->h[lvl], cw = lw + 1;
+    const int ncl_true = (lh + 1) * cw;
+    const int ncl = min(ncl_true, p.small_cells);  // (shapes that disagree with I: never index past the LDS table)
+    const int npix = lw * lh;
+    const int pstart = tab->start[lvl];
+    o += ((size_t)p.small_cells + 1) * 4;
+    o = (o + 15) / 16 * 16;
+    SmallRec<A> *s_rec = reinterpret_cast<SmallRec<A> *>(sm + o);
+    o += (size_t)p.Q * p.P * sizeof(SmallRec<A>);
+    o = (o + 15) / 16 * 16;
+    uint32_t *s_q = reinterpret_cast<uint32_t *>(sm + o);  // [kSmallBlock] row byte offsets
+    CornerW<A> *s_w = reinterpret_cast<CornerW<A> *>(sm + o + (size_t)kSmallBlock * 4);  // [kSmallBlock] weights per block pixel
+
+    __shared__ int s_red[kSmallBlock / kWave];
+    __shared__ int s_max;
+
+    for (int i = tid; i <= ncl; i += kSmallBlock) s_off[i] = 0;
+    if (tid == 0) s_max = 0;
+    __syncthreads();
+
+    // ---- samples of this (plane, level): thread t serves point t % P of the queries t / P + k * (threads / P) ----
+    const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
+    const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
+    const T *attn = static_cast<const T *>(p.attn) + plane_s0;
+    const int HLP = p.H * p.LP;
+    const int dq = p.P <= kSmallBlock ? kSmallBlock / p.P : 1;
+    const bool active = p.P <= kSmallBlock && tid < dq * p.P;
+    const int pt = active ? tid % p.P : 0, q0 = active ? tid / p.P : 0;
+    // This thread's samples, fetched ONCE and up front (both walks below reuse them): the kernel is a chain of
+    // latencies inside one workgroup, so every global round trip saved counts.  Problems this kernel is chosen for
+    // have at most kPre samples per thread; longer walks load on the spot.
+    constexpr int kPre = 4;
+    const bool pre = active && (p.Q + dq - 1) / dq <= kPre;
+    Pack<T, 2> pre_xy[kPre];
+    T pre_a[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+        pre_xy[k].v[0] = pre_xy[k].v[1] = pre_a[k] = TR::from_acc((A)0);
+        const int q = q0 + k * dq;
+        if (pre && q < p.Q) {
+            const int sidx = q * HLP + lvl * p.P + pt;
+            pre_xy[k] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+            pre_a[k] = attn[sidx];
+        }
+    }
+    auto walk = [&](auto &&visit) {  // visit(q, attention weight, in-level cell, dx, dy)
+        auto one = [&](int q, const Pack<T, 2> &xy, T at) {
+            int cell;
+            uint32_t cellw;
+            A dx, dy;
+            if (sample_cell<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), lh, lw, 0, 0, 0, p.zeros, p.align, cell, cellw, dx, dy) &&
+                cell < ncl)
+                visit(q, TR::to_acc(at), cell, dx, dy);
+        };
+        if (pre) {
+#pragma unroll
+            for (int k = 0; k < kPre; ++k)
+                if (q0 + k * dq < p.Q) one(q0 + k * dq, pre_xy[k], pre_a[k]);
+        } else if (active) {
+            for (int q = q0; q < p.Q; q += dq) {
+                const int sidx = q * HLP + lvl * p.P + pt;
+                one(q, *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx), attn[sidx]);
+            }
+        } else if (p.P > kSmallBlock) {
+            for (int q = 0; q < p.Q; ++q)
+                for (int pp = tid; pp < p.P; pp += kSmallBlock) {
+                    const int sidx = q * HLP + lvl * p.P + pp;
+                    one(q, *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx), attn[sidx]);
+                }
+        }
+    };
+    // 1 count
+    walk([&](int, A, int cell, A, A) { atomicAdd(&s_off[cell], 1); });
+    __syncthreads();
+    // 2 exclusive scan in place (each thread a contiguous run of cells), and the longest list
+    {
+        const int per = (ncl + kSmallBlock - 1) / kSmallBlock;
+        const int c_beg = min(ncl, tid * per), c_end = min(ncl, c_beg + per);
+        int sum = 0, mx = 0;
+        for (int c = c_beg; c < c_end; ++c) {
+            const int n = s_off[c];
+            sum += n;
+            mx = max(mx, n);
+        }
+        const int lane = tid & (kWave - 1), wid = tid / kWave;
+        int inc = sum;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int nn = __shfl_up(inc, d, kWave);
+            if (lane >= d) inc += nn;
+        }
+#pragma unroll
+        for (int m = 1; m < kWave; m <<= 1) mx = max(mx, __shfl_xor(mx, m, kWave));
+        if (lane == kWave - 1) s_red[wid] = inc;
+        if (lane == 0) atomicMax(&s_max, mx);
+        __syncthreads();
+        int base = inc - sum;
+        for (int i = 0; i < wid; ++i) base += s_red[i];
+        for (int c = c_beg; c < c_end; ++c) {
+            const int n = s_off[c];
+            s_off[c] = base;
+            base += n;
+        }
+        if (tid == kSmallBlock - 1) s_off[ncl] = base;  // (the last thread's run ends at ncl, possibly empty)
+        __syncthreads();
+    }
+    // 3 place: cursor = list start (restored afterwards by shifting: list c ends where list c + 1 began)
+    walk([&](int q, A at, int cell, A dx, A dy) {
+        const int pos = atomicAdd(&s_off[cell], 1);
+        SmallRec<A> r;
+        r.q = (uint32_t)q;
+        r.dx = dx;
+        r.dy = dy;
+        r.a = at;
+        s_rec[pos] = r;
+    });
+    __syncthreads();
+    // after placing, s_off[c] = END of list c (= start of list c + 1); list c = [c ? s_off[c-1] : 0, s_off[c])
+
+    // ---- 4 gather: a lane group owns a 2 x 2 block of pixels (or 1/S of a busy block's records).  The block's
+    // pixels are corners of the 3 x 3 cells around it, so each record's grad_out row is loaded ONCE per block (9 cell
+    // lists for 4 pixels; a pixel alone would walk 4 lists) and FMAed into up to four accumulator rows. ----
+    const int maxcell = s_max;
+    constexpr int SMAX = kWave / G;  // lane groups of one wave: their partial rows meet through shuffles
+    int S = 1;
+    while (S < SMAX && (9 * maxcell + S - 1) / S > 64) S <<= 1;
+    const int unit = tid / G, j = tid % G;
+    const int gbase = tid - j;
+    const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;
+    const uint32_t q_stride = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);
+    const rsrc_t rs_go = make_rsrc(gout, (uint32_t)(((size_t)p.Q * p.H * p.D - (size_t)h * p.D) * sizeof(T)));
+    const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
+    const int nbx = (lw + 1) / 2, nby = (lh + 1) / 2;
+    const int items = nbx * nby * S;
+    const int rounds = (items + NG - 1) / NG;
+    for (int r = share; r < rounds; r += nshare) {
+        const int item = r * NG + unit;
+        const bool live = item < items;
+        const int blk = live ? item / S : 0, part = live ? item % S : 0;
+        const int by = blk / max(nbx, 1), bx = blk - by * nbx;
+        // cumulative lengths of the nine lists: cell (2 bx - 1 + ci, 2 by - 1 + cj), list index ci + 3 cj
+        int lcum[10];
+        lcum[0] = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int cx = 2 * bx - 1 + (k % 3), cy = 2 * by - 1 + (k / 3);  // in [-1, lw - 1] x [-1, lh - 1] when valid
+            const int cid = (cy + 1) * cw + (cx + 1);
+            const bool ok = live && cx < lw && cy < lh && cid < ncl;
+            lcum[k + 1] = lcum[k] + (ok ? s_off[cid] - (cid > 0 ? s_off[cid - 1] : 0) : 0);
+        }
+        const int ntot = lcum[9];
+        const int mine = ntot > part ? (ntot - part + S - 1) / S : 0;  // virtual positions part, part + S, ...
+        for (int cc = 0; cc < nchan_chunks; ++cc) {
+            const int c0 = (cc * G + j) * VEC;
+            const bool lane_ok = c0 < p.D;
+            const uint32_t lane_elem = (lane_ok ? (uint32_t)c0 : 0u) * (uint32_t)sizeof(T);
+            A acc[4][VEC];  // block pixel i + 2 j'
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[k][i] = (A)0;
+            for (int v0 = 0; v0 < mine; v0 += G) {
+                // convert: lane j takes this group's record v0 + j -> (row offset, one weight per block pixel)
+                {
+                    const int v = v0 + j;
+                    const bool ok = v < mine;
+                    const int vp = part + v * S;
+                    int k = 0;
+#pragma unroll
+                    for (int t = 1; t < 9; ++t) k += (vp >= lcum[t]) ? 1 : 0;
+                    int cum = 0;
+#pragma unroll
+                    for (int t = 1; t < 9; ++t) cum = k == t ? lcum[t] : cum;
+                    const int cj = k / 3, ci = k - 3 * cj;
+                    const int cid = (2 * by + cj) * cw + 2 * bx + ci;  // the list's cell; its start is looked up again here
+                    SmallRec<A> rec;                                   // (nine starts in registers made the kernel spill)
+                    rec.q = 0;
+                    rec.dx = rec.dy = rec.a = (A)0;
+                    if (ok) rec = s_rec[(cid > 0 ? s_off[cid - 1] : 0) + vp - cum];
+                    // weight of the record for block column i: the cell's x0 = 2 bx - 1 + ci, the pixel is 2 bx + i
+                    const A wx0 = ci == 0 ? rec.dx : ci == 1 ? (A)1 - rec.dx : (A)0;
+                    const A wx1 = ci == 1 ? rec.dx : ci == 2 ? (A)1 - rec.dx : (A)0;
+                    const A wy0 = cj == 0 ? rec.dy : cj == 1 ? (A)1 - rec.dy : (A)0;
+                    const A wy1 = cj == 1 ? rec.dy : cj == 2 ? (A)1 - rec.dy : (A)0;
+                    const A ay0 = rec.a * wy0, ay1 = rec.a * wy1;
+                    CornerW<A> w;
+                    w.w[0] = ay0 * wx0;
+                    w.w[1] = ay0 * wx1;
+                    w.w[2] = ay1 * wx0;
+                    w.w[3] = ay1 * wx1;
+                    wave_lds_sync();  // the previous batch's hand-off has been read
+                    s_q[tid] = ok ? mul24(rec.q, q_stride) : 0x80000000u;
+                    s_w[tid] = w;
+                    wave_lds_sync();
+                }
+#pragma unroll
+                for (int jj = 0; jj < G; jj += UB) {
+                    if (v0 + jj < mine) {  // uniform per group
+                        Pack<T, VEC> g[UB];
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) g[u].v[i] = TR::from_acc((A)0);
+                            if (v0 + jj + u < mine)  // (uniform inside the group) no record, no load: the workgroup's one CU
+                                                     // is bound by its vector-memory path
+                                g[u] = __builtin_bit_cast(Pack<T, VEC>,
+                                                          RawLoad<sizeof(T) * VEC>::load(rs_go, s_q[gbase + jj + u] + lane_elem));
+                        }
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            const CornerW<A> w = s_w[gbase + jj + u];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                                for (int i = 0; i < VEC; ++i) acc[k][i] = fma_t(w.w[k], TR::to_acc(g[u].v[i]), acc[k][i]);
+                        }
+                    }
+                }
+            }
+            // a split block's S partial row sets sit in S neighbouring lane groups of one wave: butterfly sum
+            for (int m = G; m < G * S; m <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) acc[k][i] += __shfl_xor(acc[k][i], m, kWave);
+            }
+            if (live && part == 0 && lane_ok) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int px = 2 * bx + (k & 1), py = 2 * by + (k >> 1);
+                    if (px < lw && py < lh) {
+                        const int pix = py * lw + px;
+                        Pack<T, VEC> ov;
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) ov.v[i] = TR::from_acc(acc[k][i]);
+                        T *dst = static_cast<T *>(p.grad_value) + (((size_t)b * p.I + pstart + pix) * p.H + h) * p.D + c0;
+                        if (pstart + pix < p.I) store_stream(dst, ov);  // (shapes that disagree with I: stay inside the plane)
+                    }
+                }
+            }
+        }
+    }
+    // pixels of `I` behind the last level (shapes that describe fewer than I pixels) belong to nobody: zeros
+    if (lvl == p.L - 1 && share == 0) {
+        const int tail0 = pstart + npix;
+        const int row_elems = p.D;
+        for (long long e = (long long)tail0 * row_elems + tid; e < (long long)p.I * row_elems; e += kSmallBlock) {
+            const int px = (int)(e / row_elems), c = (int)(e - (long long)px * row_elems);
+            static_cast<T *>(p.grad_value)[(((size_t)b * p.I + px) * p.H + h) * p.D + c] = TR::from_acc((A)0);
+        }
+    }
+}
+
+}  // namespace msda
