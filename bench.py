@@ -11,9 +11,12 @@ One *step* = the body of the reference benchmark (scripts/benchmark.py:90-94 of 
 through the public autograd API, on BASELINE configs[1] at Q = 10 000 (B=4, H=8, D=32, L=4 levels
 64..8, P=4, fp32, border / align_corners=True), synthetic inputs resident in HBM.
 
-N > 1 (weak scaling): every rank owns its own 10 000-query shard of a N*10 000-query problem
-against the replicated value pyramid; forward all-gathers the per-shard outputs (RCCL), backward
-all-reduces grad_value.  `value` = query rows (b, q) processed per second by the whole job, fwd+bwd.
+N > 1 (weak scaling): every rank owns B*Q rows of a N times larger problem (global Q = N*10 000) against the
+replicated value pyramid; the kernels write the local rows straight into the result, the peers' rows arrive by an
+in-place exchange that overlaps the next piece's kernels (RCCL); grad_value is summed only among the ranks that
+share a batch element (none while N divides B).  `value` = query rows (b, q) processed per second by the whole
+job, fwd+bwd.  The same run also times a STRONG-scaling leg under the key `strong_scaling_c5`: BASELINE configs[4]
+(B=4, Q=100 000, D=64, L=5, P=8, fp16) with its 400 000 rows split over the N ranks.
 
 Rank 0 prints ONE JSON line.
 """
@@ -112,6 +115,64 @@ def torch_cpu_fallback(wl, budget_s=8.0, q_sample=1000):
             "sample": f"{len(times)} fwd+bwd passes on the first {q_sample} queries per batch element, fp32, median"}
 
 
+def strong_scaling_c5(dev, world, rank, use_dist, steps=5, warmup=2):
+    """BASELINE configs[4] (stress) with its B*Q = 400 000 rows split over the ranks: fwd+bwd ms per step.  Inputs are
+    drawn on the device (torch RNG, same seed on every rank for the replicated value pyramid): only shapes matter."""
+    import torch
+    import torch.distributed as dist
+    from msda_triton_amd import synth
+    from msda_triton_amd.distributed import row_shard_bounds, row_sharded_multiscale_deformable_attention
+    from msda_triton_amd.functional import multiscale_deformable_attention
+
+    wl = synth.WORKLOADS["c5_stress"]
+    dt = getattr(torch, wl.dtype)
+    rows = wl.B * wl.Q
+    r0, r1 = row_shard_bounds(rows, world, rank) if use_dist else (0, rows)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    value = torch.randn(wl.B, wl.I, wl.H, wl.D, device=dev, generator=g).to(dt).requires_grad_(True)
+    g.manual_seed(99 + rank)
+    n = r1 - r0
+    pts = torch.rand(n, wl.H, wl.L, wl.P, 2, device=dev, generator=g).to(dt).requires_grad_(True)
+    att = torch.softmax(torch.randn(n, wl.H, wl.L * wl.P, device=dev, generator=g), -1).reshape(n, wl.H, wl.L, wl.P).to(dt)
+    att.requires_grad_(True)
+    shapes = torch.tensor(wl.levels, device=dev)
+
+    def step():
+        if use_dist:
+            out = row_sharded_multiscale_deformable_attention(value, shapes, pts, att, wl.padding_mode, wl.align_corners,
+                                                              inputs_are_sharded=True, num_queries=wl.Q,
+                                                              grad_value_sync="owners")
+        else:
+            out = multiscale_deformable_attention(value, shapes, pts.view(wl.B, wl.Q, *pts.shape[1:]),
+                                                  att.view(wl.B, wl.Q, *att.shape[1:]), wl.padding_mode, wl.align_corners)
+        out.backward(torch.rand_like(out))
+        value.grad = pts.grad = att.grad = None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt_s = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_s = float(t.item())
+    ms = dt_s * 1e3 / steps
+    return {"workload": f"c5_stress: B={wl.B} Q={wl.Q} (global) H={wl.H} D={wl.D} L={wl.L} P={wl.P} {wl.dtype}, "
+                        f"{rows} rows over {world} rank(s)", "scaling": "strong", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": ms, "value": rows / (ms * 1e-3), "unit": "queries/s",
+            "alg_fwd_bwd_GBs": round((wl.alg_fwd_bytes + wl.alg_bwd_bytes) / (ms * 1e-3) / 1e9, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,8 +185,9 @@ def main():
                     help="multi-GPU: how grad_value is combined (owners: among the ranks sharing a batch element)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and use the sharded code path even with one rank (self-test)")
+    ap.add_argument("--no-strong-c5", action="store_true", help="skip the strong-scaling c5 leg")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
-                    help="msda_set_option override for A/B runs, e.g. --opt stage_kb=0 --opt value_path=1")
+                    help="msda_set_option override for A/B runs, e.g. --opt value_path=2 --opt overlap=0")
     args = ap.parse_args()
 
     import torch
@@ -249,8 +311,8 @@ def main():
             "config": {"workload": f"{wl.name}: B={wl.B} Q={wl.Q}/rank H={wl.H} D={wl.D} L={wl.L} "
                                    f"levels={list(wl.levels)} P={wl.P} {wl.dtype} {pm} align_corners={ac}",
                        "global_queries": gwl.Q,
-                       "parallelism": f"row-shard x{world} (B*Q rows per rank, one all-gather of the outputs"
-                                      f"{', grad_value ' + args.grad_value_sync if use_dist else ''})",
+                       "parallelism": f"row-shard x{world} (B*Q rows per rank, kernels write in place, in-place exchange "
+                                      f"overlapped with compute{', grad_value ' + args.grad_value_sync if use_dist else ''})",
                        "step": "public autograd API: fwd + backward(rand_like(out)) + grad reset"},
             "fwd_ms": ms_fwd,
             "fwd_bwd_ms": ms_step,
@@ -267,10 +329,18 @@ def main():
                          "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic,
                          "timing": "HIP events around every launch, same K steps repeated right after the timed region"},
             "kernels": kernels,
-            "options": {k: _lib.get_option(k) for k in ("xcd_map", "value_path", "stage_kb", "overlap")},
+            "options": {k: _lib.get_option(k) for k in ("xcd_map", "value_path", "overlap")},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wl)
+    strong = None
+    if not args.no_strong_c5 and args.workload == "c2_q10k":
+        del img, pts, attn, d
+        torch.cuda.empty_cache()
+        strong = strong_scaling_c5(dev, world, rank, use_dist)  # every rank takes part; rank 0 reports
+    if rank == 0:
+        if strong is not None:
+            result["strong_scaling_c5"] = strong
         print(json.dumps(result))
     if use_dist:
         dist.barrier()

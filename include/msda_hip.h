@@ -142,12 +142,14 @@ MSDA_API const char *msda_last_error(void);
  * MSDA_ERR_BAD_ARG.  Keys:
  *   "xcd_map"    1 (default): blockIdx -> (batch, head) mapping keeps each (b,h) plane on one XCD's L2
  *                0: plain linear mapping
- *   "value_path" 0 (default): grad_value by sorted gather when a workspace is supplied, except for small
- *                   problems where the single-launch LDS-tile kernel is faster
- *                1: always the LDS-tile kernel      2: always the sorted gather (if a workspace is supplied)
- *   "stage_kb"   LDS KiB a forward workgroup may spend on staged pyramid levels (the smallest levels that fit are
- *                served from LDS; default 0 = off)
- *   "cell_slices", "wg_target", "overlap", "debug": experiment knobs, see msda_triton_amd/csrc/msda_launch.hpp
+ *   "value_path" 0 (default): grad_value by the single-launch LDS kernel when a (plane, level) fits one workgroup
+ *                   (small problems; no workspace needed), else by the sorted gather when a workspace is supplied,
+ *                   else by the LDS-tile kernel
+ *                1: always the LDS-tile kernel   2: the sorted gather (if a workspace is supplied)
+ *                3: the single-launch kernel whenever it fits
+ *   "overlap"    -1 (default): grad_loc/grad_attn run on a forked side stream next to the single-launch grad_value
+ *                   kernel only;  0: never;  1: always
+ *   "cell_slices", "gather_wg", "small_ns", "wg_target", "debug": experiment knobs, see msda_triton_amd/csrc/msda_launch.hpp
  */
 MSDA_API int msda_set_option(const char *key, int value);
 MSDA_API int msda_get_option(const char *key);

@@ -14,7 +14,6 @@ namespace msda {
 
 static std::atomic<int> g_xcd_map{1};
 static std::atomic<int> g_value_path{0};
-static std::atomic<int> g_stage_kb{0};
 static std::atomic<int> g_wg_target{1 << 30};
 static std::atomic<int> g_cell_slices{0};
 static std::atomic<int> g_debug{0};
@@ -72,7 +71,6 @@ static thread_local char g_err[256] = "";
 
 int option_xcd_map() { return g_xcd_map.load(std::memory_order_relaxed); }
 int option_value_path() { return g_value_path.load(std::memory_order_relaxed); }
-int option_stage_kb() { return g_stage_kb.load(std::memory_order_relaxed); }
 int option_wg_target() { return g_wg_target.load(std::memory_order_relaxed); }
 int option_cell_slices() { return g_cell_slices.load(std::memory_order_relaxed); }
 int option_debug() { return g_debug.load(std::memory_order_relaxed); }
@@ -128,10 +126,6 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_value_path.store(value < 0 || value > 3 ? 0 : value, std::memory_order_relaxed);
         return 0;
     }
-    if (key && strcmp(key, "stage_kb") == 0 && value >= 0 && value <= 156) {
-        msda::g_stage_kb.store(value, std::memory_order_relaxed);
-        return 0;
-    }
     if (key && strcmp(key, "debug") == 0) {
         msda::g_debug.store(value, std::memory_order_relaxed);
         return 0;
@@ -164,7 +158,6 @@ extern "C" int msda_get_option(const char *key)
 {
     if (key && strcmp(key, "xcd_map") == 0) return msda::option_xcd_map();
     if (key && strcmp(key, "value_path") == 0) return msda::option_value_path();
-    if (key && strcmp(key, "stage_kb") == 0) return msda::option_stage_kb();
     if (key && strcmp(key, "wg_target") == 0) return msda::option_wg_target();
     if (key && strcmp(key, "cell_slices") == 0) return msda::option_cell_slices();
     if (key && strcmp(key, "debug") == 0) return msda::option_debug();

@@ -24,9 +24,9 @@ extern "C" __attribute__((visibility("hidden"))) int64_t msda_fused_lp_limit_imp
     int64_t best = INT64_MAX;
     for (int vec : {16 / elem_size, 1}) {
         const int NU = msda::kBlock / msda::pick_group((int)((D + vec - 1) / vec));
-        int sc, stage_bytes;
+        int sc;
         size_t lds;
-        msda::plan_gather(NU, 1 << 22, acc, 0, (int)(D * elem_size), sc, stage_bytes, lds, true);
+        msda::plan_gather(NU, 1 << 22, acc, sc, lds, true);
         if (sc < best) best = sc;
     }
     return best;

@@ -13,9 +13,8 @@
 //   sample, park {4 row offsets, 4 weights} in the wave's LDS slice.  Loads are coalesced along (l, p).
 // Phase 2 (per unit, G lanes): broadcast-read the parked record, fetch the four rows with range-checked
 //   16-byte buffer loads, FMA into per-lane accumulators.  No block barrier: a wave reads only its own records.
-// Optional (forward only, msda_set_option("stage_kb", n), off by default): the smallest pyramid levels that fit
-//   n KiB are copied into LDS once per workgroup and their rows are served by ds_read_b128 instead of the
-//   vector-memory path (measured on MI355X, c2 @ 10k: level 3 staged, 9 KiB: forward 111 -> 99 us).
+// (Serving the coarsest pyramid levels from an LDS copy was measured twice — 1024-thread groups in round 1, 256-thread
+//  groups with 9 / 15 / 41 KiB in round 2 — and removed: -7 % on c2 @ 10k only, slower on c1 / c3 / c5)
 #pragma once
 
 #include "msda_common.hpp"
@@ -36,7 +35,6 @@ struct Params {
     int nqc;       // query chunks per (b,h) plane (gather kernels)
     int qw;        // query chunks handled by one workgroup (amortises the level staging)
     int sc;        // samples of a unit parked in LDS at a time (<= LP)
-    int stage_bytes;  // LDS bytes available for staged levels (0: no staging)
     int zeros, align, xcd_map;
     const void *ref;  // fused module prologue: reference points [B, Q, ref_dim]; then `loc` holds the raw projection [B,Q,H,L,P,3]
     int ref_dim;      // 2: (x, y)   4: (cx, cy, w, h)
@@ -74,77 +72,6 @@ template <typename A> struct alignas(16) Rec4 {
     A v[4];
 };
 
-// ------------------------------------------------------------------------------------------
-// level staging
-// ------------------------------------------------------------------------------------------
-struct StagePlan {
-    int off[kMaxLevels];  // byte offset of the level's copy inside the stage area, or -1 (not staged)
-    int zero_off;         // a row of zeros: where masked corners of staged levels point
-};
-
-// Decide (thread 0) which levels are staged, then copy them (all threads).  Levels are taken from the
-// last to the first (coarse to fine in the usual ordering) while they fit.  Caller syncs before and after.
-template <typename T>
-__device__ __forceinline__ void stage_levels(const LevelTab *tab, StagePlan *plan, unsigned char *stage, rsrc_t rs,
-                                             uint32_t row_bytes, int row_b, int budget, int L)
-{
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        int used = row_b;  // slot 0 is the zero row
-        plan->zero_off = 0;
-        for (int l = L - 1; l >= 0; --l) {
-            const long long bytes = (long long)tab->h[l] * tab->w[l] * row_b;
-            if (budget > 0 && used + bytes <= (long long)budget) {
-                plan->off[l] = used;
-                used += (int)bytes;
-            } else {
-                plan->off[l] = -1;
-            }
-        }
-    }
-    __syncthreads();
-    if (budget <= 0) return;
-    const int cpr = row_b / 16;  // 16-byte pieces per row
-    for (int i = tid; i < cpr; i += kBlock) reinterpret_cast<uint4 *>(stage)[i] = make_uint4(0, 0, 0, 0);
-    const float inv_cpr = 1.0f / (float)cpr;
-    for (int l = 0; l < L; ++l) {
-        const int so = plan->off[l];
-        if (so < 0) continue;  // uniform
-        const int pieces = tab->h[l] * tab->w[l] * cpr;
-        const uint32_t src0 = (uint32_t)tab->start[l] * row_bytes;
-        for (int c = tid; c < pieces; c += kBlock) {
-            const int r = div_small(c, cpr, inv_cpr), part = c - r * cpr;
-            const auto v = RawLoad<16>::load(rs, src0 + (uint32_t)r * row_bytes + (uint32_t)part * 16u);
-            *reinterpret_cast<RawLoad<16>::type *>(stage + so + c * 16) = v;
-        }
-    }
-}
-
-// record offsets of one sample: staged level -> byte offset inside the stage area, else global plane offset
-template <typename A>
-__device__ __forceinline__ uint4 record_offsets(const Taps<A> &t, int stage_off, int zero_off, int row_b, int start,
-                                                uint32_t row_bytes)
-{
-    uint32_t o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t rel = t.off[k];  // pixel index inside the level, or kMaskedOffset
-        if (stage_off >= 0)
-            o[k] = rel == kMaskedOffset ? (uint32_t)zero_off : (uint32_t)stage_off + mul24(rel, (uint32_t)row_b);
-        else
-            o[k] = rel == kMaskedOffset ? kMaskedOffset : mul24((uint32_t)start + rel, row_bytes);
-    }
-    return make_uint4(o[0], o[1], o[2], o[3]);
-}
-
-template <typename T, int VEC>
-__device__ __forceinline__ void lds_row(const unsigned char *stage, uint32_t off, typename Traits<T>::acc (&dst)[VEC])
-{
-    const Pack<T, VEC> p = *reinterpret_cast<const Pack<T, VEC> *>(stage + off);
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) dst[i] = Traits<T>::to_acc(p.v[i]);
-}
-
 // Records parked by a wave are read back only by that same wave: DS operations of one wave execute
 // in order, so no s_barrier is needed — only a compiler fence so the accesses are not reordered.
 __device__ __forceinline__ void wave_lds_sync()
@@ -157,34 +84,28 @@ __device__ __forceinline__ void wave_lds_sync()
 // shared LDS carve-up of the two gather kernels
 template <typename A> struct GatherLds {
     LevelTab *tab;
-    StagePlan *plan;
     uint4 *s_off;
     Rec4<A> *s_rec;
     A *s_aux;  // fused backward only: per record slot (attention weight, x offset, y offset)
-    unsigned char *stage;
     __device__ __forceinline__ GatherLds(int units, int scp, bool aux = false)
     {
         unsigned char *p = msda_smem;
         tab = reinterpret_cast<LevelTab *>(p);
-        p += sizeof(LevelTab);
-        plan = reinterpret_cast<StagePlan *>(p);
-        p += (sizeof(StagePlan) + 15) / 16 * 16;
+        p += (sizeof(LevelTab) + 15) / 16 * 16;
         s_off = reinterpret_cast<uint4 *>(p);
         p += (size_t)units * scp * sizeof(uint4);
         s_rec = reinterpret_cast<Rec4<A> *>(p);
         p += (size_t)units * scp * sizeof(Rec4<A>);
         s_aux = reinterpret_cast<A *>(p);
-        if (aux) p += (size_t)units * scp * 3 * sizeof(A);
-        stage = p;
     }
 };
-constexpr size_t kGatherLdsFixed = sizeof(LevelTab) + (sizeof(StagePlan) + 15) / 16 * 16;
+constexpr size_t kGatherLdsFixed = (sizeof(LevelTab) + 15) / 16 * 16;
 
 // ==========================================================================================
 // forward.  After the one-time staging barrier every wave runs on its own: it parks the records of
 // ITS 64/G units, gathers, stores, and moves to its next query chunk without any block barrier.
 // ==========================================================================================
-template <typename T, int VEC, int G, bool STAGE, bool FUSED>
+template <typename T, int VEC, int G, bool FUSED>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void msda_fwd_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
@@ -202,17 +123,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     LevelTab *tab = lds.tab;
 
     const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);
-    const int row_b = p.D * (int)sizeof(T);
     const T *plane = static_cast<const T *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
     const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(T));
     const rsrc_t rs = make_rsrc(plane, plane_bytes);
 
     load_level_table(tab, p.shapes, p.L);
     __syncthreads();
-    if constexpr (STAGE) {
-        stage_levels<T>(tab, lds.plan, lds.stage, rs, row_bytes, row_b, p.stage_bytes, p.L);
-        __syncthreads();
-    }
 
     const int tid = threadIdx.x;
     const int wave = tid / kWave, lane = tid % kWave;
@@ -311,8 +227,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                             a = TR::to_acc(attn[sidx]);
                         }
                         Taps<A> t;
-                        make_taps<A>(sx, sy, tab->h[l], tab->w[l], STAGE ? 0 : tab->start[l], p.zeros, p.align,
-                                     STAGE ? 1u : row_bytes, t);
+                        make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l], p.zeros, p.align, row_bytes, t);
                         const A wy0 = (A)1 - t.dy, wx0 = (A)1 - t.dx;
                         Rec4<A> w;
                         w.v[0] = a * (wy0 * wx0);
@@ -320,58 +235,30 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                         w.v[2] = a * (t.dy * wx0);
                         w.v[3] = a * (t.dy * t.dx);
                         const int rslot = imul24(fu, scp) + (sl - s0);
-                        if constexpr (STAGE)
-                            w_off[rslot] = record_offsets(t, lds.plan->off[l], lds.plan->zero_off, row_b, tab->start[l], row_bytes);
-                        else
-                            w_off[rslot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
+                        w_off[rslot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
                         w_rec[rslot] = w;
                     }
                 }
                 wave_lds_sync();
-                // ---- phase 2: gather + blend, one level (run of samples) at a time ----
+                // ---- phase 2: gather + blend ----
                 if (lane_ok) {
                     const uint4 *uo = w_off + imul24(wunit, scp);
                     const Rec4<A> *uw = w_rec + imul24(wunit, scp);
-                    int s = 0;
-                    int l = div_small(s0, p.P, inv_P);  // level of the first sample; later runs are the next levels
-                    for (; s < sc; ++l) {
-                        const int run_end = min(sc, (l + 1) * p.P - s0);
-                        if (STAGE && lds.plan->off[l] >= 0) {
 #pragma unroll 4
-                            for (; s < run_end; ++s) {
-                                const uint4 o = uo[s];
-                                const Rec4<A> w = uw[s];
-                                A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-                                lds_row<T, VEC>(lds.stage, o.x + lane_off, v0);
-                                lds_row<T, VEC>(lds.stage, o.y + lane_off, v1);
-                                lds_row<T, VEC>(lds.stage, o.z + lane_off, v2);
-                                lds_row<T, VEC>(lds.stage, o.w + lane_off, v3);
+                    for (int s = 0; s < sc; ++s) {
+                        const uint4 o = uo[s];
+                        const Rec4<A> w = uw[s];
+                        A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                        load_row<T, VEC>(rs, o.x + lane_off, v0);
+                        load_row<T, VEC>(rs, o.y + lane_off, v1);
+                        load_row<T, VEC>(rs, o.z + lane_off, v2);
+                        load_row<T, VEC>(rs, o.w + lane_off, v3);
 #pragma unroll
-                                for (int i = 0; i < VEC; ++i) {  // four chained FMAs per channel: no product tree to re-pack
-                                    acc[i] = fma_t(w.v[0], v0[i], acc[i]);
-                                    acc[i] = fma_t(w.v[1], v1[i], acc[i]);
-                                    acc[i] = fma_t(w.v[2], v2[i], acc[i]);
-                                    acc[i] = fma_t(w.v[3], v3[i], acc[i]);
-                                }
-                            }
-                        } else {
-#pragma unroll 4
-                            for (; s < run_end; ++s) {
-                                const uint4 o = uo[s];
-                                const Rec4<A> w = uw[s];
-                                A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-                                load_row<T, VEC>(rs, o.x + lane_off, v0);
-                                load_row<T, VEC>(rs, o.y + lane_off, v1);
-                                load_row<T, VEC>(rs, o.z + lane_off, v2);
-                                load_row<T, VEC>(rs, o.w + lane_off, v3);
-#pragma unroll
-                                for (int i = 0; i < VEC; ++i) {  // four chained FMAs per channel: no product tree to re-pack
-                                    acc[i] = fma_t(w.v[0], v0[i], acc[i]);
-                                    acc[i] = fma_t(w.v[1], v1[i], acc[i]);
-                                    acc[i] = fma_t(w.v[2], v2[i], acc[i]);
-                                    acc[i] = fma_t(w.v[3], v3[i], acc[i]);
-                                }
-                            }
+                        for (int i = 0; i < VEC; ++i) {  // four chained FMAs per channel: no product tree to re-pack
+                            acc[i] = fma_t(w.v[0], v0[i], acc[i]);
+                            acc[i] = fma_t(w.v[1], v1[i], acc[i]);
+                            acc[i] = fma_t(w.v[2], v2[i], acc[i]);
+                            acc[i] = fma_t(w.v[3], v3[i], acc[i]);
                         }
                     }
                 }

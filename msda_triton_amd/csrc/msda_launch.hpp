@@ -15,7 +15,6 @@ namespace msda {
 // ---- process-wide options and per-thread error text (defined in msda_api.hip) ----
 int option_xcd_map();
 int option_value_path();  // 0: auto (single-launch LDS kernel when a plane-level fits, else sorted gather), 1: LDS tile kernel, 2: sorted, 3: single-launch
-int option_stage_kb();    // LDS KiB a gather workgroup may spend on staged pyramid levels (0: off)
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
 int option_gather_wg();     // threads per workgroup of the grad_value gather kernel (64 / 128 / 256)
 int option_small_ns();      // workgroups per (plane, level) of the single-launch grad_value kernel (0: automatic)
@@ -128,20 +127,14 @@ inline int pick_group(int lanes_needed)
     return 64;
 }
 
-// samples of a unit parked in LDS at a time (records), staged-level bytes, total dynamic LDS
-inline void plan_gather(int NU, int LP, size_t acc_bytes, int stage_want, int row_b, int &sc, int &stage_bytes,
-                        size_t &lds, bool aux = false)
+// samples of a unit parked in LDS at a time (records) and the total dynamic LDS
+inline void plan_gather(int NU, int LP, size_t acc_bytes, int &sc, size_t &lds, bool aux = false)
 {
     const size_t rec = 16 + (aux ? 7 : 4) * acc_bytes;  // aux: the fused backward's (a, ox, oy) per slot
     int cap = (int)((size_t)kRecordLdsBudget / (NU * rec)) - 1;
     if (cap < 1) cap = 1;
     sc = LP < cap ? LP : cap;
-    const size_t base = kGatherLdsFixed + (size_t)NU * (sc + 1) * rec;
-    long long stage = stage_want;
-    if (stage > (long long)kMaxDynLds - (long long)base) stage = (long long)kMaxDynLds - (long long)base;
-    if (stage < 2LL * row_b) stage = 0;  // not even the zero row plus one pixel
-    stage_bytes = (int)stage;
-    lds = base + (size_t)stage_bytes;
+    lds = kGatherLdsFixed + (size_t)NU * (sc + 1) * rec;
 }
 
 // MODE 0: forward, 1: grad_loc/grad_attn, 2: fused forward, 3: fused backward (sample half)
@@ -150,13 +143,10 @@ template <typename T, int VEC, int G, int MODE> inline int launch_gather(Params 
     using A = typename Traits<T>::acc;
     constexpr int NU = kBlock / G;
     size_t lds;
-    // level staging serves the plain forward only (the backward's records fill the LDS it would need, and the
-    // fused kernels' L*P limit must not depend on an option)
-    const int stage_want = (VEC > 1 && MODE == 0) ? option_stage_kb() * 1024 : 0;
-    plan_gather(NU, p.LP, sizeof(A), stage_want, p.D * (int)sizeof(T), p.sc, p.stage_bytes, lds, MODE == 3);
+    plan_gather(NU, p.LP, sizeof(A), p.sc, lds, MODE == 3);
     p.nqc = (p.Q + NU - 1) / NU;
     const int npairs = p.B * p.H;
-    // query chunks per workgroup: amortise the level staging, but keep the chip full
+    // query chunks per workgroup (1 unless the wg_target experiment knob says otherwise)
     long long qw = ((long long)p.nqc * npairs) / option_wg_target();
     p.qw = (int)(qw < 1 ? 1 : qw > 64 ? 64 : qw);
     const int slots = (p.nqc + p.qw - 1) / p.qw;
@@ -179,16 +169,11 @@ template <typename T, int VEC, int G, int MODE> inline int launch_gather(Params 
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else if constexpr (MODE == 2) {
-        auto kernel = msda_fwd_kernel<T, VEC, G, false, true>;
+        auto kernel = msda_fwd_kernel<T, VEC, G, true>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
-    } else if (p.stage_bytes > 0) {
-        static std::atomic<uint64_t> big_lds_done_staged{0};
-        auto kernel = msda_fwd_kernel<T, VEC, G, true, false>;
-        allow_big_lds(kernel, big_lds_done_staged);
-        hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else {
-        auto kernel = msda_fwd_kernel<T, VEC, G, false, false>;
+        auto kernel = msda_fwd_kernel<T, VEC, G, false>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     }
@@ -366,7 +351,6 @@ inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_co
     p.xcd_map = option_xcd_map();
     p.nqc = p.sc = p.nchunks = p.nranges = p.range_px = 0;
     p.qw = 1;
-    p.stage_bytes = 0;
     p.grid3d = 0;
     p.ref = nullptr;
     p.ref_dim = 0;

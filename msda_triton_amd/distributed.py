@@ -16,9 +16,11 @@ Two partitions are offered:
 
   rows     (:func:`row_sharded_multiscale_deformable_attention`, what ``bench.py --gpus N`` runs) — contiguous
            ranges of the flattened ``[B*Q]`` row space.  The per-rank output slices are contiguous in the final
-           ``[B, Q, H, D]`` tensor, so ONE ``all_gather_into_tensor`` lands them in place; a rank touches only the
-           batch elements its rows fall into, so grad_value needs no communication at all when the ranks divide
-           B, and otherwise only a sum among the ranks that share a batch element.
+           ``[B, Q, H, D]`` tensor: the kernels write them in place and the exchange (one ``all_gather_into_tensor``,
+           or grouped point-to-point pieces that overlap the next piece's kernels) lands the peers' rows in place
+           too — no local tensor, padding or concatenation; a rank touches only the batch elements its rows fall
+           into, so grad_value needs no communication at all when the ranks divide B, and otherwise only a sum
+           among the ranks that share a batch element.
   queries  (:func:`sharded_multiscale_deformable_attention`) — every rank takes the same query range of every
            batch element (sequence-parallel style callers that already hold ``[B, Q/N, ...]`` slices).
 """
@@ -200,57 +202,156 @@ def _owner_groups(B: int, Q: int, group):
     return out
 
 
-class _GatherRows(Function):
-    """local rows [per, H, D] on every rank -> [B, Q, H, D] on every rank with one all-gather (the slices are
-    contiguous in the result).  Backward: this rank's rows of the incoming gradient (replicated consumers) or a
-    reduce-scatter of it (``grad_sync="reduce_scatter"``)."""
+def _chunk_bounds(n: int, chunks: int, k: int) -> Tuple[int, int]:
+    """Rows [begin, end) of chunk ``k`` when ``n`` rows are cut into ``chunks`` ceil-sized pieces."""
+    cs = -(-n // chunks) if chunks > 0 else n
+    begin = min(n, k * cs)
+    return begin, min(n, begin + cs)
+
+
+def _run_pieces(fn, num_queries: int, row0: int, row1: int):
+    """Call ``fn(b, nb, q0, q1, rows_before)`` for the pieces of the row range [row0, row1): runs of whole batch
+    elements become ONE piece (nb > 1), a partial batch element its own."""
+    segs = row_segments(num_queries, row0, row1)
+    i, done = 0, 0
+    while i < len(segs):
+        b, q0, q1 = segs[i]
+        nb = 1
+        if q0 == 0 and q1 == num_queries:
+            while i + nb < len(segs) and segs[i + nb][1] == 0 and segs[i + nb][2] == num_queries:
+                nb += 1
+        fn(b, nb, q0, q1, done)
+        done += (q1 - q0) if nb == 1 else nb * num_queries
+        i += nb
+
+
+class _RowShardedMSDA(Function):
+    """The whole sharded operator as ONE autograd node.
+
+    forward: this rank's rows are computed in ``chunks`` pieces, each written by the kernel STRAIGHT into its place
+    in the full ``[B*Q, H, D]`` result (no local tensor, no padding, no concatenation); as soon as a piece is
+    enqueued its exchange starts — every rank sends the piece to every peer and receives the peers' pieces into
+    their final rows (grouped point-to-point: on the xGMI full mesh each pair uses its own link) — while the next
+    piece computes.  Equal shards and ``chunks == 1`` take one ``all_gather_into_tensor`` instead.
+    backward: this rank's rows of the incoming gradient (replicated consumers) or a reduce-scatter; the local
+    backward kernels; grad_value summed as ``grad_value_sync`` says.  Every rank runs every collective, whatever its
+    shard holds (an empty shard computes nothing and still takes part).
+    """
 
     @staticmethod
-    def forward(ctx, local: torch.Tensor, B: int, Q: int, group, grad_sync: str):
-        world = dist.get_world_size(group)
-        per, H, D = local.shape
-        ctx.group, ctx.world, ctx.rank, ctx.per, ctx.grad_sync = group, world, dist.get_rank(group), per, grad_sync
-        buf = local.new_empty((world * per, H, D))
-        _all_gather_into(buf.view(world, per, H, D), local.contiguous(), group)
-        return buf[:B * Q].view(B, Q, H, D)
+    def forward(ctx, img, img_shapes, pts_rows, att_rows, padding_mode, align_corners, num_queries, group,
+                grad_value_sync, grad_sync, owner_groups, chunks):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        B, _, H, D = img.shape
+        Q = int(num_queries)
+        rows = B * Q
+        bounds = [row_shard_bounds(rows, world, r) for r in range(world)]
+        r0, r1 = bounds[rank]
+        gpu = img.device.type == "cuda"
+        full = img.new_empty((rows, H, D))
+        equal = all(e - b == bounds[0][1] - bounds[0][0] for b, e in bounds)
+        chunks = max(1, int(chunks))
+        pending = []
+        for k in range(chunks):
+            c0, c1 = _chunk_bounds(r1 - r0, chunks, k)
+
+            def piece(b, nb, q0, q1, before, c0=c0):
+                n = (q1 - q0) if nb == 1 else nb * Q
+                at = c0 + before
+                pts = pts_rows[at:at + n].reshape(nb, n // nb, *pts_rows.shape[1:])
+                att = att_rows[at:at + n].reshape(nb, n // nb, *att_rows.shape[1:])
+                dst = full[r0 + at:r0 + at + n].view(nb, n // nb, H, D)
+                if gpu:
+                    from .functional import msda_hip_fwd
+                    msda_hip_fwd(img[b:b + nb], img_shapes, pts, att, padding_mode, align_corners, out=dst)
+                else:
+                    with torch.no_grad():
+                        dst.copy_(multiscale_deformable_attention(img[b:b + nb], img_shapes, pts, att, padding_mode,
+                                                                  align_corners))
+
+            _run_pieces(piece, Q, r0 + c0, r0 + c1)
+            if world == 1:
+                continue
+            if chunks == 1 and equal:
+                per = r1 - r0
+                _all_gather_into(full.view(world, per, H, D), full[r0:r1], group)  # in place: my rows are already there
+                continue
+            ops = []
+            for peer in range(world):
+                if peer == rank:
+                    continue
+                gpeer = dist.get_global_rank(group, peer) if group is not None else peer
+                if c1 > c0:
+                    ops.append(dist.P2POp(dist.isend, full[r0 + c0:r0 + c1], gpeer, group))
+                p0, p1 = bounds[peer]
+                pc0, pc1 = _chunk_bounds(p1 - p0, chunks, k)
+                if pc1 > pc0:
+                    ops.append(dist.P2POp(dist.irecv, full[p0 + pc0:p0 + pc1], gpeer, group))
+            if ops:
+                pending.extend(dist.batch_isend_irecv(ops))
+        for req in pending:
+            req.wait()
+        ctx.save_for_backward(img, img_shapes, pts_rows, att_rows)
+        ctx.meta = (padding_mode, align_corners, Q, group, grad_value_sync, grad_sync, owner_groups, world, rank, r0, r1)
+        return full.view(B, Q, H, D)
 
     @staticmethod
-    def backward(ctx, grad_full: torch.Tensor):
-        B, Q, H, D = grad_full.shape
-        per, world = ctx.per, ctx.world
-        rows = grad_full.reshape(B * Q, H, D)
-        if B * Q < world * per:
-            rows = torch.nn.functional.pad(rows, (0, 0, 0, 0, 0, world * per - B * Q))
-        if ctx.grad_sync == "reduce_scatter":
-            mine = torch.empty_like(rows[:per])
-            dist.reduce_scatter_tensor(mine, rows.contiguous(), group=ctx.group)
+    def backward(ctx, grad_full):
+        img, img_shapes, pts_rows, att_rows = ctx.saved_tensors
+        padding_mode, align_corners, Q, group, grad_value_sync, grad_sync, owner_groups, world, rank, r0, r1 = ctx.meta
+        B, _, H, D = img.shape
+        rows = B * Q
+        need_img, _, need_pts, need_att = ctx.needs_input_grad[:4]
+        g_rows = grad_full.reshape(rows, H, D)
+        if grad_sync == "reduce_scatter" and world > 1:
+            per = -(-rows // world)
+            padded = g_rows if rows == world * per else torch.nn.functional.pad(g_rows, (0, 0, 0, 0, 0, world * per - rows))
+            mine = torch.empty_like(padded[:per])
+            dist.reduce_scatter_tensor(mine, padded.contiguous(), group=group)
+            mine = mine[:r1 - r0]
         else:
-            mine = rows[ctx.rank * per:(ctx.rank + 1) * per]
-        return mine, None, None, None, None
+            mine = g_rows[r0:r1]
+        gpu = img.device.type == "cuda"
+        g_img = torch.zeros_like(img) if need_img else None
+        g_pts = torch.empty_like(pts_rows) if need_pts else None
+        g_att = torch.empty_like(att_rows) if need_att else None
 
+        def piece(b, nb, q0, q1, before):
+            n = (q1 - q0) if nb == 1 else nb * Q
+            pts = pts_rows[before:before + n].reshape(nb, n // nb, *pts_rows.shape[1:])
+            att = att_rows[before:before + n].reshape(nb, n // nb, *att_rows.shape[1:])
+            go = mine[before:before + n].reshape(nb, n // nb, H, D)
+            if gpu:
+                from .functional import msda_hip_bwd
+                gi, gp, ga = msda_hip_bwd(go, img[b:b + nb], img_shapes, pts, att, padding_mode, align_corners,
+                                          (need_img, need_pts, need_att))
+            else:
+                with torch.enable_grad():
+                    v_ = img[b:b + nb].detach().requires_grad_(need_img)
+                    p_ = pts.detach().requires_grad_(need_pts)
+                    a_ = att.detach().requires_grad_(need_att)
+                    o_ = multiscale_deformable_attention(v_, img_shapes, p_, a_, padding_mode, align_corners)
+                wrt = [t for t, nd in ((v_, need_img), (p_, need_pts), (a_, need_att)) if nd]
+                got = list(torch.autograd.grad(o_, wrt, go)) if wrt else []
+                gi = got.pop(0) if need_img else None
+                gp = got.pop(0) if need_pts else None
+                ga = got.pop(0) if need_att else None
+            if need_img:
+                g_img[b:b + nb] += gi
+            if need_pts:
+                g_pts[before:before + n] = gp.reshape(n, *pts_rows.shape[1:])
+            if need_att:
+                g_att[before:before + n] = ga.reshape(n, *att_rows.shape[1:])
 
-class _ValueGradSync(Function):
-    """Identity in forward.  Backward: ``"all_reduce"`` — every rank gets the complete grad_value (value computed
-    redundantly on every rank); ``"owners"`` — per batch element, summed among the ranks whose rows fall into
-    it (other batch elements keep this rank's zeros; no communication when the ranks divide B); ``"none"``."""
-
-    @staticmethod
-    def forward(ctx, value: torch.Tensor, mode: str, owner_groups, group):
-        ctx.mode, ctx.owner_groups, ctx.group = mode, owner_groups, group
-        return value.view_as(value)
-
-    @staticmethod
-    def backward(ctx, grad: torch.Tensor):
-        if ctx.mode == "all_reduce":
-            grad = grad.contiguous()
-            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=ctx.group)
-        elif ctx.mode == "owners":
-            grad = grad.contiguous()
-            me = dist.get_rank(ctx.group)
-            for b, (ranks, pg) in enumerate(ctx.owner_groups):  # ascending b on every rank: no cyclic waits
-                if pg is not None and me in ranks:
-                    dist.all_reduce(grad[b], op=dist.ReduceOp.SUM, group=pg)
-        return grad, None, None, None
+        _run_pieces(piece, Q, r0, r1)
+        if need_img and world > 1:
+            if grad_value_sync == "all_reduce":
+                dist.all_reduce(g_img, op=dist.ReduceOp.SUM, group=group)
+            elif grad_value_sync == "owners":
+                for b, (ranks, pg) in enumerate(owner_groups):  # ascending b on every rank: no cyclic waits
+                    if pg is not None and rank in ranks:
+                        dist.all_reduce(g_img[b], op=dist.ReduceOp.SUM, group=pg)
+        return (g_img, None, g_pts, g_att) + (None,) * 8
 
 
 def row_sharded_multiscale_deformable_attention(
@@ -265,8 +366,12 @@ def row_sharded_multiscale_deformable_attention(
     num_queries: Optional[int] = None,
     grad_value_sync: Literal["all_reduce", "owners", "none"] = "all_reduce",
     grad_sync: Literal["slice", "reduce_scatter"] = "slice",
+    overlap_chunks: Optional[int] = None,
 ) -> torch.Tensor:
     """Row-sharded operator; returns the full ``[B, Q, H, D]`` output on every rank.
+
+    ``overlap_chunks``: pieces the local rows are computed and exchanged in (piece k's exchange overlaps piece k+1's
+    kernels); None picks 1 .. 4 by shard size.
 
     ``img`` is ``[B, I, H, D]`` on every rank (a rank only reads the batch elements its rows fall into).
     ``inputs_are_sharded=False``: ``sampling_points [B,Q,H,L,P,2]`` / ``attention_weights [B,Q,H,L,P]`` are
@@ -288,7 +393,6 @@ def row_sharded_multiscale_deformable_attention(
         Q = sampling_points.shape[1]
     rows = B * Q
     r0, r1 = row_shard_bounds(rows, world, rank)
-    per = -(-rows // world)
     if inputs_are_sharded:
         if sampling_points.shape[0] != r1 - r0:
             raise ValueError(f"rank {rank} owns rows [{r0}, {r1}) but got {sampling_points.shape[0]} rows")
@@ -296,33 +400,9 @@ def row_sharded_multiscale_deformable_attention(
     else:
         pts_rows = sampling_points.reshape(rows, *sampling_points.shape[2:])[r0:r1]
         att_rows = attention_weights.reshape(rows, *attention_weights.shape[2:])[r0:r1]
-    if img.requires_grad and grad_value_sync != "none":
-        owners = _owner_groups(B, Q, group) if grad_value_sync == "owners" else None
-        img = _ValueGradSync.apply(img, grad_value_sync, owners, group)
-    H, D = img.shape[2], img.shape[3]
-    segs = row_segments(Q, r0, r1)
-    pieces = []
-    if segs and all(q0 == 0 and q1 == Q for _, q0, q1 in segs):  # whole batch elements: one launch
-        b0, nb = segs[0][0], len(segs)
-        out = multiscale_deformable_attention(img[b0:b0 + nb], img_shapes,
-                                              pts_rows.reshape(nb, Q, *pts_rows.shape[1:]),
-                                              att_rows.reshape(nb, Q, *att_rows.shape[1:]), padding_mode, align_corners)
-        pieces.append(out.reshape(nb * Q, H, D))
-    else:
-        at = 0
-        for b, q0, q1 in segs:
-            n = q1 - q0
-            out = multiscale_deformable_attention(img[b:b + 1], img_shapes, pts_rows[at:at + n].unsqueeze(0),
-                                                  att_rows[at:at + n].unsqueeze(0), padding_mode, align_corners)
-            pieces.append(out.reshape(n, H, D))
-            at += n
-    if not segs:
-        # empty shard (more ranks than rows): still run the operator on zero rows, so that this rank's graph reaches
-        # `img` and its _ValueGradSync backward joins the grad_value collective the other ranks are waiting in
-        out = multiscale_deformable_attention(img[:1], img_shapes, pts_rows[:0].unsqueeze(0), att_rows[:0].unsqueeze(0),
-                                              padding_mode, align_corners)
-        pieces.append(out.reshape(0, H, D))
-    if r1 - r0 < per:  # short / empty trailing shard: pad so the all-gather is regular
-        pieces.append(img.new_zeros((per - (r1 - r0), H, D)))
-    local = pieces[0] if len(pieces) == 1 else torch.cat(pieces, 0)
-    return _GatherRows.apply(local, B, Q, group, grad_sync)
+    owners = _owner_groups(B, Q, group) if (grad_value_sync == "owners" and img.requires_grad) else None
+    if overlap_chunks is None:  # exchange piece by piece only when a piece is worth a message (>= ~2k rows); the
+        # count must be the same on every rank, so it follows the nominal shard size, not this rank's
+        overlap_chunks = max(1, min(4, -(-rows // world) // 2048)) if world > 1 else 1
+    return _RowShardedMSDA.apply(img, img_shapes, pts_rows, att_rows, padding_mode, bool(align_corners), Q, group,
+                                 grad_value_sync, grad_sync, owners, overlap_chunks)

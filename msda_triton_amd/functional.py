@@ -156,15 +156,21 @@ class KernelTimer:
 # ------------------------------------------------------------------------------------------
 # launcher pair — the native seam (reference: kernels.py:351-379, 556-592)
 # ------------------------------------------------------------------------------------------
-def msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners) -> torch.Tensor:
-    """Allocate ``out`` and enqueue the forward kernel on the current stream (no host sync)."""
+def msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Allocate ``out`` (or write into the caller's contiguous ``[B, Q, H, D]`` buffer, e.g. a slice of a gather
+    buffer) and enqueue the forward kernel on the current stream (no host sync)."""
     B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
     _check_devices(img, img_shapes, sampling_points, attention_weights)
     pad = _padding_code(padding_mode)
     suf = _SUFFIX[img.dtype]
     img, sampling_points, attention_weights = img.contiguous(), sampling_points.contiguous(), attention_weights.contiguous()
     shapes = _shapes_i64(img_shapes)
-    out = torch.empty((B, Q, H, D), dtype=img.dtype, device=img.device)
+    if out is None:
+        out = torch.empty((B, Q, H, D), dtype=img.dtype, device=img.device)
+    elif tuple(out.shape) != (B, Q, H, D) or out.dtype != img.dtype or out.device != img.device or not out.is_contiguous():
+        raise ValueError(f"`out` should be a contiguous {(B, Q, H, D)} {img.dtype} tensor on {img.device}, but got "
+                         f"{tuple(out.shape)} {out.dtype} on {out.device} (contiguous: {out.is_contiguous()}).")
     lib = _lib.load()
     fn = getattr(lib, f"msda_fwd_{suf}")
 

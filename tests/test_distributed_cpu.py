@@ -79,7 +79,7 @@ def test_shard_bounds_cover_and_partition():
 # ---------------------------------------------------------------------------------------------
 # row partition (flattened (b, q) row space): what bench.py --gpus N runs
 # ---------------------------------------------------------------------------------------------
-def _row_worker(rank, world, port, batch, q_total, sharded_inputs, value_sync, grad_sync, ret):
+def _row_worker(rank, world, port, batch, q_total, sharded_inputs, value_sync, grad_sync, chunks, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -97,11 +97,13 @@ def _row_worker(rank, world, port, batch, q_total, sharded_inputs, value_sync, g
             l_in, a_in = dr["loc"].clone().requires_grad_(True), dr["attn"].clone().requires_grad_(True)
             out = row_sharded_multiscale_deformable_attention(v, d["shapes"], l_in, a_in, "zeros", False,
                                                               inputs_are_sharded=True, num_queries=q_total,
-                                                              grad_value_sync=value_sync, grad_sync=grad_sync)
+                                                              grad_value_sync=value_sync, grad_sync=grad_sync,
+                                                              overlap_chunks=chunks)
         else:
             l_in, a_in = d["loc"].clone().requires_grad_(True), d["attn"].clone().requires_grad_(True)
             out = row_sharded_multiscale_deformable_attention(v, d["shapes"], l_in, a_in, "zeros", False,
-                                                              grad_value_sync=value_sync, grad_sync=grad_sync)
+                                                              grad_value_sync=value_sync, grad_sync=grad_sync,
+                                                              overlap_chunks=chunks)
         g = d["grad_out"] if grad_sync == "slice" else d["grad_out"] / world
         out.backward(g)
         v2, l2, a2 = (t.detach().clone().requires_grad_(True) for t in (d["value"], d["loc"], d["attn"]))
@@ -130,18 +132,20 @@ def _row_worker(rank, world, port, batch, q_total, sharded_inputs, value_sync, g
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,batch,q_total,sharded_inputs,value_sync,grad_sync", [
-    (2, 2, 7, True, "owners", "slice"),            # ranks divide B: whole batch elements, no grad_value traffic
-    (2, 1, 9, False, "owners", "slice"),           # more ranks than batch elements: both share b = 0
-    (2, 3, 5, True, "all_reduce", "slice"),        # rank boundaries inside a batch element
-    (2, 3, 4, False, "none", "reduce_scatter"),
-    (3, 2, 5, True, "owners", "slice"),            # the middle rank belongs to two owner groups
-    (3, 1, 2, False, "all_reduce", "slice"),       # more ranks than rows: rank 2's shard is EMPTY, it must still join
-    (3, 1, 2, True, "owners", "slice"),            #   the grad_value collective (hang)
+@pytest.mark.parametrize("world,batch,q_total,sharded_inputs,value_sync,grad_sync,chunks", [
+    (2, 2, 7, True, "owners", "slice", 1),         # ranks divide B: whole batch elements, one in-place all-gather
+    (2, 2, 7, True, "owners", "slice", 3),         # ... the same in three pieces (exchange overlapped with compute)
+    (2, 1, 9, False, "owners", "slice", 2),        # more ranks than batch elements: both share b = 0; ragged shards
+    (2, 3, 5, True, "all_reduce", "slice", 1),     # rank boundaries inside a batch element
+    (2, 3, 4, False, "none", "reduce_scatter", 2),
+    (3, 2, 5, True, "owners", "slice", 2),         # the middle rank belongs to two owner groups
+    (3, 1, 2, False, "all_reduce", "slice", 1),    # more ranks than rows: rank 2's shard is EMPTY, it must still join
+    (3, 1, 2, True, "owners", "slice", 2),         #   the exchange and the grad_value collective (hang)
+    (2, 4, 6, True, "owners", "slice", 4),         # several whole batch elements per rank, cut into four pieces
 ])
-def test_row_shard_gloo(world, batch, q_total, sharded_inputs, value_sync, grad_sync):
+def test_row_shard_gloo(world, batch, q_total, sharded_inputs, value_sync, grad_sync, chunks):
     ret = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_row_worker, args=(world, _free_port(), batch, q_total, sharded_inputs, value_sync, grad_sync, ret),
+    mp.spawn(_row_worker, args=(world, _free_port(), batch, q_total, sharded_inputs, value_sync, grad_sync, chunks, ret),
              nprocs=world, join=True)
     assert dict(ret) == {r: True for r in range(world)}
 

@@ -577,26 +577,6 @@ def test_grad_value_without_workspace_uses_tile_kernel(oracle):
     np.testing.assert_allclose(ga.cpu().numpy(), r_ga, **BWD_TOL[torch.float32])
 
 
-def test_level_staging_option_gives_same_results():
-    """msda_set_option("stage_kb", n) copies small pyramid levels into LDS; results must not change."""
-    from msda_triton_amd import _lib, synth
-    ops = _ops()
-    d = synth.make_inputs_torch(synth.WORKLOADS["c1_readme"], DEV, seed=6, loc_lo=-0.1, loc_hi=1.1)
-    res = []
-    try:
-        for kb in (0, 9, 48):   # 9 KiB: the coarsest level only; 48 KiB: the two coarsest
-            _lib.set_option("stage_kb", kb)
-            v, l, a = (d[k].clone().requires_grad_(True) for k in ("value", "loc", "attn"))
-            o = ops.multiscale_deformable_attention(v, d["shapes"], l, a, "zeros", False)
-            o.backward(d["grad_out"])
-            res.append((o.detach(), l.grad, a.grad))
-    finally:
-        _lib.set_option("stage_kb", 0)
-    for other in res[1:]:
-        for x, y in zip(res[0], other):
-            torch.testing.assert_close(x, y, atol=1e-6, rtol=1e-6)
-
-
 def test_c_abi_rejects_bad_arguments_without_launching():
     from msda_triton_amd import _lib
     lib = _lib.load()
