@@ -8,7 +8,10 @@ Timing follows triton.testing.do_bench's recipe (which the reference uses): ~100
 repetitions, one HIP-event pair per repetition, an L2-sized buffer zeroed before each, median and the
 20 / 80 % quantiles.  Results go to outputs/benchmark_results/*.csv.
 
-    python scripts/benchmark_sweep.py [--queries 10 100 ...] [--no-native]
+The three plots the reference ships (assets/images/msda *.png; benchmark.py:177-180 saves them next to the CSV) are
+written as PNGs beside the CSV: forward ms, forward+backward ms and peak memory over the number of queries.
+
+    python scripts/benchmark_sweep.py [--queries 10 100 ...] [--no-native] [--no-plots]
 """
 import argparse
 import csv
@@ -66,6 +69,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--queries", type=int, nargs="+", default=[10, 100, 300, 900, 1000, 10000])
     ap.add_argument("--no-native", action="store_true")
+    ap.add_argument("--no-plots", action="store_true")
     ap.add_argument("--out", default="outputs/benchmark_results")
     args = ap.parse_args()
     providers = {"hip": multiscale_deformable_attention}
@@ -104,6 +108,39 @@ def main():
         w.writeheader()
         w.writerows(rows)
     print("wrote", path)
+    if not args.no_plots:
+        plot(rows, args.out)
+
+
+def plot(rows, out_dir):
+    """One PNG per measured quantity, a line per provider, log-log axes (reference: triton.testing.perf_report plots)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+
+    labels = {"hip": "HIP kernels (this package, MI355X)", "torch": "plain PyTorch on the same GPU"}
+    for key, title, fname in (("fwd_ms", "msda fwd runtime (ms)", "msda_fwd_runtime_ms.png"),
+                              ("fwdbwd_ms", "msda fwd+bwd runtime (ms)", "msda_fwd_bwd_runtime_ms.png"),
+                              ("peak_mem_MB", "msda memory consumption (MB)", "msda_memory_consumption_MB.png")):
+        fig, ax = plt.subplots(figsize=(6, 4))
+        for prov in sorted({r["provider"] for r in rows}):
+            pts = sorted((r["num_queries"], r[key]) for r in rows if r["provider"] == prov)
+            ax.plot([p[0] for p in pts], [p[1] for p in pts], marker="o", label=labels.get(prov, prov))
+            if key != "peak_mem_MB":
+                lo = [r[key + "_p20"] for r in sorted(rows, key=lambda r: r["num_queries"]) if r["provider"] == prov]
+                hi = [r[key + "_p80"] for r in sorted(rows, key=lambda r: r["num_queries"]) if r["provider"] == prov]
+                ax.fill_between([p[0] for p in pts], lo, hi, alpha=0.15)
+        ax.set_xscale("log")
+        ax.set_yscale("log")
+        ax.set_xlabel("num_queries")
+        ax.set_ylabel(title)
+        ax.set_title(title)
+        ax.grid(True, which="both", alpha=0.3)
+        ax.legend()
+        fig.tight_layout()
+        fig.savefig(os.path.join(out_dir, fname), dpi=110)
+        plt.close(fig)
+        print("wrote", os.path.join(out_dir, fname))
 
 
 if __name__ == "__main__":

@@ -175,3 +175,21 @@ def test_optional_cpp_binding_builds_and_matches_the_abi():
     assert os.path.exists(path)
     mod = _ext.load()
     assert mod is not None and int(mod.abi_version()) == _lib.ABI_VERSION
+
+
+def test_backward_workspace_sizes_stay_within_budget():
+    """msda_bwd_workspace_bytes (no GPU needed): the sorted pipeline's scratch is sized from the shapes alone —
+    round 1 asked for 319 MB at c2 @ 10k and 5.6 GB at c5; the pixel-indexed partial rows brought that down, and
+    problems the single-launch kernel takes need none at all."""
+    from msda_triton_amd import _lib, synth
+    lib = _lib.load()
+
+    def ws(name):
+        wl = synth.WORKLOADS[name]
+        return int(lib.msda_bwd_workspace_bytes(wl.B, wl.I, wl.H, wl.D, wl.Q, wl.L, wl.P, wl.elem_size))
+
+    assert ws("c2_q10k") <= 200 * 2**20          # entries 82 MB + partial rows 89 MB + cell tables
+    assert ws("c5_stress") <= 3 * 2**30           # entries 2.05 GB + partial rows 0.72 GB
+    assert ws("c1_readme") == 0 and ws("c4_gdino_dec") == 0 and ws("c2_q1k") == 0
+    wl = synth.WORKLOADS["c2_q10k"]
+    assert ws("c2_q10k") >= wl.B * wl.H * wl.Q * wl.L * wl.P * 16  # at least the sorted records

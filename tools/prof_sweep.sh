@@ -7,10 +7,14 @@ for spec in "$@"; do
   echo "== $spec"
   tail -1 gpurun_out/prof_sw.log | cut -c1-200
   python - <<'PY'
-import csv,glob
-for f in glob.glob('gpurun_out/prof_sw/*/*kernel_stats.csv'):
-    for r in csv.DictReader(open(f)):
-        if 'msda' in r['Name']:
-            print(f"{r['Name'].split('msda::')[1].split('(')[0]:55s} {float(r['AverageNs'])/1000:9.1f} us  x{r['Calls']}")
+import csv, glob, os, re
+f = max(glob.glob('gpurun_out/prof_sw/*/*kernel_stats.csv'), key=os.path.getmtime)
+for r in csv.DictReader(open(f)):
+    n = r['Name']
+    if 'msda' not in n:
+        continue
+    m = re.search(r'msda_\w+?_kernel', n)
+    tail = n.split(m.group(0), 1)[1].split('(')[0][:40] if m else ''
+    print(f"{(m.group(0) if m else n)[:40] + tail:70s} {float(r['AverageNs'])/1000:9.1f} us  x{r['Calls']}")
 PY
 done

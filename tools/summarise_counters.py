@@ -14,7 +14,9 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    return name.split("msda::")[1].split("(")[0]
+    import re
+    m = re.search(r"msda_\w+?_kernel", name)
+    return (m.group(0) + name.split(m.group(0), 1)[1].split("(")[0]) if m else name
 
 
 vals = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel -> counter -> [per dispatch]
@@ -26,7 +28,7 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"{tag}_pmc_*"))):
     per_dispatch = collections.defaultdict(float)
     meta = {}
     for r in csv.DictReader(open(f)):
-        if "msda::" not in r["Kernel_Name"]:
+        if "msda" not in r["Kernel_Name"]:
             continue
         key = (r["Dispatch_Id"], r["Counter_Name"])
         per_dispatch[key] += float(r["Counter_Value"])  # rows are per dimension instance (XCD/SE...): sum them

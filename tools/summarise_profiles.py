@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 outputs of tools/collect_profiles.sh into the committed summaries under profiles/.
 
-    python tools/summarise_profiles.py r01 c2_q10k
+    python tools/summarise_profiles.py r02 c2_q10k
 """
 import collections
 import csv
+import re
 import glob
 import json
 import os
@@ -18,25 +19,26 @@ os.makedirs(out_dir, exist_ok=True)
 
 
 def short(name):
-    return name.split("msda::")[1].split("<")[0].split("(")[0]
+    m = re.search(r"msda_\w+?_kernel", name)  # demangled ("void msda::x<...>") and mangled ("_ZN4msda..x...") names alike
+    return m.group(0) if m else name
 
 
 GROUPS = {  # launcher-level groups timed by bench.py's KernelTimer
     "msda_fwd": ["msda_fwd_kernel"],
     "msda_bwd_sample": ["msda_bwd_sample_kernel"],
-    "msda_bwd_value": ["msda_cell_pass_kernel", "msda_cell_total_kernel", "msda_cell_scan_kernel",
-                       "msda_value_gather_kernel", "msda_value_finish_kernel", "msda_bwd_value_kernel"],
+    "msda_bwd_value": ["msda_cell_pass_kernel", "msda_cell_scan_kernel", "msda_value_gather_kernel",
+                       "msda_value_finish_kernel", "msda_value_small_kernel", "msda_bwd_value_kernel"],
 }
 
 def newest(pattern):  # gpurun merges new outputs next to older ones: take the most recent
     return max(glob.glob(pattern), key=os.path.getmtime)
 
 
-stats = newest(os.path.join(root, "gpurun_out", f"{tag}_stats", "*", "*kernel_stats.csv"))
+stats = newest(os.path.join(root, "gpurun_out", f"{tag}_{workload}_stats", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(out_dir, f"{tag}_{workload}_kernel_stats.csv"))
 per_kernel = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(stats)):
-    if "msda::" in r["Name"]:
+    if "msda" in r["Name"]:
         k = short(r["Name"])
         per_kernel[k][0] += int(r["Calls"])
         per_kernel[k][1] += float(r["TotalDurationNs"])
@@ -44,10 +46,10 @@ for r in csv.DictReader(open(stats)):
 pmc = {}
 rows = []
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = newest(os.path.join(root, "gpurun_out", f"{tag}_{counter.split('_')[0].lower()}", "*", "*counter_collection.csv"))
+    f = newest(os.path.join(root, "gpurun_out", f"{tag}_{workload}_{counter.split('_')[0].lower()}", "*", "*counter_collection.csv"))
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter and "msda::" in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and "msda" in r["Kernel_Name"]:
             acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         pmc.setdefault(k, {})[counter] = (sum(v) / len(v), len(v))
