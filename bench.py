@@ -323,8 +323,8 @@ def main():
             "reference_readme_rtx2060_ms": README_RTX2060_MS,
             "speedup_vs_reference_readme": {"fwd": README_RTX2060_MS["fwd"] / ms_fwd,
                                             "fwd_bwd": README_RTX2060_MS["fwd_bwd"] / ms_step},
-            "roofline": {"kernel": dom + (" (sorted-gather pipeline: cell_pass x2, cell_total, cell_scan, "
-                                          "value_gather, value_finish; timed as one C-ABI call)"
+            "roofline": {"kernel": dom + (" (grad_value: cell_pass x2, cell_scan, value_gather, value_finish — or the "
+                                          "single-launch kernel on small problems; timed as one C-ABI call)"
                                           if dom == "msda_bwd_value" else ""), "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic,
                          "timing": "HIP events around every launch, same K steps repeated right after the timed region"},

@@ -147,9 +147,9 @@ MSDA_API const char *msda_last_error(void);
  *                   else by the LDS-tile kernel
  *                1: always the LDS-tile kernel   2: the sorted gather (if a workspace is supplied)
  *                3: the single-launch kernel whenever it fits
- *   "overlap"    -1 (default): grad_loc/grad_attn run on a forked side stream next to the single-launch grad_value
- *                   kernel only;  0: never;  1: always
- *   "cell_slices", "gather_wg", "small_ns", "wg_target", "debug": experiment knobs, see msda_triton_amd/csrc/msda_launch.hpp
+ *   "overlap"    -1 (default): grad_loc/grad_attn run on a forked side stream next to grad_value where that was
+ *                   measured to pay (single-launch grad_value kernel; rows of >= 128 bytes);  0: never;  1: always
+ *   "cell_slices", "small_ns", "wg_target", "debug": experiment knobs, see msda_triton_amd/csrc/msda_launch.hpp
  */
 MSDA_API int msda_set_option(const char *key, int value);
 MSDA_API int msda_get_option(const char *key);

@@ -17,7 +17,6 @@ static std::atomic<int> g_value_path{0};
 static std::atomic<int> g_wg_target{1 << 30};
 static std::atomic<int> g_cell_slices{0};
 static std::atomic<int> g_debug{0};
-static std::atomic<int> g_gather_wg{256};
 static std::atomic<int> g_small_ns{0};
 static std::atomic<int> g_overlap{-1};
 
@@ -74,7 +73,6 @@ int option_value_path() { return g_value_path.load(std::memory_order_relaxed); }
 int option_wg_target() { return g_wg_target.load(std::memory_order_relaxed); }
 int option_cell_slices() { return g_cell_slices.load(std::memory_order_relaxed); }
 int option_debug() { return g_debug.load(std::memory_order_relaxed); }
-int option_gather_wg() { return g_gather_wg.load(std::memory_order_relaxed); }
 int option_small_ns() { return g_small_ns.load(std::memory_order_relaxed); }
 int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
 
@@ -134,10 +132,6 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_small_ns.store(value, std::memory_order_relaxed);
         return 0;
     }
-    if (key && strcmp(key, "gather_wg") == 0 && (value == 64 || value == 128 || value == 256)) {
-        msda::g_gather_wg.store(value, std::memory_order_relaxed);
-        return 0;
-    }
     if (key && strcmp(key, "overlap") == 0) {
         msda::g_overlap.store(value < 0 ? -1 : value ? 1 : 0, std::memory_order_relaxed);
         return 0;
@@ -161,7 +155,6 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "wg_target") == 0) return msda::option_wg_target();
     if (key && strcmp(key, "cell_slices") == 0) return msda::option_cell_slices();
     if (key && strcmp(key, "debug") == 0) return msda::option_debug();
-    if (key && strcmp(key, "gather_wg") == 0) return msda::option_gather_wg();
     if (key && strcmp(key, "small_ns") == 0) return msda::option_small_ns();
     if (key && strcmp(key, "overlap") == 0) return msda::option_overlap();
     msda::set_error("unknown option '%s'", key ? key : "(null)");

@@ -16,7 +16,6 @@ namespace msda {
 int option_xcd_map();
 int option_value_path();  // 0: auto (single-launch LDS kernel when a plane-level fits, else sorted gather), 1: LDS tile kernel, 2: sorted, 3: single-launch
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
-int option_gather_wg();     // threads per workgroup of the grad_value gather kernel (64 / 128 / 256)
 int option_small_ns();      // workgroups per (plane, level) of the single-launch grad_value kernel (0: automatic)
 int option_debug();         // dev-only ablation mask
 int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream; 0: never; -1: automatic
@@ -253,11 +252,7 @@ template <typename T, int VEC, int G, int GB> inline int launch_value_gather_blo
 
 template <typename T, int VEC, int G> inline int launch_value_gather(Params &p, hipStream_t stream)
 {
-    const int want = option_gather_wg();
-    if constexpr (G <= 64)
-        if (want == 64) return launch_value_gather_block<T, VEC, G, 64>(p, stream);
-    if constexpr (G <= 128)
-        if (want == 128) return launch_value_gather_block<T, VEC, G, 128>(p, stream);
+    // (64- and 128-thread gather workgroups were measured too: 71-74 us against 73.6 at c2-10k — no effect, removed)
     return launch_value_gather_block<T, VEC, G, 256>(p, stream);
 }
 
@@ -576,10 +571,12 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     // forked side stream next to the grad_value pipeline (fork/join with events: still graph-capturable).
     hipStream_t sample_stream = stream;
     bool forked = false;
-    // ... by default only next to the single-launch grad_value kernel, which leaves most CUs idle most of its time
-    // (c4: fwd+bwd 0.130 -> 0.117 ms); next to the sorted pipeline the two halves want the same pipes (~1 %)
+    // ... by default next to the single-launch grad_value kernel, which leaves most CUs idle most of its time (c4:
+    // fwd+bwd 0.130 -> 0.117 ms), and next to the sorted pipeline when rows are at least 128 bytes: its place pass
+    // is bound by L2 write requests, the sample kernel by the vector-memory path (measured, fwd+bwd: c2 @ 10k
+    // -3.5 %, c2 @ 5k -2 %, c5 -0.3 %; with 64-byte rows, c3: +2 %, so not there)
     const int ov = option_overlap();
-    if (want_sample && want_value && (ov == 1 || (ov < 0 && small_path_chosen<T>(d)))) {
+    if (want_sample && want_value && (ov == 1 || (ov < 0 && (small_path_chosen<T>(d) || D * (int64_t)sizeof(T) >= 128)))) {
         hipStream_t side = side_stream_fork(stream);
         if (side != nullptr) {
             sample_stream = side;

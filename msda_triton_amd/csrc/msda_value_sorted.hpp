@@ -38,7 +38,7 @@
 namespace msda {
 
 constexpr int kWin = 64;              // records per gather window
-constexpr int kGatherMinBlock = 64;   // smallest gather workgroup (sizes the continuation rows)
+constexpr int kGatherMinBlock = 256;  // threads per gather workgroup (sizes the continuation rows)
 constexpr int kCellBlock = 1024;      // threads of K1 / K3
 constexpr int kScanCells = 256;       // cells per K2 workgroup (= its thread count)
 constexpr int kCellLdsInts = 36864;   // cells a K1 / K3 workgroup keeps in LDS at a time (144 KiB)

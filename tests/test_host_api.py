@@ -193,3 +193,25 @@ def test_backward_workspace_sizes_stay_within_budget():
     assert ws("c1_readme") == 0 and ws("c4_gdino_dec") == 0 and ws("c2_q1k") == 0
     wl = synth.WORKLOADS["c2_q10k"]
     assert ws("c2_q10k") >= wl.B * wl.H * wl.Q * wl.L * wl.P * 16  # at least the sorted records
+
+
+def test_module_feeds_the_projection_output_to_the_kernel_in_place(monkeypatch):
+    """SURVEY 8f-4 (frontend.py:264-267): the value projection's `[B, I, H*D]` output IS the kernel's `[B, I, H, D]`
+    layout — the module hands it over as a view, no reshape copy, no transpose."""
+    import torch
+    import msda_triton_amd.module as mod
+    seen = {}
+    real = mod.fused_module_core
+
+    def spy(value, *a, **k):
+        seen["value"] = value
+        return real(value, *a, **k)
+
+    monkeypatch.setattr(mod, "fused_module_core", spy)
+    m = mod.MultiscaleDeformableAttention(16, 32, 2, 4, 2, "zeros", False)
+    m.img_input_proj.register_forward_hook(lambda _m, _i, out: seen.__setitem__("proj", out))
+    shapes = torch.tensor([(3, 4), (2, 2)])
+    m(torch.randn(2, 16, 16), shapes, torch.randn(2, 5, 16), torch.rand(2, 5, 2))
+    assert seen["value"].shape == (2, 16, 4, 8) and seen["value"].is_contiguous()
+    assert seen["value"].data_ptr() == seen["proj"].data_ptr()          # same storage: a view
+    assert seen["value"].untyped_storage().data_ptr() == seen["proj"].untyped_storage().data_ptr()
