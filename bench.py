@@ -115,7 +115,7 @@ def torch_cpu_fallback(wl, budget_s=8.0, q_sample=1000):
             "sample": f"{len(times)} fwd+bwd passes on the first {q_sample} queries per batch element, fp32, median"}
 
 
-def strong_scaling_c5(dev, world, rank, use_dist, steps=5, warmup=2):
+def strong_scaling_c5(dev, world, rank, use_dist, chunks=None, steps=5, warmup=2):
     """BASELINE configs[4] (stress) with its B*Q = 400 000 rows split over the ranks: fwd+bwd ms per step.  Inputs are
     drawn on the device (torch RNG, same seed on every rank for the replicated value pyramid): only shapes matter."""
     import torch
@@ -141,7 +141,7 @@ def strong_scaling_c5(dev, world, rank, use_dist, steps=5, warmup=2):
         if use_dist:
             out = row_sharded_multiscale_deformable_attention(value, shapes, pts, att, wl.padding_mode, wl.align_corners,
                                                               inputs_are_sharded=True, num_queries=wl.Q,
-                                                              grad_value_sync="owners")
+                                                              grad_value_sync="owners", overlap_chunks=chunks)
         else:
             out = multiscale_deformable_attention(value, shapes, pts.view(wl.B, wl.Q, *pts.shape[1:]),
                                                   att.view(wl.B, wl.Q, *att.shape[1:]), wl.padding_mode, wl.align_corners)
@@ -232,11 +232,14 @@ def main():
     img, shapes = d["value"].requires_grad_(True), d["shapes"]
     pts, attn = d["loc"].requires_grad_(True), d["attn"].requires_grad_(True)
 
+    exchange = {"chunks": None}  # None: automatic (pieces overlapped with compute); 1: one in-place all-gather
+
     def op():
         if not use_dist:
             return multiscale_deformable_attention(img, shapes, pts, attn, pm, ac)
         return row_sharded_multiscale_deformable_attention(img, shapes, pts, attn, pm, ac, inputs_are_sharded=True,
-                                                           num_queries=gwl.Q, grad_value_sync=args.grad_value_sync)
+                                                           num_queries=gwl.Q, grad_value_sync=args.grad_value_sync,
+                                                           overlap_chunks=exchange["chunks"])
 
     def step():
         out = op()
@@ -266,6 +269,17 @@ def main():
             dt = float(t.item())
         return dt
 
+    if use_dist and world > 1:
+        # The piece-wise point-to-point exchange has only ever run over gloo in the build container (no multi-GPU box
+        # there): if the RCCL build on this node rejects it, every rank sees the same error and falls back to the
+        # single all-gather.  The choice is reported in config.exchange.
+        try:
+            step()
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            if rank == 0:
+                print(f"bench.py: piece-wise exchange failed ({e!r}); using one all-gather per step", file=sys.stderr)
+            exchange["chunks"] = 1
     for _ in range(args.warmup):
         step()
     # ---- the timed region: exactly K steps of the un-instrumented public API ----
@@ -313,7 +327,10 @@ def main():
                        "global_queries": gwl.Q,
                        "parallelism": f"row-shard x{world} (B*Q rows per rank, kernels write in place, in-place exchange "
                                       f"overlapped with compute{', grad_value ' + args.grad_value_sync if use_dist else ''})",
-                       "step": "public autograd API: fwd + backward(rand_like(out)) + grad reset"},
+                       "step": "public autograd API: fwd + backward(rand_like(out)) + grad reset",
+                       "exchange": ("none (one rank)" if world == 1 else
+                                    "one in-place all-gather" if exchange["chunks"] == 1 else
+                                    "grouped point-to-point pieces overlapped with compute")},
             "fwd_ms": ms_fwd,
             "fwd_bwd_ms": ms_step,
             "sum_kernel_us_fwd_bwd": round(sum_kernel_us, 2),
@@ -337,7 +354,7 @@ def main():
     if not args.no_strong_c5 and args.workload == "c2_q10k":
         del img, pts, attn, d
         torch.cuda.empty_cache()
-        strong = strong_scaling_c5(dev, world, rank, use_dist)  # every rank takes part; rank 0 reports
+        strong = strong_scaling_c5(dev, world, rank, use_dist, exchange["chunks"])  # every rank takes part; rank 0 reports
     if rank == 0:
         if strong is not None:
             result["strong_scaling_c5"] = strong

@@ -312,19 +312,28 @@ class _RowShardedMSDA(Function):
         else:
             mine = g_rows[r0:r1]
         gpu = img.device.type == "cuda"
-        g_img = torch.zeros_like(img) if need_img else None
+        # Gradient tensors of the shard; the kernels write every piece straight into its slice.  A contiguous row
+        # range meets a batch element in at most one piece, so grad_value needs no accumulation: the batch elements
+        # this rank does not touch are zeroed, the others are written whole.
+        g_img = torch.empty_like(img) if need_img else None
         g_pts = torch.empty_like(pts_rows) if need_pts else None
         g_att = torch.empty_like(att_rows) if need_att else None
+        touched = torch.zeros(B, dtype=torch.bool)
 
         def piece(b, nb, q0, q1, before):
             n = (q1 - q0) if nb == 1 else nb * Q
             pts = pts_rows[before:before + n].reshape(nb, n // nb, *pts_rows.shape[1:])
             att = att_rows[before:before + n].reshape(nb, n // nb, *att_rows.shape[1:])
             go = mine[before:before + n].reshape(nb, n // nb, H, D)
+            touched[b:b + nb] = True
             if gpu:
                 from .functional import msda_hip_bwd
-                gi, gp, ga = msda_hip_bwd(go, img[b:b + nb], img_shapes, pts, att, padding_mode, align_corners,
-                                          (need_img, need_pts, need_att))
+                need_s = need_pts or need_att
+                dst = (g_img[b:b + nb] if need_img else None,
+                       g_pts[before:before + n].view(nb, n // nb, *pts_rows.shape[1:]) if need_pts else None,
+                       g_att[before:before + n].view(nb, n // nb, *att_rows.shape[1:]) if need_att else None)
+                msda_hip_bwd(go, img[b:b + nb], img_shapes, pts, att, padding_mode, align_corners,
+                             (need_img, need_s, need_s), out=dst)
             else:
                 with torch.enable_grad():
                     v_ = img[b:b + nb].detach().requires_grad_(need_img)
@@ -333,17 +342,18 @@ class _RowShardedMSDA(Function):
                     o_ = multiscale_deformable_attention(v_, img_shapes, p_, a_, padding_mode, align_corners)
                 wrt = [t for t, nd in ((v_, need_img), (p_, need_pts), (a_, need_att)) if nd]
                 got = list(torch.autograd.grad(o_, wrt, go)) if wrt else []
-                gi = got.pop(0) if need_img else None
-                gp = got.pop(0) if need_pts else None
-                ga = got.pop(0) if need_att else None
-            if need_img:
-                g_img[b:b + nb] += gi
-            if need_pts:
-                g_pts[before:before + n] = gp.reshape(n, *pts_rows.shape[1:])
-            if need_att:
-                g_att[before:before + n] = ga.reshape(n, *att_rows.shape[1:])
+                if need_img:
+                    g_img[b:b + nb] = got.pop(0)
+                if need_pts:
+                    g_pts[before:before + n] = got.pop(0).reshape(n, *pts_rows.shape[1:])
+                if need_att:
+                    g_att[before:before + n] = got.pop(0).reshape(n, *att_rows.shape[1:])
 
         _run_pieces(piece, Q, r0, r1)
+        if need_img:
+            for b in range(B):
+                if not bool(touched[b]):
+                    g_img[b].zero_()
         if need_img and world > 1:
             if grad_value_sync == "all_reduce":
                 dist.all_reduce(g_img, op=dist.ReduceOp.SUM, group=group)

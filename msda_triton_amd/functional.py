@@ -186,13 +186,15 @@ def msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mo
 
 
 def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners,
-                 needs: Tuple[bool, bool, bool] = (True, True, True)
+                 needs: Tuple[bool, bool, bool] = (True, True, True),
+                 out: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]] = None,
                  ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
     """Returns ``(img_grad, sampling_points_grad, attention_weights_grad)``; entries not in ``needs`` are None.
 
     Gradients are allocated contiguous (the reference's ``zeros_like(...).contiguous()`` would write
     into a temporary for permuted inputs, kernels.py:570-578) and are fully written by the kernels,
-    so they are not pre-zeroed.
+    so they are not pre-zeroed.  ``out``: contiguous buffers of the gradients' shapes to write into instead (e.g.
+    slices of a shard's gradient tensors); an entry that is None is allocated here.
     """
     B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
     _check_devices(img, img_shapes, sampling_points, attention_weights, out_grad)
@@ -206,9 +208,19 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
     want_value = bool(needs[0])
     want_sample = bool(needs[1] or needs[2])
     kw = dict(dtype=img.dtype, device=img.device)
-    g_img = torch.empty((B, I, H, D), **kw) if want_value else None
-    g_pts = torch.empty((B, Q, H, L, P, 2), **kw) if want_sample else None
-    g_att = torch.empty((B, Q, H, L, P), **kw) if want_sample else None
+    def buf(i, shape, wanted):
+        if not wanted:
+            return None
+        t = out[i] if out is not None else None
+        if t is None:
+            return torch.empty(shape, **kw)
+        if tuple(t.shape) != tuple(shape) or t.dtype != img.dtype or t.device != img.device or not t.is_contiguous():
+            raise ValueError(f"`out[{i}]` should be a contiguous {tuple(shape)} {img.dtype} tensor on {img.device}")
+        return t
+
+    g_img = buf(0, (B, I, H, D), want_value)
+    g_pts = buf(1, (B, Q, H, L, P, 2), want_sample)
+    g_att = buf(2, (B, Q, H, L, P), want_sample)
     if want_value or want_sample:
         lib = _lib.load()
         fn = getattr(lib, f"msda_bwd_{suf}")
