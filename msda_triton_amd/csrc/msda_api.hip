@@ -18,6 +18,7 @@ static std::atomic<int> g_wg_target{1 << 30};
 static std::atomic<int> g_cell_slices{0};
 static std::atomic<int> g_debug{0};
 static std::atomic<int> g_small_ns{0};
+static std::atomic<int> g_q_round{0};
 static std::atomic<int> g_overlap{-1};
 
 // one side stream + two events per device, created on first use and kept for the life of the process
@@ -74,6 +75,7 @@ int option_wg_target() { return g_wg_target.load(std::memory_order_relaxed); }
 int option_cell_slices() { return g_cell_slices.load(std::memory_order_relaxed); }
 int option_debug() { return g_debug.load(std::memory_order_relaxed); }
 int option_small_ns() { return g_small_ns.load(std::memory_order_relaxed); }
+int option_q_round() { return g_q_round.load(std::memory_order_relaxed); }
 int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
 
 void set_error(const char *fmt, ...)
@@ -128,6 +130,10 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_debug.store(value, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "q_round") == 0 && value >= 0) {
+        msda::g_q_round.store(value, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "small_ns") == 0 && value >= 0 && value <= 216) {  // ns + 100 * extra
         msda::g_small_ns.store(value, std::memory_order_relaxed);
         return 0;
@@ -156,6 +162,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "cell_slices") == 0) return msda::option_cell_slices();
     if (key && strcmp(key, "debug") == 0) return msda::option_debug();
     if (key && strcmp(key, "small_ns") == 0) return msda::option_small_ns();
+    if (key && strcmp(key, "q_round") == 0) return msda::option_q_round();
     if (key && strcmp(key, "overlap") == 0) return msda::option_overlap();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;

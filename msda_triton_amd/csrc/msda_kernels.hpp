@@ -61,6 +61,11 @@ struct Params {
     int nc_cap, nblk_cap, win_cap, cont_cap;
     int nsplit;         // query slices per plane in the count / place passes
     int cell_cap;       // cells a count / place workgroup holds in LDS at a time
+    // query chunking of the sorted path (Q so large that a plane's grad_out rows leave L2): the passes of one round
+    // serve the queries [q_begin, q_end); ent_cap = records a plane's list can hold; finish_mode: 0 store grad_value,
+    // 1 first round (-> accumulator), 2 middle round (accumulator +=), 3 last round (accumulator + this -> grad_value)
+    int q_begin, q_end, ent_cap, finish_mode;
+    void *ws_accum;     // [pairs][I][D] acc-typed running sums between rounds (nullptr: a single round)
     int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
     int small_ns;       // ... workgroups per (plane, level)
     int small_extra;    // ... plus this many for the level with the most pixels

@@ -17,6 +17,7 @@ int option_xcd_map();
 int option_value_path();  // 0: auto (single-launch LDS kernel when a plane-level fits, else sorted gather), 1: LDS tile kernel, 2: sorted, 3: single-launch
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
 int option_small_ns();      // workgroups per (plane, level) of the single-launch grad_value kernel (0: automatic)
+int option_q_round();       // queries per round of the sorted grad_value path (0: automatic)
 int option_debug();         // dev-only ablation mask
 int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream; 0: never; -1: automatic
 // fork-join helpers around a lazily created per-device side stream (msda_api.hip)
@@ -289,11 +290,13 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
     p.ws_entries = ws + w.off_entries;
     p.ws_scratch = ws + w.off_scratch;
     p.ws_cont = ws + w.off_cont;
+    p.ws_accum = w.rounds > 1 ? ws + w.off_accum : nullptr;
     p.nc_cap = w.nc_cap;
     p.nblk_cap = w.nblk_cap;
     p.win_cap = w.win_cap;
     p.cont_cap = w.cont_cap;
     p.nsplit = w.nsplit;
+    p.ent_cap = (int)((int64_t)w.q_round * d.L * d.P);
     // cells a count / place workgroup keeps in LDS at a time: what the LDS holds next to the level table and the
     // per-block totals
     {
@@ -317,18 +320,25 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
     static std::atomic<uint64_t> big_lds_count{0}, big_lds_place{0};
     allow_big_lds(msda_cell_pass_kernel<T, false>, big_lds_count);
     allow_big_lds(msda_cell_pass_kernel<T, true>, big_lds_place);
-    hipLaunchKernelGGL((msda_cell_pass_kernel<T, false>), gcell, dim3(kCellBlock), cell_lds, stream, p);
     const int64_t scan_blocks = (int64_t)p.nblk_cap * npairs;
     if (scan_blocks >= ((int64_t)1 << 31)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)scan_blocks), dim3(kScanCells), 0, stream, p);
-    hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
-    int rc = (int)hipGetLastError();
-    if (rc) return rc;
     constexpr int VECF = 16 / sizeof(T);
-    return vec_ok ? dispatch_value_gather_group<T, VECF>(p, stream) : dispatch_value_gather_group<T, 1>(p, stream);
+    for (int r = 0; r < w.rounds; ++r) {  // one round unless Q is so large that a plane's grad_out rows leave L2
+        p.q_begin = r * w.q_round;
+        p.q_end = p.q_begin + w.q_round < p.Q ? p.q_begin + w.q_round : p.Q;
+        p.finish_mode = w.rounds == 1 ? 0 : r == 0 ? 1 : r == w.rounds - 1 ? 3 : 2;
+        hipLaunchKernelGGL((msda_cell_pass_kernel<T, false>), gcell, dim3(kCellBlock), cell_lds, stream, p);
+        hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)scan_blocks), dim3(kScanCells), 0, stream, p);
+        hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
+        int rc = (int)hipGetLastError();
+        if (rc) return rc;
+        rc = vec_ok ? dispatch_value_gather_group<T, VECF>(p, stream) : dispatch_value_gather_group<T, 1>(p, stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_corners)

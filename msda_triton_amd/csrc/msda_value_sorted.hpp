@@ -150,8 +150,8 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
     int pair, slice;
     if (!decode_block(p.grid3d, p.B * p.H, p.nsplit, p.xcd_map, pair, slice)) return;
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
-    const int qper = (p.Q + p.nsplit - 1) / p.nsplit;
-    const int qa = min(p.Q, slice * qper), qb = min(p.Q, qa + qper);
+    const int qper = (p.q_end - p.q_begin + p.nsplit - 1) / p.nsplit;  // this round's queries, cut into the slices
+    const int qa = min(p.q_end, p.q_begin + slice * qper), qb = min(p.q_end, qa + qper);
 
     LevelTab *tab = reinterpret_cast<LevelTab *>(msda_smem);
     int *s_cell = reinterpret_cast<int *>(msda_smem + sizeof(LevelTab));
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
     int *part = p.ws_part + ((size_t)pair * p.nsplit + slice) * p.nc_cap;  // [cell] of this slice
     int *blocktot = p.ws_blocktot + ((size_t)pair * p.nsplit + slice) * p.nblk_cap;
     const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
-    Entry<A> *entries = static_cast<Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
+    Entry<A> *entries = static_cast<Entry<A> *>(p.ws_entries) + (size_t)pair * p.ent_cap;
     // per-plane bases (64-bit, uniform) + 32-bit per-sample offsets (the host checks Q*H*L*P*2 < 2^31)
     const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
     const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(GB) void msda_value_gather_kernel(const Params p)
     __shared__ int s_cont[NU];   // the unit's first segment continues the previous window's cell
     __shared__ int s_pure[NU];   // ... and is the unit's only segment
 
-    const Entry<A> *entries = static_cast<const Entry<A> *>(p.ws_entries) + (size_t)pair * p.Q * p.LP;
+    const Entry<A> *entries = static_cast<const Entry<A> *>(p.ws_entries) + (size_t)pair * p.ent_cap;
     const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
     const uint32_t q_stride = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);  // bytes; Q*H*D*sizeof < 2^31 is checked on the host
     // grad_out rows of this plane through a buffer descriptor: scalar base + 32-bit byte offset per lane
@@ -765,6 +765,22 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
                 add(t1, t2, 2);
                 add(t0, t1, 3);
             }
+            // several rounds over the queries: running sums in the accumulate type between them
+            if (p.finish_mode != 0) {
+                A *run = static_cast<A *>(p.ws_accum) + ((size_t)pair * p.I + pix) * p.D + c0;
+                if (p.finish_mode != 1) {
+                    const Pack<A, VEC> prev = *reinterpret_cast<const Pack<A, VEC> *>(run);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] += prev.v[v];
+                }
+                if (p.finish_mode != 3) {
+                    Pack<A, VEC> keep;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) keep.v[v] = acc[v];
+                    *reinterpret_cast<Pack<A, VEC> *>(run) = keep;
+                    continue;
+                }
+            }
             Pack<T, VEC> o;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
@@ -779,8 +795,11 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
 // ------------------------------------------------------------------------------------------
 struct SortedWsLayout {
     int nc_cap, nblk_cap, win_cap, cont_cap, nsplit;
-    size_t off_part, off_blocktot, off_off, off_total, off_meta, off_entries, off_scratch, off_cont, total;
+    int q_round, rounds;  // queries per round and rounds over the queries (1: everything at once)
+    size_t off_part, off_blocktot, off_off, off_total, off_meta, off_entries, off_scratch, off_cont, off_accum, total;
 };
+
+int option_q_round();  // queries per round of the sorted path (0: automatic), msda_api.hip
 
 int option_cell_slices();  // 0: automatic (msda_api.hip)
 
@@ -802,7 +821,27 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
 {
     SortedWsLayout w;
     const size_t pairs = (size_t)(B * H);
-    const size_t samples = (size_t)(Q * L * P);  // per plane
+    // Rounds over the queries bound the record buffer: at most ~1 GiB of sorted records at a time (c5: 2 rounds of
+    // 50 000 queries, workspace 2.9 -> 2.0 GB; everything up to c2 / c3 size: one round).  Measured at c5 (grad_value,
+    // us): 1 round 5529, 2 rounds 5425, 3 rounds 5518, 4 rounds 5601, 7 rounds 6720 — the place pass gains from the
+    // smaller scatter range what the repeated finish pass and fixed costs take; keeping a plane's grad_out rows in L2
+    // this way (rounds of 16k queries) did not speed the gather up.
+    int64_t q_round = Q;
+    {
+        const int64_t per_query = (int64_t)pairs * L * P * (acc_bytes == 8 ? 32 : 16);
+        const int64_t budget = (int64_t)1 << 30;
+        if (per_query > 0 && Q * per_query > budget + budget / 4) {
+            const int64_t rounds = (Q * per_query + budget - 1) / budget;
+            q_round = (Q + rounds - 1) / rounds;
+        }
+    }
+    if (option_q_round() > 0) q_round = option_q_round();
+    if (q_round < 1) q_round = 1;
+    if (q_round > Q) q_round = Q > 0 ? Q : 1;
+    w.q_round = (int)q_round;
+    w.rounds = (int)((Q + q_round - 1) / q_round);
+    if (w.rounds < 1) w.rounds = 1;
+    const size_t samples = (size_t)(q_round * L * P);  // per plane and round
     w.nc_cap = (int)(2 * I + 2 * L);             // (w+1)(h+1) <= 2wh + 2 per level
     w.nblk_cap = (w.nc_cap + kScanCells - 1) / kScanCells;
     w.win_cap = (int)((samples + kWin - 1) / kWin);
@@ -815,7 +854,7 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     if (ns > by_work) ns = by_work;
     if (option_cell_slices() > 0) ns = option_cell_slices();
     if (ns > 64) ns = 64;
-    if (ns > Q) ns = Q;
+    if (ns > q_round) ns = q_round;
     if (ns < 1) ns = 1;
     w.nsplit = (int)ns;
     const size_t entry_bytes = acc_bytes == 8 ? 32 : 16;
@@ -828,6 +867,7 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     w.off_entries = o;  o = align_up(o + pairs * samples * entry_bytes, 256);
     w.off_scratch = o;  o = align_up(o + pairs * (size_t)I * 4 * (size_t)D * acc_bytes, 256);
     w.off_cont = o;     o = align_up(o + pairs * (size_t)w.cont_cap * 4 * (size_t)D * acc_bytes, 256);
+    w.off_accum = o;    if (w.rounds > 1) o = align_up(o + pairs * (size_t)I * (size_t)D * acc_bytes, 256);
     w.total = o;
     return w;
 }

@@ -769,6 +769,32 @@ def test_random_shapes_against_oracle(oracle, seed, value_path):
         _lib.set_option("value_path", 0)
 
 
+@pytest.mark.parametrize("td", [torch.float32, torch.float64, torch.bfloat16], ids=["f32", "f64", "bf16"])
+def test_sorted_grad_value_in_query_rounds(oracle, td):
+    """Very large Q is served in rounds over the queries (a plane's grad_out rows stay in L2; running sums in the
+    accumulate type between rounds).  Forced here with tiny rounds: first / middle / last round paths, ragged last
+    round, every storage class of the running sums."""
+    from msda_triton_amd import _lib
+    rng = np.random.default_rng(4242)
+    npdt = np.float64 if td == torch.float64 else np.float32
+    c = rand_case(rng, 2, 53, 3, 32, [(9, 7), (4, 5), (2, 2)], 3, lo=-0.2, hi=1.2, dtype=npdt)
+    if td == torch.bfloat16:
+        for k in ("value", "loc", "attn", "grad_out"):
+            c[k] = torch.from_numpy(c[k]).to(td).float().numpy()
+    try:
+        _lib.set_option("value_path", 2)
+        for q_round in (7, 20, 52):
+            _lib.set_option("q_round", q_round)
+            for pm, ac in (("zeros", False), ("border", True)):
+                _, gv, _, _ = run_hip(c["value"], c["shapes"], c["loc"], c["attn"], c["grad_out"], pm, ac, dtype=td)
+                r_gv, _, _ = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], pm, ac)
+                tol = dict(atol=5e-2, rtol=2e-2) if td == torch.bfloat16 else BWD_TOL[td]
+                np.testing.assert_allclose(gv, r_gv, err_msg=f"q_round {q_round} {pm} {ac}", **tol)
+    finally:
+        _lib.set_option("q_round", 0)
+        _lib.set_option("value_path", 0)
+
+
 def test_make_graphed_callables_replays_forward_and_backward():
     """torch.cuda.make_graphed_callables captures the operator's forward and backward (no host sync, no allocation
     outside PyTorch's capture pool) — the way to take the launch overhead off small problems."""
