@@ -1,6 +1,6 @@
-// msda_value_tile.hpp — grad_value fallback that needs no workspace: owner-computes tiles in LDS.
-// Used when the caller passes no (or too small a) workspace to msda_bwd_*, or with
-// msda_set_option("value_path", 1).  The default path is the sorted gather in msda_value_sorted.hpp.
+// msda_value_tile.hpp — grad_value last resort: owner-computes tiles in LDS, no workspace.
+// Used when neither the single-launch kernel (msda_value_small.hpp: small problems) nor the sorted gather
+// (msda_value_sorted.hpp: needs the caller's workspace, L <= 16) applies, or with msda_set_option("value_path", 1).
 #pragma once
 
 #include "msda_kernels.hpp"

@@ -15,6 +15,13 @@ MODES = [("zeros", False), ("zeros", True), ("border", False), ("border", True)]
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # MSDA_TEST_OPTS="value_path=2,q_round=11": run the suite under library option overrides (variant matrix)
+    opts = os.environ.get("MSDA_TEST_OPTS", "")
+    if opts:
+        from msda_triton_amd import _lib
+        for kv in opts.split(","):
+            k, v = kv.split("=")
+            _lib.set_option(k.strip(), int(v))
 
 
 def mode_key(pm, ac):
