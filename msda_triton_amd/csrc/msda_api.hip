@@ -134,7 +134,7 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_q_round.store(value, std::memory_order_relaxed);
         return 0;
     }
-    if (key && strcmp(key, "small_ns") == 0 && value >= 0 && value <= 216) {  // ns + 100 * extra
+    if (key && strcmp(key, "small_ns") == 0 && value >= 0 && value <= 16) {
         msda::g_small_ns.store(value, std::memory_order_relaxed);
         return 0;
     }

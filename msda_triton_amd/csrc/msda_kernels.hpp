@@ -68,7 +68,6 @@ struct Params {
     void *ws_accum;     // [pairs][I][D] acc-typed running sums between rounds (nullptr: a single round)
     int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
     int small_ns;       // ... workgroups per (plane, level)
-    int small_extra;    // ... plus this many for the level with the most pixels
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char msda_smem[];

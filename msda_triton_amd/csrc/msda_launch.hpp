@@ -456,7 +456,7 @@ template <typename T> inline size_t small_need_bytes(const Dims &d, bool vec)
 template <typename T, int VEC, int G> inline int launch_value_small(Params &p, size_t lds, hipStream_t stream)
 {
     dim3 grid;
-    if (!plane_grid(p, p.B * p.H, (int64_t)p.L * p.small_ns + p.small_extra, grid)) {
+    if (!plane_grid(p, p.B * p.H, (int64_t)p.L * p.small_ns, grid)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
@@ -486,8 +486,8 @@ template <typename T> inline int run_value_small(Params &p, const Dims &d, hipSt
     // workgroups per (plane, level): fill the 256 CUs when there are few planes; two when the planes just fill them
     // (a level's workgroups then finish at different times and the busiest level no longer sets the pace)
     const int64_t wgs = d.B * d.H * d.L;
-    p.small_ns = option_small_ns() > 0 ? option_small_ns() % 100 : wgs <= 64 ? 4 : wgs <= 128 ? 2 : 1;
-    p.small_extra = option_small_ns() / 100;  // (experiment knob: an extra workgroup for the largest level — measured: no gain)
+    // (also measured: one more workgroup for the level with the most pixels only — c4 55 -> 62 us, dropped)
+    p.small_ns = option_small_ns() > 0 ? option_small_ns() : wgs <= 64 ? 4 : wgs <= 128 ? 2 : 1;
     const size_t lds = small_need_bytes<T>(d, vec_ok);
     return vec_ok ? dispatch_value_small_group<T, VECF>(p, lds, stream) : dispatch_value_small_group<T, 1>(p, lds, stream);
 }

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     // p.small_ns workgroups per (plane, level): each builds the level's sorted records for itself (cheap) and takes
     // every small_ns-th round of the gather, so few planes still fill the chip and busy levels get more CUs' time
     int pair, slot;
-    if (!decode_block(p.grid3d, p.B * p.H, p.L * p.small_ns + p.small_extra, p.xcd_map, pair, slot)) return;
+    if (!decode_block(p.grid3d, p.B * p.H, p.L * p.small_ns, p.xcd_map, pair, slot)) return;
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int tid = threadIdx.x;
 
@@ -59,26 +59,8 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     int *s_off = reinterpret_cast<int *>(sm + o);  // [ncl + 1]
     load_level_table(tab, p.shapes, p.L);
     __syncthreads();
-    // slot -> (level, share of the level's gather rounds).  With small_extra the level with the most pixels gets one
-    // more workgroup than the others, and its workgroups come first in dispatch order: on a pyramid the finest level
-    // holds 3/4 of the pixels and would otherwise set the pace of the whole launch.
-    int lvl, share, nshare;
-    {
-        int big = 0;
-        for (int l = 1; l < p.L; ++l)
-            if (tab->h[l] * tab->w[l] > tab->h[big] * tab->w[big]) big = l;
-        const int nbig = p.small_ns + p.small_extra;
-        if (slot < nbig) {
-            lvl = big;
-            share = slot;
-            nshare = nbig;
-        } else {
-            const int k = (slot - nbig) / p.small_ns;  // k-th of the other levels
-            lvl = k < big ? k : k + 1;
-            share = (slot - nbig) - k * p.small_ns;
-            nshare = p.small_ns;
-        }
-    }
+    // slot -> (level, share of the level's gather rounds)
+    const int lvl = slot / p.small_ns, share = slot - lvl * p.small_ns, nshare = p.small_ns;
     const int lw = tab->w[lvl], lh = tab->h[lvl], cw = lw + 1;
     const int ncl_true = (lh + 1) * cw;
     const int ncl = min(ncl_true, p.small_cells);  // (shapes that disagree with I: never index past the LDS table)

@@ -544,7 +544,8 @@ __global__ __launch_bounds__(GB) void msda_value_gather_kernel(const Params p)
                 cw.w[0] = ax0 - cw.w[2];
                 const uint32_t cellw = ok ? e_cur.cellflag() : 0xFFFFFFFEu;
                 // the previous record's cell: the lane to the left, or (lane 0) the record before this batch
-                uint32_t left = __shfl_up(cellw, 1, kWave);
+                // (wave_shr:1 — a DPP move, no LDS round trip; lane 0 of the wave keeps its own value and is a group's lane 0)
+                uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp((int)cellw, (int)cellw, 0x138, 0xF, 0xF, false);
                 if (j == 0) left = last_cellw;
                 // a segment starts at the window's first record and wherever the cell changes; it takes over the ended
                 // cell's right-hand corners when it is the right-hand x-neighbour in the same row: next pixel index,
