@@ -105,6 +105,7 @@ def test_hip_matches_reference_digest_fullsize(path):
             got, want = dg["samples"], z[f"{nm}_{k}_samples"].astype(np.float64)
             if nm == "grad_loc":  # not comparable where the pixel coordinate sits on a grid kink (conftest.kink_mask)
                 kinks = kink_mask(f32["loc"], f32["shapes"], ac).reshape(-1)[::dg["step"]][:got.size]
+                assert kinks.mean() < 0.02, f"{kinks.mean():.3%} of the sampled grad_loc entries sit on a grid kink"
                 got, want = np.where(kinks, 0, got), np.where(kinks, 0, want)
             tol = FWD_TOL[torch.float32] if nm == "out" else BWD_TOL[torch.float32]
             np.testing.assert_allclose(got, want, err_msg=f"{nm} {k}", **tol)
@@ -150,7 +151,7 @@ def test_hip_vs_oracle_f64(oracle, name, pm, ac):
     check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float64], BWD_TOL[torch.float64], mask_kinks=False)
 
 
-@pytest.mark.parametrize("td,atol,rtol", [(torch.float16, 2e-2, 2e-2), (torch.bfloat16, 1e-1, 5e-2)],
+@pytest.mark.parametrize("td,atol,rtol", [(torch.float16, 2e-2, 2e-2), (torch.bfloat16, 4e-2, 2e-2)],
                          ids=["fp16", "bf16"])
 @pytest.mark.parametrize("name", ["d32_vec_g8", "d64_vec_g16", "d5_scalar", "d8_vec_g4"])
 @pytest.mark.parametrize("pm,ac", [("zeros", False), ("border", True)], ids=["zeros_0", "border_1"])
