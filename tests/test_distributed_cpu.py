@@ -142,6 +142,8 @@ def _row_worker(rank, world, port, batch, q_total, sharded_inputs, value_sync, g
     (3, 1, 2, False, "all_reduce", "slice", 1),    # more ranks than rows: rank 2's shard is EMPTY, it must still join
     (3, 1, 2, True, "owners", "slice", 2),         #   the exchange and the grad_value collective (hang)
     (2, 4, 6, True, "owners", "slice", 4),         # several whole batch elements per rank, cut into four pieces
+    (4, 4, 6, True, "owners", "slice", 2),         # bench.py --gpus 4: one batch element per rank
+    (8, 4, 6, True, "owners", "slice", 2),         # bench.py --gpus 8: two ranks share a batch element (pair-wise sums)
 ])
 def test_row_shard_gloo(world, batch, q_total, sharded_inputs, value_sync, grad_sync, chunks):
     ret = mp.get_context("spawn").Manager().dict()
