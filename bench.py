@@ -173,6 +173,37 @@ def strong_scaling_c5(dev, world, rank, use_dist, chunks=None, steps=5, warmup=2
             "alg_fwd_bwd_GBs": round((wl.alg_fwd_bytes + wl.alg_bwd_bytes) / (ms * 1e-3) / 1e9, 1)}
 
 
+class _StallGuard:
+    """N>1 only.  A step that exchanges over RCCL is armed with a deadline; if it stalls, rank 0 prints the result
+    measured so far (with config.stalled naming the step) and every rank leaves the process, so a wedged exchange
+    costs the optional legs and not the bench line."""
+
+    def __init__(self, rank):
+        self.rank, self.result, self.timer, self.what = rank, None, None, ""
+        self.have_result = False  # set on every rank once rank 0 holds a complete bench line
+
+    def arm(self, seconds, what):
+        import threading
+        self.disarm()
+        self.what = what
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _fire(self):
+        if self.rank == 0 and self.result is not None:
+            self.result["config"]["stalled"] = self.what
+            print(json.dumps(self.result), flush=True)
+        sys.stderr.write(f"bench.py: rank {self.rank}: {self.what} stalled; leaving\n")
+        sys.stderr.flush()
+        os._exit(0 if self.have_result else 3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,31 +300,36 @@ def main():
             dt = float(t.item())
         return dt
 
-    if use_dist and world > 1:
-        # The piece-wise point-to-point exchange has only ever run over gloo in the build container (no multi-GPU box
-        # there): if the RCCL build on this node rejects it, every rank sees the same error and falls back to the
-        # single all-gather.  The choice is reported in config.exchange.
-        try:
+    guard = _StallGuard(rank)
+
+    def measure():
+        for _ in range(args.warmup):
             step()
-            torch.cuda.synchronize()
-        except RuntimeError as e:
-            if rank == 0:
-                print(f"bench.py: piece-wise exchange failed ({e!r}); using one all-gather per step", file=sys.stderr)
-            exchange["chunks"] = 1
-    for _ in range(args.warmup):
-        step()
-    # ---- the timed region: exactly K steps of the un-instrumented public API ----
-    dt = timed(step, args.steps)
-    ms_step = dt * 1e3 / args.steps
+        # ---- the timed region: exactly K steps of the un-instrumented public API ----
+        ms = timed(step, args.steps) * 1e3 / args.steps
+        for _ in range(max(3, args.warmup // 2)):
+            fwd_only()
+        return ms, timed(fwd_only, args.steps) * 1e3 / args.steps
+
+    exchange_ms = None
+    if use_dist and world > 1:
+        # Two ways to exchange the output rows: one in-place all-gather after the kernels, or grouped point-to-point
+        # pieces overlapped with the compute.  The second has only ever run over gloo in the build container (no
+        # multi-GPU box there), so the all-gather is measured first and the piece-wise exchange runs under a stall
+        # guard: if it raises or stalls, the all-gather figure stands.  Both times are reported; `value` is the
+        # faster one (config.exchange says which).
+        exchange["chunks"] = 1
+        guard.arm(600, "weak-scaling leg (all-gather exchange)")
+        ms_step, ms_fwd = measure()
+        guard.disarm()
+        exchange_ms = {"all_gather": {"fwd_bwd_ms": ms_step, "fwd_ms": ms_fwd}}
+    else:
+        ms_step, ms_fwd = measure()
     # ---- the same K steps again with per-launch HIP events (KernelTimer splits the backward into one C-ABI call
     #      per kernel group, so its two halves run back to back here instead of concurrently) ----
     with KernelTimer() as kt:
         timed(step, args.steps)
     kern = kt.summary()
-
-    for _ in range(max(3, args.warmup // 2)):
-        fwd_only()
-    ms_fwd = timed(fwd_only, args.steps) * 1e3 / args.steps
 
     if rank == 0:
         alg = kernel_alg_bytes(wl)
@@ -350,15 +386,43 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wl)
+    else:
+        result = None
+    guard.result, guard.have_result = result, True
+    if exchange_ms is not None:
+        guard.arm(240, "piece-wise exchange (weak-scaling leg)")
+        exchange["chunks"] = None
+        try:
+            ms2, fwd2 = measure()
+            exchange_ms["pieces"] = {"fwd_bwd_ms": ms2, "fwd_ms": fwd2}
+        except RuntimeError as e:  # every rank sees the same RCCL error; a rank left waiting trips the guard
+            ms2 = None
+            exchange_ms["pieces"] = {"error": repr(e)[:200]}
+        guard.disarm()
+        if ms2 is not None and ms2 < ms_step:  # the all-reduced max over ranks: the same decision everywhere
+            ms_step, ms_fwd = ms2, fwd2
+        else:
+            exchange["chunks"] = 1
+        if rank == 0:
+            result.update(value=wl.B * wl.Q * world / (ms_step * 1e-3), ms_per_step=ms_step, fwd_bwd_ms=ms_step,
+                          fwd_ms=ms_fwd, exchange_ms=exchange_ms,
+                          alg_fwd_bwd_GBs=round((wl.alg_fwd_bytes + wl.alg_bwd_bytes) / (ms_step * 1e-3) / 1e9, 1),
+                          speedup_vs_reference_readme={"fwd": README_RTX2060_MS["fwd"] / ms_fwd,
+                                                       "fwd_bwd": README_RTX2060_MS["fwd_bwd"] / ms_step})
+            result["config"]["exchange"] = ("one in-place all-gather" if exchange["chunks"] == 1 else
+                                            "grouped point-to-point pieces overlapped with compute")
     strong = None
     if not args.no_strong_c5 and args.workload == "c2_q10k":
         del img, pts, attn, d
         torch.cuda.empty_cache()
+        if world > 1:
+            guard.arm(300, "strong-scaling c5 leg")
         strong = strong_scaling_c5(dev, world, rank, use_dist, exchange["chunks"])  # every rank takes part; rank 0 reports
+        guard.disarm()
     if rank == 0:
         if strong is not None:
             result["strong_scaling_c5"] = strong
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
