@@ -73,7 +73,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 5
+#define MSDA_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define MSDA_API __attribute__((visibility("default")))
@@ -116,6 +116,13 @@ MSDA_DECLARE(f32)
 MSDA_DECLARE(f16)
 MSDA_DECLARE(bf16)
 MSDA_DECLARE(f64)
+/* Mixed storage: `value` and `grad_value` are bf16 / fp16, every other tensor (sampling points, attention weights,
+ * projection, reference points, out, grad_out and the other gradients) is fp32.  For modules that keep the value
+ * pyramid in 16 bits (the value projection written straight in the kernel's layout and dtype) without
+ * giving up fp32 sampling coordinates; arithmetic is fp32 as everywhere.  Same signatures; workspace sizes are those
+ * of elem_size 4. */
+MSDA_DECLARE(f32_vbf16)
+MSDA_DECLARE(f32_vf16)
 #undef MSDA_DECLARE
 
 /* Bytes of device workspace msda_bwd_<dtype> wants for these sizes; elem_size = sizeof(dtype). */

@@ -15,9 +15,10 @@ LIB_NAME = "libmsda_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PADDING_MODES = {"border": 0, "zeros": 1}
-DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64")
+# one storage type for every tensor, then the mixed ones: value / grad_value in 16 bits, everything else fp32
+DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64", "f32_vbf16", "f32_vf16")
 
 # every symbol include/msda_hip.h declares
 EXPORTED_SYMBOLS = tuple(

@@ -32,7 +32,7 @@ def msda_forward(img: torch.Tensor, img_shapes: torch.Tensor, sampling_points: t
 @msda_forward.register_fake
 def _(img, img_shapes, sampling_points, attention_weights, zeros, align_corners):
     B, _, H, D = img.shape
-    return img.new_empty((B, sampling_points.shape[1], H, D))
+    return sampling_points.new_empty((B, sampling_points.shape[1], H, D))  # (mixed storage: the result is fp32)
 
 
 @torch.library.custom_op("msda_amd::backward", mutates_args=(), device_types="cuda")
@@ -102,7 +102,7 @@ def msda_fused_forward(img: torch.Tensor, img_shapes: torch.Tensor, proj: torch.
 @msda_fused_forward.register_fake
 def _(img, img_shapes, proj, reference_points, zeros, align_corners):
     B, _, H, D = img.shape
-    return img.new_empty((B, proj.shape[1], H, D))
+    return proj.new_empty((B, proj.shape[1], H, D))
 
 
 @torch.library.custom_op("msda_amd::fused_backward", mutates_args=(), device_types="cuda")
@@ -148,7 +148,7 @@ def _fused_lp_limit(head_dim: int, elem_size: int) -> int:
 
 def fused_lp_ok(img: torch.Tensor, proj: torch.Tensor) -> bool:
     """Do the fused kernels take this L*P for this head dimension / dtype?  (Static shapes: decided at trace time.)"""
-    return int(proj.shape[3]) * int(proj.shape[4]) <= _fused_lp_limit(int(img.shape[-1]), img.element_size())
+    return int(proj.shape[3]) * int(proj.shape[4]) <= _fused_lp_limit(int(img.shape[-1]), proj.element_size())
 
 
 def compiled_fused_module_core(img, img_shapes, proj, reference_points, padding_mode, align_corners) -> torch.Tensor:

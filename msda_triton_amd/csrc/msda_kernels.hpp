@@ -109,11 +109,14 @@ constexpr size_t kGatherLdsFixed = (sizeof(LevelTab) + 15) / 16 * 16;
 // forward.  After the one-time staging barrier every wave runs on its own: it parks the records of
 // ITS 64/G units, gathers, stores, and moves to its next query chunk without any block barrier.
 // ==========================================================================================
-template <typename T, int VEC, int G, bool FUSED>
+// TV: storage type of the value rows (T unless the caller keeps value in 16 bits next to fp32 coordinates / weights /
+// output: the "mixed" entry points, msda_mixed.hip)
+template <typename T, int VEC, int G, bool FUSED, typename TV = T>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void msda_fwd_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
+    static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
     constexpr int NU = kBlock / G;     // units per workgroup and query chunk
     constexpr int UPW = kWave / G;     // units per wave
 
@@ -126,9 +129,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     const GatherLds<A> lds(NU, scp);
     LevelTab *tab = lds.tab;
 
-    const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);
-    const T *plane = static_cast<const T *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
-    const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(T));
+    const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TV);
+    const TV *plane = static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
+    const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV));
     const rsrc_t rs = make_rsrc(plane, plane_bytes);
 
     load_level_table(tab, p.shapes, p.L);
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         for (int cc = 0; cc < nchan_chunks; ++cc) {
             const int c0 = (cc * G + j) * VEC;
             const bool lane_ok = unit_ok && (c0 < p.D);
-            const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
+            const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(TV);
             A acc[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) acc[i] = (A)0;
@@ -253,10 +256,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                         const uint4 o = uo[s];
                         const Rec4<A> w = uw[s];
                         A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-                        load_row<T, VEC>(rs, o.x + lane_off, v0);
-                        load_row<T, VEC>(rs, o.y + lane_off, v1);
-                        load_row<T, VEC>(rs, o.z + lane_off, v2);
-                        load_row<T, VEC>(rs, o.w + lane_off, v3);
+                        load_row<TV, VEC>(rs, o.x + lane_off, v0);
+                        load_row<TV, VEC>(rs, o.y + lane_off, v1);
+                        load_row<TV, VEC>(rs, o.z + lane_off, v2);
+                        load_row<TV, VEC>(rs, o.w + lane_off, v3);
 #pragma unroll
                         for (int i = 0; i < VEC; ++i) {  // four chained FMAs per channel: no product tree to re-pack
                             acc[i] = fma_t(w.v[0], v0[i], acc[i]);
@@ -282,11 +285,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 // backward, part 1: grad_loc and grad_attn.  Same decomposition as the forward; every sample's
 // three results are reduced over the unit's G lanes with DPP moves and written exactly once.
 // ==========================================================================================
-template <typename T, int VEC, int G, bool FUSED>
+template <typename T, int VEC, int G, bool FUSED, typename TV = T>
 __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
+    static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
     constexpr int NU = kBlock / G;
     constexpr int UPW = kWave / G;
 
@@ -300,9 +304,9 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
     const GatherLds<A> lds(NU, scp, FUSED);
     LevelTab *tab = lds.tab;
 
-    const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);
-    const T *plane = static_cast<const T *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
-    const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(T));
+    const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TV);
+    const TV *plane = static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
+    const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV));
     const rsrc_t rs = make_rsrc(plane, plane_bytes);
 
     load_level_table(tab, p.shapes, p.L);
@@ -450,12 +454,12 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                     constexpr int UB = 4;
                     const int c0 = j * VEC;
                     const bool lane_in = c0 < p.D;
-                    const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
+                    const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(TV);
                     Pack<T, VEC> gp;
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) gp.v[i] = TR::from_acc((A)0);
                     if (lane_in) gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
-                    if constexpr (TR::kDot2 && (VEC % 2) == 0) {
+                    if constexpr (TR::kDot2 && (VEC % 2) == 0 && sizeof(TV) == sizeof(T)) {
                         // 16-bit rows: the four dot products with grad_out straight from the packed pairs
                         // (v_dot2c_f32_f16 / _bf16: two multiply-adds per instruction, no widening)
                         using P2 = typename TR::pair_t;
@@ -512,10 +516,10 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
                             const uint32_t lo = lane_in ? lane_off : 0u;
-                            load_row<T, VEC>(rs, o[u].x + lo, v[u][0]);
-                            load_row<T, VEC>(rs, o[u].y + lo, v[u][1]);
-                            load_row<T, VEC>(rs, o[u].z + lo, v[u][2]);
-                            load_row<T, VEC>(rs, o[u].w + lo, v[u][3]);
+                            load_row<TV, VEC>(rs, o[u].x + lo, v[u][0]);
+                            load_row<TV, VEC>(rs, o[u].y + lo, v[u][1]);
+                            load_row<TV, VEC>(rs, o[u].z + lo, v[u][2]);
+                            load_row<TV, VEC>(rs, o[u].w + lo, v[u][3]);
                         }
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
@@ -539,13 +543,13 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                         for (int cc = 0; cc < nchan_chunks; ++cc) {
                             const int c0 = (cc * G + j) * VEC;
                             if (c0 < p.D) {
-                                const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(T);
+                                const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(TV);
                                 const Pack<T, VEC> gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
                                 A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-                                load_row<T, VEC>(rs, o.x + lane_off, v0);
-                                load_row<T, VEC>(rs, o.y + lane_off, v1);
-                                load_row<T, VEC>(rs, o.z + lane_off, v2);
-                                load_row<T, VEC>(rs, o.w + lane_off, v3);
+                                load_row<TV, VEC>(rs, o.x + lane_off, v0);
+                                load_row<TV, VEC>(rs, o.y + lane_off, v1);
+                                load_row<TV, VEC>(rs, o.z + lane_off, v2);
+                                load_row<TV, VEC>(rs, o.w + lane_off, v3);
 #pragma unroll
                                 for (int i = 0; i < VEC; ++i) {
                                     const A gg = TR::to_acc(gp.v[i]);

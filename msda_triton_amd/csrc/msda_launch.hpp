@@ -138,7 +138,7 @@ inline void plan_gather(int NU, int LP, size_t acc_bytes, int &sc, size_t &lds, 
 }
 
 // MODE 0: forward, 1: grad_loc/grad_attn, 2: fused forward, 3: fused backward (sample half)
-template <typename T, int VEC, int G, int MODE> inline int launch_gather(Params &p, hipStream_t stream)
+template <typename T, int VEC, int G, int MODE, typename TV = T> inline int launch_gather(Params &p, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
     constexpr int NU = kBlock / G;
@@ -161,45 +161,45 @@ template <typename T, int VEC, int G, int MODE> inline int launch_gather(Params 
     }
     static std::atomic<uint64_t> big_lds_done{0};  // one per template instantiation
     if constexpr (MODE == 3) {
-        auto kernel = msda_bwd_sample_kernel<T, VEC, G, true>;
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, true, TV>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else if constexpr (MODE == 1) {
-        auto kernel = msda_bwd_sample_kernel<T, VEC, G, false>;
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, false, TV>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else if constexpr (MODE == 2) {
-        auto kernel = msda_fwd_kernel<T, VEC, G, true>;
+        auto kernel = msda_fwd_kernel<T, VEC, G, true, TV>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else {
-        auto kernel = msda_fwd_kernel<T, VEC, G, false>;
+        auto kernel = msda_fwd_kernel<T, VEC, G, false, TV>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     }
     return (int)hipGetLastError();
 }
 
-template <typename T, int VEC, int MODE> inline int dispatch_group(Params &p, hipStream_t stream)
+template <typename T, int VEC, int MODE, typename TV = T> inline int dispatch_group(Params &p, hipStream_t stream)
 {
     const int lanes = (p.D + VEC - 1) / VEC;
     switch (pick_group(lanes)) {
-    case 4: return launch_gather<T, VEC, 4, MODE>(p, stream);
-    case 8: return launch_gather<T, VEC, 8, MODE>(p, stream);
-    case 16: return launch_gather<T, VEC, 16, MODE>(p, stream);
-    case 32: return launch_gather<T, VEC, 32, MODE>(p, stream);
-    default: return launch_gather<T, VEC, 64, MODE>(p, stream);
+    case 4: return launch_gather<T, VEC, 4, MODE, TV>(p, stream);
+    case 8: return launch_gather<T, VEC, 8, MODE, TV>(p, stream);
+    case 16: return launch_gather<T, VEC, 16, MODE, TV>(p, stream);
+    case 32: return launch_gather<T, VEC, 32, MODE, TV>(p, stream);
+    default: return launch_gather<T, VEC, 64, MODE, TV>(p, stream);
     }
 }
 
-template <typename T, int MODE> inline int dispatch_gather(Params &p, bool vec_ok, hipStream_t stream)
+template <typename T, int MODE, typename TV = T> inline int dispatch_gather(Params &p, bool vec_ok, hipStream_t stream)
 {
-    constexpr int VECF = 16 / sizeof(T);
-    if (vec_ok && (p.D % VECF) == 0) return dispatch_group<T, VECF, MODE>(p, stream);
-    return dispatch_group<T, 1, MODE>(p, stream);
+    constexpr int VECF = 16 / sizeof(T);  // channels per lane (mixed storage: the 16-bit value rows load as 8-byte pieces)
+    if (vec_ok && (p.D % VECF) == 0) return dispatch_group<T, VECF, MODE, TV>(p, stream);
+    return dispatch_group<T, 1, MODE, TV>(p, stream);
 }
 
-template <typename T, int CH> inline int launch_value(Params &p, hipStream_t stream)
+template <typename T, int CH, typename TV = T> inline int launch_value(Params &p, hipStream_t stream)
 {
     const size_t px_bytes = (size_t)CH * sizeof(TileAcc);
     const size_t room = kValueLdsBudget - sizeof(LevelTab);
@@ -215,25 +215,25 @@ template <typename T, int CH> inline int launch_value(Params &p, hipStream_t str
         return MSDA_ERR_TOO_LARGE;
     }
     static std::atomic<uint64_t> big_lds_done{0};
-    allow_big_lds(msda_bwd_value_kernel<T, CH>, big_lds_done);
-    hipLaunchKernelGGL((msda_bwd_value_kernel<T, CH>), grid, dim3(kValueBlock), lds, stream, p);
+    allow_big_lds(msda_bwd_value_kernel<T, CH, TV>, big_lds_done);
+    hipLaunchKernelGGL((msda_bwd_value_kernel<T, CH, TV>), grid, dim3(kValueBlock), lds, stream, p);
     return (int)hipGetLastError();
 }
 
-template <typename T> inline int dispatch_value(Params &p, hipStream_t stream)
+template <typename T, typename TV = T> inline int dispatch_value(Params &p, hipStream_t stream)
 {
     const size_t room = kValueLdsBudget - sizeof(LevelTab);
     auto fits = [&](int ch) {
-        return (p.D % ch) == 0 && aligned_to(p.grad_out, ch * sizeof(T)) && aligned_to(p.grad_value, ch * sizeof(T)) &&
+        return (p.D % ch) == 0 && aligned_to(p.grad_out, ch * sizeof(T)) && aligned_to(p.grad_value, ch * sizeof(TV)) &&
                (size_t)p.I * ch * sizeof(TileAcc) <= room;
     };
-    if (fits(4)) return launch_value<T, 4>(p, stream);
-    if (fits(2)) return launch_value<T, 2>(p, stream);
-    return launch_value<T, 1>(p, stream);
+    if (fits(4)) return launch_value<T, 4, TV>(p, stream);
+    if (fits(2)) return launch_value<T, 2, TV>(p, stream);
+    return launch_value<T, 1, TV>(p, stream);
 }
 
 // ---- sorted (gather-formulated) grad_value: K1..K5 of msda_value_sorted.hpp ----
-template <typename T, int VEC, int G, int GB> inline int launch_value_gather_block(Params &p, hipStream_t stream)
+template <typename T, int VEC, int G, int GB, typename TV = T> inline int launch_value_gather_block(Params &p, hipStream_t stream)
 {
     constexpr int NU = kBlock / G, NUG = GB / G;
     const int npairs = p.B * p.H;
@@ -247,36 +247,36 @@ template <typename T, int VEC, int G, int GB> inline int launch_value_gather_blo
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    hipLaunchKernelGGL((msda_value_finish_kernel<T, VEC, G, GB>), g5, dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((msda_value_finish_kernel<T, VEC, G, GB, TV>), g5, dim3(kBlock), 0, stream, p);
     return (int)hipGetLastError();
 }
 
-template <typename T, int VEC, int G> inline int launch_value_gather(Params &p, hipStream_t stream)
+template <typename T, int VEC, int G, typename TV = T> inline int launch_value_gather(Params &p, hipStream_t stream)
 {
     // (64- and 128-thread gather workgroups were measured too: 71-74 us against 73.6 at c2-10k — no effect, removed)
-    return launch_value_gather_block<T, VEC, G, 256>(p, stream);
+    return launch_value_gather_block<T, VEC, G, 256, TV>(p, stream);
 }
 
-template <typename T, int VEC> inline int dispatch_value_gather_group(Params &p, hipStream_t stream)
+template <typename T, int VEC, typename TV = T> inline int dispatch_value_gather_group(Params &p, hipStream_t stream)
 {
     const int lanes = (p.D + VEC - 1) / VEC;
     switch (pick_group(lanes)) {
-    case 4: return launch_value_gather<T, VEC, 4>(p, stream);
-    case 8: return launch_value_gather<T, VEC, 8>(p, stream);
-    case 16: return launch_value_gather<T, VEC, 16>(p, stream);
-    case 32: return launch_value_gather<T, VEC, 32>(p, stream);
-    default: return launch_value_gather<T, VEC, 64>(p, stream);
+    case 4: return launch_value_gather<T, VEC, 4, TV>(p, stream);
+    case 8: return launch_value_gather<T, VEC, 8, TV>(p, stream);
+    case 16: return launch_value_gather<T, VEC, 16, TV>(p, stream);
+    case 32: return launch_value_gather<T, VEC, 32, TV>(p, stream);
+    default: return launch_value_gather<T, VEC, 64, TV>(p, stream);
     }
 }
 
 // can the gather kernels use 16-byte row pieces for this call?
 template <typename T> inline bool value_vec_ok(const Params &p)
 {
-    constexpr int VECF = 16 / sizeof(T);
+    constexpr int VECF = 16 / sizeof(T);  // (mixed storage: grad_value rows are stored as 8-byte pieces, also fine at 16)
     return aligned_to(p.grad_out, 16) && aligned_to(p.grad_value, 16) && (p.D % VECF) == 0;
 }
 
-template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void *workspace, hipStream_t stream)
+template <typename T, typename TV = T> inline int run_value_sorted(Params &p, const Dims &d, void *workspace, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
     const bool vec_ok = value_vec_ok<T>(p);
@@ -335,7 +335,7 @@ template <typename T> inline int run_value_sorted(Params &p, const Dims &d, void
         hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
         int rc = (int)hipGetLastError();
         if (rc) return rc;
-        rc = vec_ok ? dispatch_value_gather_group<T, VECF>(p, stream) : dispatch_value_gather_group<T, 1>(p, stream);
+        rc = vec_ok ? dispatch_value_gather_group<T, VECF, TV>(p, stream) : dispatch_value_gather_group<T, 1, TV>(p, stream);
         if (rc) return rc;
     }
     return 0;
@@ -363,7 +363,7 @@ inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_co
     p.div_h = make_fast_div((uint32_t)d.H);
 }
 
-template <typename T>
+template <typename T, typename TV = T>
 int run_fwd(const void *value, const int64_t *shapes, const void *loc, const void *attn, void *out, int64_t B,
             int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int padding_mode, int align_corners,
             void *stream_)
@@ -381,7 +381,7 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
     const void *ptrs2[] = {value, shapes, loc, attn};
     rc = check_common<T>(d, padding_mode, ptrs2, 4);
     if (rc) return rc;
-    if (!aligned_to(value, sizeof(T)) || !aligned_to(out, sizeof(T)) || !aligned_to(loc, 2 * sizeof(T)) ||
+    if (!aligned_to(value, sizeof(TV)) || !aligned_to(out, sizeof(T)) || !aligned_to(loc, 2 * sizeof(T)) ||
         !aligned_to(attn, sizeof(T)) || !aligned_to(shapes, 8)) {
         set_error("misaligned buffer");
         return MSDA_ERR_MISALIGNED;
@@ -394,14 +394,14 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
     p.out = out;
     fill_params(p, d, padding_mode, align_corners);
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
-    rc = dispatch_gather<T, 0>(p, vec_ok, stream);
+    rc = dispatch_gather<T, 0, TV>(p, vec_ok, stream);
     if (rc > 0) set_error("forward launch failed: %s", hipGetErrorString((hipError_t)rc));  // negative: message already set
     return rc;
 }
 
 // Module forward with the prologue fused in: `proj` is the raw query projection
 // [B, Q, H, L, P, 3] = (x offset, y offset, attention logit), `ref` the reference points [B, Q, ref_dim].
-template <typename T>
+template <typename T, typename TV = T>
 int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, const void *ref, void *out, int64_t B,
                   int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,
                   int align_corners, void *stream_)
@@ -425,7 +425,7 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
         set_error("projection too large for 32-bit sample offsets");
         return MSDA_ERR_TOO_LARGE;
     }
-    if (!aligned_to(value, sizeof(T)) || !aligned_to(out, sizeof(T)) || !aligned_to(proj, sizeof(T)) ||
+    if (!aligned_to(value, sizeof(TV)) || !aligned_to(out, sizeof(T)) || !aligned_to(proj, sizeof(T)) ||
         !aligned_to(ref, sizeof(T)) || !aligned_to(shapes, 8)) {
         set_error("misaligned buffer");
         return MSDA_ERR_MISALIGNED;
@@ -440,7 +440,7 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
     p.ref = ref;
     p.ref_dim = ref_dim;
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
-    rc = dispatch_gather<T, 2>(p, vec_ok, stream);
+    rc = dispatch_gather<T, 2, TV>(p, vec_ok, stream);
     if (rc > 0) set_error("fused forward launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }
@@ -453,7 +453,7 @@ template <typename T> inline size_t small_need_bytes(const Dims &d, bool vec)
     return small_lds_bytes((size_t)(2 * d.I + 2 * d.L), (size_t)(d.Q * d.P), sizeof(A), vecw);
 }
 
-template <typename T, int VEC, int G> inline int launch_value_small(Params &p, size_t lds, hipStream_t stream)
+template <typename T, int VEC, int G, typename TV = T> inline int launch_value_small(Params &p, size_t lds, hipStream_t stream)
 {
     dim3 grid;
     if (!plane_grid(p, p.B * p.H, (int64_t)p.L * p.small_ns, grid)) {
@@ -461,24 +461,24 @@ template <typename T, int VEC, int G> inline int launch_value_small(Params &p, s
         return MSDA_ERR_TOO_LARGE;
     }
     static std::atomic<uint64_t> big_lds_done{0};
-    allow_big_lds(msda_value_small_kernel<T, VEC, G>, big_lds_done);
-    hipLaunchKernelGGL((msda_value_small_kernel<T, VEC, G>), grid, dim3(kSmallBlock), lds, stream, p);
+    allow_big_lds(msda_value_small_kernel<T, VEC, G, TV>, big_lds_done);
+    hipLaunchKernelGGL((msda_value_small_kernel<T, VEC, G, TV>), grid, dim3(kSmallBlock), lds, stream, p);
     return (int)hipGetLastError();
 }
 
-template <typename T, int VEC> inline int dispatch_value_small_group(Params &p, size_t lds, hipStream_t stream)
+template <typename T, int VEC, typename TV = T> inline int dispatch_value_small_group(Params &p, size_t lds, hipStream_t stream)
 {
     const int lanes = (p.D + VEC - 1) / VEC;
     switch (pick_group(lanes)) {
-    case 4: return launch_value_small<T, VEC, 4>(p, lds, stream);
-    case 8: return launch_value_small<T, VEC, 8>(p, lds, stream);
-    case 16: return launch_value_small<T, VEC, 16>(p, lds, stream);
-    case 32: return launch_value_small<T, VEC, 32>(p, lds, stream);
-    default: return launch_value_small<T, VEC, 64>(p, lds, stream);
+    case 4: return launch_value_small<T, VEC, 4, TV>(p, lds, stream);
+    case 8: return launch_value_small<T, VEC, 8, TV>(p, lds, stream);
+    case 16: return launch_value_small<T, VEC, 16, TV>(p, lds, stream);
+    case 32: return launch_value_small<T, VEC, 32, TV>(p, lds, stream);
+    default: return launch_value_small<T, VEC, 64, TV>(p, lds, stream);
     }
 }
 
-template <typename T> inline int run_value_small(Params &p, const Dims &d, hipStream_t stream)
+template <typename T, typename TV = T> inline int run_value_small(Params &p, const Dims &d, hipStream_t stream)
 {
     constexpr int VECF = 16 / sizeof(T);
     const bool vec_ok = value_vec_ok<T>(p);
@@ -489,7 +489,7 @@ template <typename T> inline int run_value_small(Params &p, const Dims &d, hipSt
     // (also measured: one more workgroup for the level with the most pixels only — c4 55 -> 62 us, dropped)
     p.small_ns = option_small_ns() > 0 ? option_small_ns() : wgs <= 64 ? 4 : wgs <= 128 ? 2 : 1;
     const size_t lds = small_need_bytes<T>(d, vec_ok);
-    return vec_ok ? dispatch_value_small_group<T, VECF>(p, lds, stream) : dispatch_value_small_group<T, 1>(p, lds, stream);
+    return vec_ok ? dispatch_value_small_group<T, VECF, TV>(p, lds, stream) : dispatch_value_small_group<T, 1, TV>(p, lds, stream);
 }
 
 // the sorted pipeline's record format: 4 level bits, 24-bit biased pixel index, 32-bit slot offsets
@@ -516,7 +516,7 @@ template <typename T> inline bool small_path_chosen(const Dims &d)
 
 // grad_value: the sorted-gather pipeline when the caller's workspace allows it, else (or for small problems) the
 // LDS-tile kernel.
-template <typename T>
+template <typename T, typename TV = T>
 inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspace_bytes, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
@@ -526,14 +526,14 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
                             sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p)).total;
     const bool small_path = small_path_chosen<T>(d) || (option_value_path() == 0 && !sorted && small_fits<T>(d));
     // (no workspace: the single-launch kernel is still better than the LDS-tile kernel whenever it fits)
-    const int rc = small_path ? run_value_small<T>(p, d, stream)
-                   : sorted   ? run_value_sorted<T>(p, d, workspace, stream)
-                              : dispatch_value<T>(p, stream);
+    const int rc = small_path ? run_value_small<T, TV>(p, d, stream)
+                   : sorted   ? run_value_sorted<T, TV>(p, d, workspace, stream)
+                              : dispatch_value<T, TV>(p, stream);
     if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }
 
-template <typename T>
+template <typename T, typename TV = T>
 int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, const void *loc, const void *attn,
             void *grad_value, void *grad_loc, void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,
             int64_t L, int64_t P, int padding_mode, int align_corners, void *workspace, int64_t workspace_bytes,
@@ -543,7 +543,7 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = check_common<T>(d, padding_mode, nullptr, 0);
     if (rc) return rc;
-    const size_t gv_bytes = (size_t)(B * I * H * D) * sizeof(T);
+    const size_t gv_bytes = (size_t)(B * I * H * D) * sizeof(TV);
     const size_t ns = (size_t)(B * Q * H * L * P);
     if (B * Q * H * D == 0 || L * P == 0 || I == 0) {  // no sample touches anything: all gradients are zero
         hipError_t e = hipSuccess;
@@ -561,7 +561,7 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     const void *ptrs[] = {grad_out, value, shapes, loc, attn};
     rc = check_common<T>(d, padding_mode, ptrs, 5);
     if (rc) return rc;
-    if (!aligned_to(value, sizeof(T)) || !aligned_to(grad_out, sizeof(T)) || !aligned_to(grad_value, sizeof(T)) ||
+    if (!aligned_to(value, sizeof(TV)) || !aligned_to(grad_out, sizeof(T)) || !aligned_to(grad_value, sizeof(TV)) ||
         !aligned_to(loc, 2 * sizeof(T)) || !aligned_to(grad_loc, 2 * sizeof(T)) || !aligned_to(attn, sizeof(T)) ||
         !aligned_to(grad_attn, sizeof(T)) || !aligned_to(shapes, 8)) {
         set_error("misaligned buffer");
@@ -600,14 +600,14 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     }
     if (want_sample) {
         const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
-        rc = dispatch_gather<T, 1>(p, vec_ok, sample_stream);
+        rc = dispatch_gather<T, 1, TV>(p, vec_ok, sample_stream);
         if (rc) {
             if (rc > 0) set_error("backward (grad_loc/grad_attn) launch failed: %s", hipGetErrorString((hipError_t)rc));
             if (forked) (void)side_stream_join(stream);
             return rc;
         }
     }
-    if (want_value) rc = run_value<T>(p, d, workspace, workspace_bytes, stream);
+    if (want_value) rc = run_value<T, TV>(p, d, workspace, workspace_bytes, stream);
     if (forked) {
         const int jrc = side_stream_join(stream);
         if (rc == 0 && jrc != 0) {
@@ -627,7 +627,7 @@ inline size_t fused_mat_bytes(int64_t B, int64_t H, int64_t Q, int64_t L, int64_
     return align_up((size_t)(B * Q * H * L * P) * 3 * elem, 256);
 }
 
-template <typename T>
+template <typename T, typename TV = T>
 int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes, const void *proj, const void *ref,
                   void *grad_value, void *grad_proj, void *grad_ref_part, int64_t B, int64_t I, int64_t H, int64_t D,
                   int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode, int align_corners, void *workspace,
@@ -645,7 +645,7 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
         set_error("the fused backward always produces grad_proj and the grad_reference_points partials");
         return MSDA_ERR_BAD_ARG;
     }
-    const size_t gv_bytes = (size_t)(B * I * H * D) * sizeof(T);
+    const size_t gv_bytes = (size_t)(B * I * H * D) * sizeof(TV);
     const size_t ns = (size_t)(B * Q * H * L * P);
     if (B * Q * H * D == 0 || L * P == 0 || I == 0) {  // no sample touches anything: all gradients are zero
         hipError_t e = hipSuccess;
@@ -661,7 +661,7 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
         set_error("projection too large for 32-bit sample offsets");
         return MSDA_ERR_TOO_LARGE;
     }
-    if (!aligned_to(value, sizeof(T)) || !aligned_to(grad_out, sizeof(T)) || !aligned_to(grad_value, sizeof(T)) ||
+    if (!aligned_to(value, sizeof(TV)) || !aligned_to(grad_out, sizeof(T)) || !aligned_to(grad_value, sizeof(TV)) ||
         !aligned_to(proj, sizeof(T)) || !aligned_to(grad_proj, sizeof(T)) || !aligned_to(ref, sizeof(T)) ||
         !aligned_to(grad_ref_part, sizeof(T)) || !aligned_to(shapes, 8)) {
         set_error("misaligned buffer");
@@ -691,7 +691,7 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
         p.mat_attn = ws + ns * 2 * sizeof(T);
     }
     const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
-    rc = dispatch_gather<T, 3>(p, vec_ok, stream);
+    rc = dispatch_gather<T, 3, TV>(p, vec_ok, stream);
     if (rc) {
         if (rc > 0) set_error("fused backward launch failed: %s", hipGetErrorString((hipError_t)rc));
         return rc;
@@ -701,19 +701,19 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
         p.attn = p.mat_attn;
         p.ref = nullptr;
         p.ref_dim = 0;
-        rc = run_value<T>(p, d, ws + mat, workspace_bytes - (int64_t)mat, stream);
+        rc = run_value<T, TV>(p, d, ws + mat, workspace_bytes - (int64_t)mat, stream);
     }
     return rc;
 }
 
 }  // namespace msda
 
-#define MSDA_DEFINE_ENTRY_POINTS(SUF, T)                                                                         \
+#define MSDA_DEFINE_ENTRY_POINTS2(SUF, T, TV)                                                                        \
     extern "C" int msda_fwd_##SUF(const void *value, const int64_t *shapes, const void *loc, const void *attn,  \
                                   void *out, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,  \
                                   int64_t P, int padding_mode, int align_corners, void *stream)                 \
     {                                                                                                            \
-        return msda::run_fwd<T>(value, shapes, loc, attn, out, B, I, H, D, Q, L, P, padding_mode,               \
+        return msda::run_fwd<T, TV>(value, shapes, loc, attn, out, B, I, H, D, Q, L, P, padding_mode,               \
                                 align_corners, stream);                                                          \
     }                                                                                                            \
     extern "C" int msda_fwd_fused_##SUF(const void *value, const int64_t *shapes, const void *proj,             \
@@ -721,7 +721,7 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
                                         int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,          \
                                         int align_corners, void *stream)                                         \
     {                                                                                                            \
-        return msda::run_fwd_fused<T>(value, shapes, proj, ref, out, B, I, H, D, Q, L, P, ref_dim, padding_mode, \
+        return msda::run_fwd_fused<T, TV>(value, shapes, proj, ref, out, B, I, H, D, Q, L, P, ref_dim, padding_mode, \
                                       align_corners, stream);                                                    \
     }                                                                                                            \
     extern "C" int msda_bwd_##SUF(const void *grad_out, const void *value, const int64_t *shapes,               \
@@ -730,7 +730,7 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
                                   int64_t L, int64_t P, int padding_mode, int align_corners, void *workspace,   \
                                   int64_t workspace_bytes, void *stream)                                         \
     {                                                                                                            \
-        return msda::run_bwd<T>(grad_out, value, shapes, loc, attn, grad_value, grad_loc, grad_attn, B, I, H,   \
+        return msda::run_bwd<T, TV>(grad_out, value, shapes, loc, attn, grad_value, grad_loc, grad_attn, B, I, H,   \
                                 D, Q, L, P, padding_mode, align_corners, workspace, workspace_bytes, stream);    \
     }                                                                                                            \
     extern "C" int msda_bwd_fused_##SUF(const void *grad_out, const void *value, const int64_t *shapes,         \
@@ -740,7 +740,10 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
                                         int align_corners, void *workspace, int64_t workspace_bytes,             \
                                         void *stream)                                                            \
     {                                                                                                            \
-        return msda::run_bwd_fused<T>(grad_out, value, shapes, proj, ref, grad_value, grad_proj,                \
+        return msda::run_bwd_fused<T, TV>(grad_out, value, shapes, proj, ref, grad_value, grad_proj,                \
                                       grad_ref_partial, B, I, H, D, Q, L, P, ref_dim, padding_mode,              \
                                       align_corners, workspace, workspace_bytes, stream);                        \
     }
+
+// one storage type for every tensor
+#define MSDA_DEFINE_ENTRY_POINTS(SUF, T) MSDA_DEFINE_ENTRY_POINTS2(SUF, T, T)

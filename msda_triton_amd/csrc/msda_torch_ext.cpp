@@ -34,8 +34,17 @@ struct Fns {
     BwdFusedFn bwd_fused;
 };
 
-Fns fns_for(at::ScalarType t)
+// `t`: dtype of the value pyramid (and its gradient); `c`: dtype of every other tensor — the same, or float next to a
+// 16-bit pyramid (the mixed-storage entry points)
+Fns fns_for(at::ScalarType t, at::ScalarType c)
 {
+    if (t != c) {
+        TORCH_CHECK_VALUE(c == at::kFloat && (t == at::kBFloat16 || t == at::kHalf),
+                          "unsupported dtype combination: value ", t, " with ", c);
+        if (t == at::kBFloat16)
+            return {msda_fwd_f32_vbf16, msda_bwd_f32_vbf16, msda_fwd_fused_f32_vbf16, msda_bwd_fused_f32_vbf16};
+        return {msda_fwd_f32_vf16, msda_bwd_f32_vf16, msda_fwd_fused_f32_vf16, msda_bwd_fused_f32_vf16};
+    }
     switch (t) {
     case at::kFloat: return {msda_fwd_f32, msda_bwd_f32, msda_fwd_fused_f32, msda_bwd_fused_f32};
     case at::kHalf: return {msda_fwd_f16, msda_bwd_f16, msda_fwd_fused_f16, msda_bwd_fused_f16};
@@ -81,9 +90,9 @@ public:
         const at::Tensor shapes = shapes_.to(at::kLong).contiguous();  // stays on the device
         const int64_t B = img.size(0), I = img.size(1), H = img.size(2), D = img.size(3);
         const int64_t Q = pts.size(1), L = pts.size(3), P = pts.size(4);
-        at::Tensor out = at::empty({B, Q, H, D}, img.options());
+        at::Tensor out = at::empty({B, Q, H, D}, pts.options());
         const c10::DeviceGuard guard(img.device());
-        check_rc(fns_for(img.scalar_type())
+        check_rc(fns_for(img.scalar_type(), pts.scalar_type())
                      .fwd(img.data_ptr(), shapes.data_ptr<int64_t>(), pts.data_ptr(), att.data_ptr(), out.data_ptr(), B, I,
                           H, D, Q, L, P, (int)padding_mode, align_corners ? 1 : 0, current_stream(img)),
                  "msda_fwd");
@@ -101,7 +110,7 @@ public:
         const int padding_mode = (int)ctx->saved_data["padding_mode"].toInt();
         const bool align_corners = ctx->saved_data["align_corners"].toBool();
         at::Tensor gout = grads[0].contiguous();
-        if (gout.scalar_type() != img.scalar_type()) gout = gout.to(img.scalar_type());
+        if (gout.scalar_type() != pts.scalar_type()) gout = gout.to(pts.scalar_type());
         const bool want_value = ctx->needs_input_grad(0);
         const bool want_sample = ctx->needs_input_grad(2) || ctx->needs_input_grad(3);
         const int64_t B = img.size(0), I = img.size(1), H = img.size(2), D = img.size(3);
@@ -110,7 +119,7 @@ public:
         int64_t ws_bytes = 0;
         if (want_value) {
             g_img = at::empty_like(img);
-            ws_bytes = msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, (int)img.element_size());
+            ws_bytes = msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, (int)pts.element_size());
             ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));  // scratch: no initialisation needed
         }
         if (want_sample) {
@@ -119,7 +128,7 @@ public:
         }
         if (want_value || want_sample) {
             const c10::DeviceGuard guard(img.device());
-            check_rc(fns_for(img.scalar_type())
+            check_rc(fns_for(img.scalar_type(), pts.scalar_type())
                          .bwd(gout.data_ptr(), img.data_ptr(), shapes.data_ptr<int64_t>(), pts.data_ptr(), att.data_ptr(),
                               want_value ? g_img.data_ptr() : nullptr, want_sample ? g_pts.data_ptr() : nullptr,
                               want_sample ? g_att.data_ptr() : nullptr, B, I, H, D, Q, L, P, padding_mode,
@@ -142,9 +151,9 @@ public:
         const at::Tensor shapes = shapes_.to(at::kLong).contiguous();
         const int64_t B = img.size(0), I = img.size(1), H = img.size(2), D = img.size(3);
         const int64_t Q = proj.size(1), L = proj.size(3), P = proj.size(4);
-        at::Tensor out = at::empty({B, Q, H, D}, img.options());
+        at::Tensor out = at::empty({B, Q, H, D}, proj.options());
         const c10::DeviceGuard guard(img.device());
-        check_rc(fns_for(img.scalar_type())
+        check_rc(fns_for(img.scalar_type(), proj.scalar_type())
                      .fwd_fused(img.data_ptr(), shapes.data_ptr<int64_t>(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(),
                                 B, I, H, D, Q, L, P, (int)ref.size(-1), (int)padding_mode, align_corners ? 1 : 0,
                                 current_stream(img)),
@@ -163,22 +172,22 @@ public:
         const int padding_mode = (int)ctx->saved_data["padding_mode"].toInt();
         const bool align_corners = ctx->saved_data["align_corners"].toBool();
         at::Tensor gout = grads[0].contiguous();
-        if (gout.scalar_type() != img.scalar_type()) gout = gout.to(img.scalar_type());
+        if (gout.scalar_type() != proj.scalar_type()) gout = gout.to(proj.scalar_type());
         const bool want_value = ctx->needs_input_grad(0);
         const int64_t B = img.size(0), I = img.size(1), H = img.size(2), D = img.size(3);
         const int64_t Q = proj.size(1), L = proj.size(3), P = proj.size(4);
         const int64_t ref_dim = ref.size(-1);
         at::Tensor g_img, ws;
-        at::Tensor g_proj = at::empty_like(proj), g_ref_part = at::empty({B, Q, H, ref_dim}, img.options());
+        at::Tensor g_proj = at::empty_like(proj), g_ref_part = at::empty({B, Q, H, ref_dim}, proj.options());
         int64_t ws_bytes = 0;
         if (want_value) {
             g_img = at::empty_like(img);
-            ws_bytes = msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, (int)img.element_size());
+            ws_bytes = msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, (int)proj.element_size());
             ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));
         }
         {
             const c10::DeviceGuard guard(img.device());
-            check_rc(fns_for(img.scalar_type())
+            check_rc(fns_for(img.scalar_type(), proj.scalar_type())
                          .bwd_fused(gout.data_ptr(), img.data_ptr(), shapes.data_ptr<int64_t>(), proj.data_ptr(),
                                     ref.data_ptr(), want_value ? g_img.data_ptr() : nullptr, g_proj.data_ptr(),
                                     g_ref_part.data_ptr(), B, I, H, D, Q, L, P, (int)ref_dim, padding_mode,

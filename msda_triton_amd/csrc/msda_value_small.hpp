@@ -39,11 +39,12 @@ inline size_t small_lds_bytes(size_t cells, size_t samples, size_t acc_bytes, si
     return o + 64;
 }
 
-template <typename T, int VEC, int G>
+template <typename T, int VEC, int G, typename TV = T>  // TV: storage type of grad_value (see msda_fwd_kernel)
 __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
+    using TVR = Traits<TV>;
     constexpr int NG = kSmallBlock / G;  // lane groups per workgroup
     constexpr int UB = G < 8 ? G : 8;    // row loads in flight per lane
     // p.small_ns workgroups per (plane, level): each builds the level's sorted records for itself (cheap) and takes
@@ -293,10 +294,10 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
                     const int px = 2 * bx + (k & 1), py = 2 * by + (k >> 1);
                     if (px < lw && py < lh) {
                         const int pix = py * lw + px;
-                        Pack<T, VEC> ov;
+                        Pack<TV, VEC> ov;
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) ov.v[i] = TR::from_acc(acc[k][i]);
-                        T *dst = static_cast<T *>(p.grad_value) + (((size_t)b * p.I + pstart + pix) * p.H + h) * p.D + c0;
+                        for (int i = 0; i < VEC; ++i) ov.v[i] = TVR::from_acc(acc[k][i]);
+                        TV *dst = static_cast<TV *>(p.grad_value) + (((size_t)b * p.I + pstart + pix) * p.H + h) * p.D + c0;
                         if (pstart + pix < p.I) store_stream(dst, ov);  // (shapes that disagree with I: stay inside the plane)
                     }
                 }
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
         const int row_elems = p.D;
         for (long long e = (long long)tail0 * row_elems + tid; e < (long long)p.I * row_elems; e += kSmallBlock) {
             const int px = (int)(e / row_elems), c = (int)(e - (long long)px * row_elems);
-            static_cast<T *>(p.grad_value)[(((size_t)b * p.I + px) * p.H + h) * p.D + c] = TR::from_acc((A)0);
+            static_cast<TV *>(p.grad_value)[(((size_t)b * p.I + px) * p.H + h) * p.D + c] = TVR::from_acc((A)0);
         }
     }
 }

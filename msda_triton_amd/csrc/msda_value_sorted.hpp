@@ -680,11 +680,11 @@ template <typename A, int VEC> __device__ __forceinline__ Pack<A, VEC> load_acc_
 
 constexpr int kFinishPix = 1;  // pixels per lane group of the finish kernel: their loads are issued together
 
-template <typename T, int VEC, int G, int GB>
+template <typename T, int VEC, int G, int GB, typename TV = T>  // TV: storage type of grad_value (see msda_fwd_kernel)
 __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
-    using TR = Traits<T>;
+    using TR = Traits<TV>;
     constexpr int NU = kBlock / G;
     constexpr int NUG = GB / G;  // windows per gather workgroup
     constexpr int PP = kFinishPix;
@@ -782,10 +782,10 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
                     continue;
                 }
             }
-            Pack<T, VEC> o;
+            Pack<TV, VEC> o;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
-            T *dst = static_cast<T *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
+            TV *dst = static_cast<TV *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
             store_stream(dst, o);
         }
     }

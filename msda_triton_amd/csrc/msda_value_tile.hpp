@@ -17,11 +17,12 @@ namespace msda {
 constexpr int kValueBlock = 1024;
 using TileAcc = double;
 
-template <typename T, int CH>
+template <typename T, int CH, typename TV = T>  // TV: storage type of grad_value (see msda_fwd_kernel)
 __global__ __launch_bounds__(kValueBlock) void msda_bwd_value_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
+    using TVR = Traits<TV>;
 
     int pair, tile;
     if (!decode_block(p.grid3d, p.B * p.H, p.nchunks * p.nranges, p.xcd_map, pair, tile)) return;
@@ -98,12 +99,12 @@ __global__ __launch_bounds__(kValueBlock) void msda_bwd_value_kernel(const Param
     }
     __syncthreads();
     // tile write-out: CH contiguous channels per pixel
-    T *gv = static_cast<T *>(p.grad_value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D + chunk * CH;
+    TV *gv = static_cast<TV *>(p.grad_value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D + chunk * CH;
     for (int i = tid; i < npx; i += kValueBlock) {
-        Pack<T, CH> o;
+        Pack<TV, CH> o;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) o.v[c] = TR::from_acc((A)s_acc[c * npx + i]);
-        *reinterpret_cast<Pack<T, CH> *>(gv + (size_t)(p0 + i) * p.H * p.D) = o;
+        for (int c = 0; c < CH; ++c) o.v[c] = TVR::from_acc((A)s_acc[c * npx + i]);
+        *reinterpret_cast<Pack<TV, CH> *>(gv + (size_t)(p0 + i) * p.H * p.D) = o;
     }
 }
 

@@ -32,6 +32,23 @@ _SUFFIX = {
     torch.float64: "f64",
 }
 VALID_DTYPES = tuple(_SUFFIX)
+# mixed storage: `img` (and its gradient) in 16 bits next to fp32 sampling points / attention weights / output
+_MIXED_SUFFIX = {torch.bfloat16: "f32_vbf16", torch.float16: "f32_vf16"}
+
+
+def dtypes_supported(img_dtype: torch.dtype, compute_dtype: torch.dtype) -> bool:
+    """One dtype for every tensor, or a 16-bit `img` with fp32 everything else (the result is then fp32)."""
+    if img_dtype == compute_dtype:
+        return img_dtype in _SUFFIX
+    return compute_dtype == torch.float32 and img_dtype in _MIXED_SUFFIX
+
+
+def _suffix_for(img_dtype: torch.dtype, compute_dtype: torch.dtype) -> str:
+    if not dtypes_supported(img_dtype, compute_dtype):
+        raise ValueError(
+            "`img`, `sampling_points` and `attention_weights` should share one dtype (or `img` be float16 / bfloat16 "
+            f"next to float32 sampling inputs), but got {img_dtype} and {compute_dtype}.")
+    return _SUFFIX[img_dtype] if img_dtype == compute_dtype else _MIXED_SUFFIX[img_dtype]
 
 
 def _padding_code(padding_mode: str) -> int:
@@ -163,13 +180,17 @@ def msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mo
     B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
     _check_devices(img, img_shapes, sampling_points, attention_weights)
     pad = _padding_code(padding_mode)
-    suf = _SUFFIX[img.dtype]
+    cdt = sampling_points.dtype  # dtype of everything but `img` (the same, or fp32 next to a 16-bit `img`)
+    if attention_weights.dtype != cdt:
+        raise ValueError(f"`sampling_points` and `attention_weights` should share one dtype, but got {cdt} and "
+                         f"{attention_weights.dtype}.")
+    suf = _suffix_for(img.dtype, cdt)
     img, sampling_points, attention_weights = img.contiguous(), sampling_points.contiguous(), attention_weights.contiguous()
     shapes = _shapes_i64(img_shapes)
     if out is None:
-        out = torch.empty((B, Q, H, D), dtype=img.dtype, device=img.device)
-    elif tuple(out.shape) != (B, Q, H, D) or out.dtype != img.dtype or out.device != img.device or not out.is_contiguous():
-        raise ValueError(f"`out` should be a contiguous {(B, Q, H, D)} {img.dtype} tensor on {img.device}, but got "
+        out = torch.empty((B, Q, H, D), dtype=cdt, device=img.device)
+    elif tuple(out.shape) != (B, Q, H, D) or out.dtype != cdt or out.device != img.device or not out.is_contiguous():
+        raise ValueError(f"`out` should be a contiguous {(B, Q, H, D)} {cdt} tensor on {img.device}, but got "
                          f"{tuple(out.shape)} {out.dtype} on {out.device} (contiguous: {out.is_contiguous()}).")
     lib = _lib.load()
     fn = getattr(lib, f"msda_fwd_{suf}")
@@ -199,34 +220,38 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
     B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
     _check_devices(img, img_shapes, sampling_points, attention_weights, out_grad)
     pad = _padding_code(padding_mode)
-    suf = _SUFFIX[img.dtype]
+    cdt = sampling_points.dtype
+    if attention_weights.dtype != cdt:
+        raise ValueError(f"`sampling_points` and `attention_weights` should share one dtype, but got {cdt} and "
+                         f"{attention_weights.dtype}.")
+    suf = _suffix_for(img.dtype, cdt)
     img, sampling_points, attention_weights = img.contiguous(), sampling_points.contiguous(), attention_weights.contiguous()
     out_grad = out_grad.contiguous()
-    if out_grad.dtype != img.dtype:
-        out_grad = out_grad.to(img.dtype)
+    if out_grad.dtype != cdt:
+        out_grad = out_grad.to(cdt)
     shapes = _shapes_i64(img_shapes)
     want_value = bool(needs[0])
     want_sample = bool(needs[1] or needs[2])
-    kw = dict(dtype=img.dtype, device=img.device)
-    def buf(i, shape, wanted):
+
+    def buf(i, shape, wanted, dtype):
         if not wanted:
             return None
         t = out[i] if out is not None else None
         if t is None:
-            return torch.empty(shape, **kw)
-        if tuple(t.shape) != tuple(shape) or t.dtype != img.dtype or t.device != img.device or not t.is_contiguous():
-            raise ValueError(f"`out[{i}]` should be a contiguous {tuple(shape)} {img.dtype} tensor on {img.device}")
+            return torch.empty(shape, dtype=dtype, device=img.device)
+        if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != img.device or not t.is_contiguous():
+            raise ValueError(f"`out[{i}]` should be a contiguous {tuple(shape)} {dtype} tensor on {img.device}")
         return t
 
-    g_img = buf(0, (B, I, H, D), want_value)
-    g_pts = buf(1, (B, Q, H, L, P, 2), want_sample)
-    g_att = buf(2, (B, Q, H, L, P), want_sample)
+    g_img = buf(0, (B, I, H, D), want_value, img.dtype)
+    g_pts = buf(1, (B, Q, H, L, P, 2), want_sample, cdt)
+    g_att = buf(2, (B, Q, H, L, P), want_sample, cdt)
     if want_value or want_sample:
         lib = _lib.load()
         fn = getattr(lib, f"msda_bwd_{suf}")
         ws, ws_bytes = None, 0
         if want_value:  # scratch for the inverted index; the caching allocator makes this cheap
-            key = (B, I, H, D, Q, L, P, img.element_size(), _lib.OPTION_EPOCH)
+            key = (B, I, H, D, Q, L, P, sampling_points.element_size(), _lib.OPTION_EPOCH)
             ws_bytes = _WS_BYTES.get(key)
             if ws_bytes is None:
                 ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes(*key[:8]))
@@ -294,10 +319,10 @@ def hip_multiscale_deformable_attention(
     for name, t in (("img", img), ("sampling_points", sampling_points), ("attention_weights", attention_weights)):
         if t.dtype not in VALID_DTYPES:
             raise ValueError(f"Dtype of `{name}` should be in {list(VALID_DTYPES)}, but got {t.dtype}.")
-    if not (img.dtype == sampling_points.dtype == attention_weights.dtype):
+    if sampling_points.dtype != attention_weights.dtype or not dtypes_supported(img.dtype, sampling_points.dtype):
         raise ValueError(
-            "`img`, `sampling_points` and `attention_weights` should share one dtype, but got "
-            f"{img.dtype}, {sampling_points.dtype}, {attention_weights.dtype}.")
+            "`img`, `sampling_points` and `attention_weights` should share one dtype (or `img` be float16 / bfloat16 "
+            f"next to float32 sampling inputs), but got {img.dtype}, {sampling_points.dtype}, {attention_weights.dtype}.")
     _check_devices(img, img_shapes, sampling_points, attention_weights)
     _padding_code(padding_mode)
     if torch.compiler.is_compiling():  # traced by torch.compile / export: use the registered custom ops
@@ -354,10 +379,13 @@ def msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, al
         raise ValueError(f"`img_shapes` should be [{L}, 2], but got {tuple(img_shapes.shape)}.")
     _check_devices(img, img_shapes, proj, reference_points)
     pad = _padding_code(padding_mode)
-    suf = _SUFFIX[img.dtype]
+    cdt = proj.dtype
+    if reference_points.dtype != cdt:
+        raise ValueError(f"`proj` and `reference_points` should share one dtype, but got {cdt} and {reference_points.dtype}.")
+    suf = _suffix_for(img.dtype, cdt)
     img, proj, reference_points = img.contiguous(), proj.contiguous(), reference_points.contiguous()
     shapes = _shapes_i64(img_shapes)
-    out = torch.empty((B, Q, H, D), dtype=img.dtype, device=img.device)
+    out = torch.empty((B, Q, H, D), dtype=cdt, device=img.device)
     fn = getattr(_lib.load(), f"msda_fwd_fused_{suf}")
 
     def call():
@@ -383,21 +411,22 @@ def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, paddin
     ref_dim = reference_points.shape[-1]
     _check_devices(img, img_shapes, proj, reference_points, out_grad)
     pad = _padding_code(padding_mode)
-    suf = _SUFFIX[img.dtype]
+    cdt = proj.dtype
+    suf = _suffix_for(img.dtype, cdt)
     img, proj, reference_points = img.contiguous(), proj.contiguous(), reference_points.contiguous()
     out_grad = out_grad.contiguous()
-    if out_grad.dtype != img.dtype:
-        out_grad = out_grad.to(img.dtype)
+    if out_grad.dtype != cdt:
+        out_grad = out_grad.to(cdt)
     shapes = _shapes_i64(img_shapes)
-    kw = dict(dtype=img.dtype, device=img.device)
-    g_img = torch.empty((B, I, H, D), **kw) if need_img else None
+    kw = dict(dtype=cdt, device=img.device)
+    g_img = torch.empty((B, I, H, D), dtype=img.dtype, device=img.device) if need_img else None
     g_proj = torch.empty((B, Q, H, L, P, 3), **kw)
     g_ref_part = torch.empty((B, Q, H, ref_dim), **kw)
     lib = _lib.load()
     fn = getattr(lib, f"msda_bwd_fused_{suf}")
     ws, ws_bytes = None, 0
     if need_img:
-        ws_bytes = int(lib.msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, img.element_size()))
+        ws_bytes = int(lib.msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, proj.element_size()))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
     def call():
@@ -471,14 +500,21 @@ def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, ali
         img_shapes = img_shapes.to(img.device)
     if img.device.type == "cuda":
         _check_devices(img, proj, reference_points)
-    if img.device.type == "cuda" and img.dtype in VALID_DTYPES and proj.dtype == img.dtype and \
-            reference_points.dtype == img.dtype and not torch.compiler.is_compiling():
+    floating = img.is_floating_point() and proj.is_floating_point() and reference_points.is_floating_point()
+    if img.device.type == "cuda" and floating and _autocast_on() and not torch.compiler.is_compiling():
+        # under autocast the op computes in fp32 whatever the projections' dtypes are (custom_fwd casts every floating
+        # input, frontend.py:111): mixed bf16 projections / fp32 reference points still take the fused kernels
+        _padding_code(padding_mode)
+        return _HipFusedModuleCoreFunction.apply(img, img_shapes, proj, reference_points, padding_mode,
+                                                 bool(align_corners))
+    if img.device.type == "cuda" and dtypes_supported(img.dtype, proj.dtype) and \
+            reference_points.dtype == proj.dtype and not torch.compiler.is_compiling():
         pad = _padding_code(padding_mode)
         ext = _ext.load()
         if ext is not None and KernelTimer.active is None and not _autocast_on():
             # C++ autograd glue (see hip_multiscale_deformable_attention); only when the fused kernels take this L*P
             B, I, H, D = img.shape
-            key = (D, img.element_size())
+            key = (D, proj.element_size())
             limit = _FUSED_LP_LIMIT.get(key)
             if limit is None:
                 limit = _FUSED_LP_LIMIT[key] = int(ext.fused_lp_limit(*key))
@@ -490,8 +526,8 @@ def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, ali
                 return ext.msda_fused(img, img_shapes, proj, reference_points, pad, bool(align_corners))
         return _HipFusedModuleCoreFunction.apply(img, img_shapes, proj, reference_points, padding_mode,
                                                  bool(align_corners))
-    if img.device.type == "cuda" and torch.compiler.is_compiling() and img.dtype in VALID_DTYPES and \
-            proj.dtype == img.dtype and reference_points.dtype == img.dtype:
+    if img.device.type == "cuda" and torch.compiler.is_compiling() and dtypes_supported(img.dtype, proj.dtype) and \
+            reference_points.dtype == proj.dtype:
         from . import compile_op  # traced: keep the fused kernels as one custom op per direction
         if compile_op.fused_lp_ok(img, proj):
             return compile_op.compiled_fused_module_core(img, img_shapes, proj, reference_points, padding_mode,
@@ -528,7 +564,7 @@ def native_multiscale_deformable_attention(
     _padding_code(padding_mode)
     B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
     planes = img.permute(0, 2, 1, 3)  # [B, H, I, D]
-    out = img.new_zeros((B, H, Q, D))
+    out = img.new_zeros((B, H, Q, D), dtype=torch.result_type(img, sampling_points))
     start = 0
     for lvl, (h, w) in enumerate(img_shapes.tolist()):
         plane = planes[:, :, start:start + h * w]                      # [B, H, h*w, D]

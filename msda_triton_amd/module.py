@@ -7,7 +7,7 @@ the reference's, so state dicts interchange.  The projections are plain ``nn.Lin
 """
 from __future__ import annotations
 
-from typing import Literal
+from typing import Literal, Optional
 
 import torch
 from torch import nn
@@ -26,17 +26,28 @@ class MultiscaleDeformableAttention(nn.Module):
         num_points: sampling points per level.
         padding_mode: ``"border"`` or ``"zeros"``.
         align_corners: grid alignment.
+        value_dtype: (not in the reference; GPU only) ``torch.bfloat16`` / ``torch.float16``: keep the projected value
+            pyramid — the largest tensor the attention core reads, and the one autograd saves — in 16 bits, in the
+            kernel's ``[B, I, H, D]`` layout, while sampling offsets, attention logits, reference points and the
+            result stay fp32 (the kernels' mixed-storage entry points; arithmetic is fp32 either way).  Under
+            ``torch.autocast`` to that dtype the projection GEMM writes it directly; otherwise its output is cast
+            once.  ``None`` (default): the reference's behaviour — everything in the parameters' dtype, fp32 under
+            autocast.
 
     Raises:
         ValueError: if ``hidden_dim`` is not divisible by ``num_heads`` (frontend.py:211-212).
     """
 
     def __init__(self, emb_dim: int, hidden_dim: int, num_levels: int, num_heads: int, num_points: int,
-                 padding_mode: Literal["border", "zeros"], align_corners: bool):
+                 padding_mode: Literal["border", "zeros"], align_corners: bool,
+                 value_dtype: Optional[torch.dtype] = None):
         super().__init__()
         if hidden_dim % num_heads != 0:
             raise ValueError(
                 f"Hidden dimension ({hidden_dim=}) should be divisible by number of heads ({num_heads=}).")
+        if value_dtype not in (None, torch.bfloat16, torch.float16):
+            raise ValueError(f"`value_dtype` should be None, torch.bfloat16 or torch.float16, but got {value_dtype}.")
+        self.value_dtype = value_dtype
         self.num_levels = num_levels
         self.num_heads = num_heads
         self.num_points = num_points
@@ -77,5 +88,14 @@ class MultiscaleDeformableAttention(nn.Module):
         # and the offset -> sampling-point math run inside the attention kernel's prologue
         proj = self.query_input_proj(queries).reshape(B, N, H, L, P, 3)
         value = self.img_input_proj(img).reshape(B, I, H, self.hidden_dim // H)
-        attended = fused_module_core(value, img_shapes, proj, reference_points, self.padding_mode, self.align_corners)
+        if self.value_dtype is not None and value.device.type == "cuda":
+            # 16-bit value pyramid next to fp32 sampling inputs: the mixed-storage kernels read it as it is (no fp32
+            # copy, which is what autocast's cast_inputs would make), so the call sits outside autocast
+            value = value.to(self.value_dtype)  # nothing to do when autocast already produced this dtype
+            with torch.autocast("cuda", enabled=False):
+                attended = fused_module_core(value, img_shapes, proj.float(), reference_points.float(),
+                                             self.padding_mode, self.align_corners).to(proj.dtype)
+        else:
+            attended = fused_module_core(value, img_shapes, proj, reference_points, self.padding_mode,
+                                         self.align_corners)
         return self.query_output_proj(attended.reshape(B, N, self.hidden_dim))

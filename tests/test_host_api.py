@@ -215,3 +215,32 @@ def test_module_feeds_the_projection_output_to_the_kernel_in_place(monkeypatch):
     assert seen["value"].shape == (2, 16, 4, 8) and seen["value"].is_contiguous()
     assert seen["value"].data_ptr() == seen["proj"].data_ptr()          # same storage: a view
     assert seen["value"].untyped_storage().data_ptr() == seen["proj"].untyped_storage().data_ptr()
+
+
+def test_host_path_with_a_16_bit_pyramid_promotes_to_float32():
+    """Mixed storage on host tensors (the GPU entry points msda_*_f32_vbf16 / _vf16 have the same contract): a bf16
+    pyramid next to fp32 sampling inputs gives an fp32 result equal to the fp32 computation on the rounded pyramid."""
+    import msda_triton_amd as ops
+    torch.manual_seed(0)
+    shapes = torch.tensor([[5, 4], [3, 2]])
+    img = torch.randn(2, 26, 3, 8).bfloat16()
+    pts = torch.rand(2, 7, 3, 2, 4, 2)
+    att = torch.rand(2, 7, 3, 2, 4)
+    out = ops.multiscale_deformable_attention(img, shapes, pts, att, "zeros", False)
+    assert out.dtype == torch.float32
+    want = ops.multiscale_deformable_attention(img.float(), shapes, pts, att, "zeros", False)
+    torch.testing.assert_close(out, want, atol=1e-6, rtol=1e-6)
+
+
+def test_module_value_dtype_is_validated_and_ignored_on_host_tensors():
+    import msda_triton_amd as ops
+    kw = dict(emb_dim=16, hidden_dim=16, num_levels=2, num_heads=2, num_points=2, padding_mode="border", align_corners=True)
+    with pytest.raises(ValueError, match="value_dtype"):
+        ops.MultiscaleDeformableAttention(**kw, value_dtype=torch.float64)
+    torch.manual_seed(0)
+    a = ops.MultiscaleDeformableAttention(**kw)
+    b = ops.MultiscaleDeformableAttention(**kw, value_dtype=torch.bfloat16)
+    b.load_state_dict(a.state_dict())
+    shapes = torch.tensor([[4, 3], [2, 2]])
+    img, q, ref = torch.randn(1, 16, 16), torch.randn(1, 5, 16), torch.rand(1, 5, 2)
+    torch.testing.assert_close(a(img, shapes, q, ref), b(img, shapes, q, ref))
