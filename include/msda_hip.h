@@ -155,7 +155,9 @@ MSDA_API const char *msda_last_error(void);
  *                1: always the LDS-tile kernel   2: the sorted gather (if a workspace is supplied)
  *                3: the single-launch kernel whenever it fits
  *   "overlap"    -1 (default): grad_loc/grad_attn run on a forked side stream next to grad_value where that was
- *                   measured to pay (single-launch grad_value kernel; rows of >= 128 bytes);  0: never;  1: always
+ *                   measured to pay (next to the single-launch kernel from ~800k samples; next to the sorted pipeline
+ *                   from 4M samples when rows have >= 128 bytes): the fork/join itself costs ~14 us of host time and
+ *                   ~19 us of latency;  0: never;  1: always
  *   "cell_slices", "small_ns", "wg_target", "debug": experiment knobs, see msda_triton_amd/csrc/msda_launch.hpp
  */
 MSDA_API int msda_set_option(const char *key, int value);
