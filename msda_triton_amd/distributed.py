@@ -248,7 +248,7 @@ class _RowShardedMSDA(Function):
         bounds = [row_shard_bounds(rows, world, r) for r in range(world)]
         r0, r1 = bounds[rank]
         gpu = img.device.type == "cuda"
-        full = img.new_empty((rows, H, D))
+        full = pts_rows.new_empty((rows, H, D))  # the sampling inputs' dtype (fp32 next to a 16-bit pyramid)
         equal = all(e - b == bounds[0][1] - bounds[0][0] for b, e in bounds)
         chunks = max(1, int(chunks))
         pending = []
