@@ -162,3 +162,43 @@ def test_row_segments_partition_the_row_space():
                 assert 0 <= b < B and 0 <= q0 < q1 <= Q
                 seen.extend(range(b * Q + q0, b * Q + q1))
         assert seen == list(range(B * Q))
+
+
+def _row_worker_mixed(rank, world, port, ret):
+    """bf16 pyramid next to fp32 sampling inputs (the mixed-storage contract): the exchanged result is fp32, the
+    pyramid's gradient stays bf16; ranks divide B, so grad_value needs no communication."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        from msda_triton_amd import multiscale_deformable_attention, synth
+        from msda_triton_amd.distributed import row_shard_bounds, row_sharded_multiscale_deformable_attention
+        batch, q_total = 2, 6
+        wl = synth.Workload("t", batch, q_total, 3, 8, ((6, 5), (3, 3)), 2, "float32", "border", True)
+        d = synth.make_inputs_torch(wl, "cpu", seed=7)
+        r0, r1 = row_shard_bounds(batch * q_total, world, rank)
+        dr = synth.make_inputs_torch(wl, "cpu", seed=7, rows=(r0, r1))
+        v = d["value"].bfloat16().requires_grad_(True)
+        l_in, a_in = dr["loc"].clone().requires_grad_(True), dr["attn"].clone().requires_grad_(True)
+        out = row_sharded_multiscale_deformable_attention(v, d["shapes"], l_in, a_in, "border", True,
+                                                          inputs_are_sharded=True, num_queries=q_total,
+                                                          grad_value_sync="owners", overlap_chunks=2)
+        out.backward(d["grad_out"])
+        v2 = d["value"].bfloat16().requires_grad_(True)
+        l2, a2 = d["loc"].clone().requires_grad_(True), d["attn"].clone().requires_grad_(True)
+        ref = multiscale_deformable_attention(v2, d["shapes"], l2, a2, "border", True)
+        ref.backward(d["grad_out"])
+        ok = out.dtype == torch.float32 and v.grad.dtype == torch.bfloat16 and torch.allclose(out, ref, atol=1e-6)
+        ok &= torch.allclose(v.grad[rank].float(), v2.grad[rank].float(), atol=2e-2, rtol=2e-2)
+        ok &= float(v.grad[1 - rank].float().abs().sum()) == 0.0
+        rows = batch * q_total
+        ok &= torch.allclose(l_in.grad, l2.grad.reshape(rows, *l2.grad.shape[2:])[r0:r1], atol=1e-5)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_shard_gloo_mixed_storage():
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_row_worker_mixed, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert dict(ret) == {0: True, 1: True}
