@@ -175,15 +175,25 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
     const int HLP = p.H * p.LP;
     const int tid = threadIdx.x;
 
-    // fixed slot per thread: threads [0, dq * LP) are active; thread t serves slot t % LP of the queries
-    // qa + t / LP + k * dq.  (More slots than threads: each thread strides over the slots of one query at a time.)
+    // fixed slot per thread: with LPt (level, point) slots in play, threads [0, dq * LPt) are active; thread t serves
+    // slot t % LPt of the queries qa + t / LPt + k * dq.  (More slots than threads: each thread strides over the
+    // slots of one query at a time.)
     const bool fixed = p.LP <= kCellBlock;
-    const int dq = fixed ? kCellBlock / p.LP : 1;
-    const int sl0 = fixed ? tid % p.LP : 0, tq = fixed ? tid / p.LP : 0;
-    const bool active = fixed && tq < dq;
 
     for (int c0 = 0; c0 < ncells; c0 += cap) {  // one trip unless the plane has more cells than fit in LDS
         const int n = min(cap, ncells - c0);
+        // A trip only walks the samples of the levels whose cells it holds (a sample's level is known from its
+        // index): a plane with several trips reads its samples about once in total instead of once per trip, and
+        // all threads share the trip's levels (c5, 88k cells, three trips: levels 0 | 0-1 | 1-4).
+        int l_lo = 0, l_hi = p.L - 1;
+        if (fixed && ncells > cap) {
+            while (l_lo < p.L - 1 && tab->cstart[l_lo + 1] <= c0) ++l_lo;           // last level starting at or before c0
+            while (l_hi > l_lo && tab->cstart[l_hi] >= c0 + n) --l_hi;               // ... and before the chunk's end
+        }
+        const int LPt = fixed ? (l_hi - l_lo + 1) * p.P : p.LP;
+        const int dq = fixed ? kCellBlock / LPt : 1;
+        const int sl0 = fixed ? l_lo * p.P + tid % LPt : 0, tq = fixed ? tid / LPt : 0;
+        const bool active = fixed && tq < dq;
         for (int i = tid; i < n; i += kCellBlock) {
             int v = 0;
             if constexpr (PLACE)  // this slice's first slot in every cell list

@@ -1,0 +1,24 @@
+"""dev tool: a pyramid with more bilinear cells than the count / place passes keep in LDS at once (several trips per
+workgroup): per-group kernel times.  Usage: python tools/big_pyramid_bench.py [lib.so]"""
+import os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 1:
+    shutil.copy(sys.argv[1], os.path.join(ROOT, "msda_triton_amd", "libmsda_hip.so"))
+import torch
+from msda_triton_amd import synth
+from msda_triton_amd.functional import KernelTimer, multiscale_deformable_attention
+
+wl = synth.Workload("big", 1, 20000, 8, 32, ((256, 256), (128, 128), (64, 64), (32, 32)), 4, "float32", "border", True)
+dev = torch.device("cuda", 0)
+d = synth.make_inputs_torch(wl, dev, seed=0)
+v, pts, att = d["value"].requires_grad_(True), d["loc"].requires_grad_(True), d["attn"].requires_grad_(True)
+go = torch.rand(wl.B, wl.Q, wl.H, wl.D, device=dev)
+def step():
+    multiscale_deformable_attention(v, d["shapes"], pts, att, wl.padding_mode, wl.align_corners).backward(go)
+    v.grad = pts.grad = att.grad = None
+for _ in range(5): step()
+with KernelTimer() as kt:
+    for _ in range(20): step()
+torch.cuda.synchronize()
+print({k: round(ms * 1e3, 1) for k, (n, ms) in kt.summary().items()})
