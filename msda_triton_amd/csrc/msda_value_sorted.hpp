@@ -863,6 +863,13 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     int64_t ns = pairs ? (int64_t)((256 + pairs - 1) / pairs) : 1;
     const int64_t by_work = (int64_t)((samples + 2047) / 2048);
     if (ns > by_work) ns = by_work;
+    // ... and no more slices than the per-slice cell tables are worth: every slice writes, scans and reads back a
+    // table of ~I counters, so with few samples per pixel the tables outweigh the samples.  About 36 bytes of sample
+    // traffic against 16 bytes of table traffic per cell and slice; measured on a 256..32 px pyramid, 8 planes
+    // (grad_value us): Q=20 000: 32 slices 288, 16 slices 255, 8 slices 274; Q=5 000: 32 slices 196, 8 slices 172,
+    // 4 slices 183.
+    const int64_t by_tables = I > 0 ? (int64_t)((9 * samples) / (2 * (size_t)I)) : ns;
+    if (ns > by_tables) ns = by_tables;
     if (option_cell_slices() > 0) ns = option_cell_slices();
     if (ns > 64) ns = 64;
     if (ns > q_round) ns = q_round;
