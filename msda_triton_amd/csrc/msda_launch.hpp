@@ -235,7 +235,7 @@ template <typename T, typename TV = T> inline int dispatch_value(Params &p, hipS
 // ---- sorted (gather-formulated) grad_value: K1..K5 of msda_value_sorted.hpp ----
 template <typename T, int VEC, int G, int GB, typename TV = T> inline int launch_value_gather_block(Params &p, hipStream_t stream)
 {
-    constexpr int NU = kBlock / G, NUG = GB / G;
+    constexpr int NUG = GB / G;
     const int npairs = p.B * p.H;
     dim3 g4, g5;
     if (!plane_grid(p, npairs, (p.win_cap + NUG - 1) / NUG, g4)) {
@@ -243,11 +243,15 @@ template <typename T, int VEC, int G, int GB, typename TV = T> inline int launch
         return MSDA_ERR_TOO_LARGE;
     }
     hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G, GB>), g4, dim3(GB), 0, stream, p);
-    if (!plane_grid(p, npairs, (p.I + NU * kFinishPix - 1) / (NU * kFinishPix), g5)) {
+    const int fp = finish_pixels(npairs, p.I);
+    if (!plane_grid(p, npairs, (p.I + fp - 1) / fp, g5)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    hipLaunchKernelGGL((msda_value_finish_kernel<T, VEC, G, GB, TV>), g5, dim3(kBlock), 0, stream, p);
+    if (fp == 64)
+        hipLaunchKernelGGL((msda_value_finish_kernel<T, VEC, G, GB, TV, 64>), g5, dim3(kBlock), 0, stream, p);
+    else
+        hipLaunchKernelGGL((msda_value_finish_kernel<T, VEC, G, GB, TV, 32>), g5, dim3(kBlock), 0, stream, p);
     return (int)hipGetLastError();
 }
 

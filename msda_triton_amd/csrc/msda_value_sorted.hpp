@@ -688,50 +688,80 @@ template <typename A, int VEC> __device__ __forceinline__ Pack<A, VEC> load_acc_
     }
 }
 
-constexpr int kFinishPix = 1;  // pixels per lane group of the finish kernel: their loads are issued together
+// Pixels per finish workgroup.  Measured (finish kernel, us): 1.1 M pixels with ~0.8 samples per pixel (a 100 x 134 ..
+// 13 x 17 pyramid, 64 planes, 900 queries: Deformable-DETR / Grounding-DINO decoder at COCO size) 32: 81, 64: 62, 128:
+// 64; c2-10k (174 k pixels) 32: 20.3, 64: 21.4, 128: 24.6 — few pixels want many small workgroups.
+inline int finish_pixels(long long planes, long long I) { return planes * I >= 400000 ? 64 : 32; }
 
-template <typename T, int VEC, int G, int GB, typename TV = T>  // TV: storage type of grad_value (see msda_fwd_kernel)
+// K5, two phases per workgroup of kFinishPixels consecutive pixels.
+// Phase 1, ONE LANE PER PIXEL (the first kFinishPixels threads): pixel -> (level, x, y), the six list starts around
+// it, which of its four slots were written, whether continuation rows exist.  That is ~250 vector + ~140 scalar
+// instructions; with one G-lane group per pixel doing it all (the previous kernel) a wave paid them for 8 pixels, and
+// they were 40 of the kernel's 88 us on a 1.1 M-pixel problem (ablation: no memory operation at all in the body still
+// took 56 us against 16 for the launch + level table).
+// Phase 2, G lanes per pixel row: the loads of up to four rows' slots are issued together (only written slots; a load
+// no lane of the wave needs is not issued), fixed-order sums, one store per row.
+// TV: storage type of grad_value (see msda_fwd_kernel); kFinishPixels: pixels per workgroup (finish_pixels)
+template <typename T, int VEC, int G, int GB, typename TV = T, int kFinishPixels = 32>
 __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<TV>;
     constexpr int NU = kBlock / G;
     constexpr int NUG = GB / G;  // windows per gather workgroup
-    constexpr int PP = kFinishPix;
-    const int slots = (p.I + NU * PP - 1) / (NU * PP);
+    constexpr int ROUNDS = (kFinishPixels + NU - 1) / NU;  // pixel rows per lane group
+    constexpr int RB = ROUNDS < 4 ? ROUNDS : 4;            // ... whose slot loads are in flight together
+    const int slots = (p.I + kFinishPixels - 1) / kFinishPixels;
     int pair, slot;
     if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
     __shared__ LevelTab tab;
+    __shared__ int s_rng[kFinishPixels][6];     // list starts t0 t1 t2 (cell row y-1), u0 u1 u2 (cell row y)
+    __shared__ uint32_t s_flags[kFinishPixels];  // bits 0-3: slot k was written; bit 4: continuation rows to add
     load_level_table(&tab, p.shapes, p.L);
     __syncthreads();
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
-    const int unit = threadIdx.x / G, j = threadIdx.x % G;
-    const int pix0 = (slot * NU + unit) * PP;
-    if (pix0 >= p.I) return;
-    const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
-    const int ncells = min(plane_cells(tab, p.L), p.nc_cap);
-    // record ranges of the cells (x-1,y-1), (x,y-1) | (x-1,y), (x,y) of every pixel: consecutive cell ids, consecutive
-    // ranges.  A pixel the shapes tensor does not describe (sum h*w != I), or one whose cells were dropped for lack
-    // of workspace, has no cells: all ranges empty, the row is stored as zeros.
-    int tt[PP][3], uu[PP][3];
-#pragma unroll
-    for (int t = 0; t < PP; ++t) {
-        const int pix = min(pix0 + t, p.I - 1);
-        int l = 0;
-        while (l < p.L - 1 && pix >= tab.start[l + 1]) ++l;
-        const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
-        const int y = rel / max(w, 1), x = rel - y * w;
-        const int c11 = tab.cstart[l] + y * cw + x;  // cell (x-1, y-1)
-        const bool in_tab = w > 0 && y < tab.h[l] && c11 + cw + 2 <= ncells;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            tt[t][k] = in_tab ? off[c11 + k] : 0;
-            uu[t][k] = in_tab ? off[c11 + cw + k] : 0;
-        }
-    }
-    auto carried = [](int a0, int a1, int a2) { return a1 > a0 && a2 > a1 && (a0 / kWin) == (a1 / kWin); };
+    const int tid = threadIdx.x;
+    const int pix_base = slot * kFinishPixels;
+    // (list starts are non-negative: unsigned shifts instead of signed divisions)
+    auto window = [](int r) { return (uint32_t)r / (uint32_t)kWin; };
+    auto carried = [&](int a0, int a1, int a2) { return a1 > a0 && a2 > a1 && window(a0) == window(a1); };
     // continuation row sets: gather-workgroup boundaries strictly inside a cell's window range
-    auto nconts = [](int beg, int end) { return end > beg ? ((end - 1) / kWin) / NUG - (beg / kWin) / NUG : 0; };
+    auto nconts = [&](int beg, int end) {
+        return end > beg ? (int)(window(end - 1) / (uint32_t)NUG) - (int)(window(beg) / (uint32_t)NUG) : 0;
+    };
+    // ---- phase 1: record ranges of the cells (x-1,y-1), (x,y-1) | (x-1,y), (x,y) of the thread's pixel: consecutive
+    // cell ids, consecutive ranges.  A pixel the shapes tensor does not describe (sum h*w != I), or one whose cells
+    // were dropped for lack of workspace, has no cells: all ranges empty, the row is stored as zeros. ----
+    if (tid < kFinishPixels) {
+        const int pix = pix_base + tid;
+        struct Three {
+            int v[3];
+        };
+        Three ta{{0, 0, 0}}, ua{{0, 0, 0}};
+        if (pix < p.I) {
+            const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
+            const int ncells = min(plane_cells(tab, p.L), p.nc_cap);
+            int l = 0;
+            while (l < p.L - 1 && pix >= tab.start[l + 1]) ++l;
+            const int rel = pix - tab.start[l], w = tab.w[l], cw = w + 1;
+            const int y = rel / max(w, 1), x = rel - y * w;
+            const int c11 = tab.cstart[l] + y * cw + x;  // cell (x-1, y-1)
+            if (w > 0 && y < tab.h[l] && c11 + cw + 2 <= ncells) {
+                __builtin_memcpy(&ta, off + c11, sizeof(Three));  // three consecutive list starts: one 12-byte load
+                __builtin_memcpy(&ua, off + c11 + cw, sizeof(Three));
+            }
+        }
+        const int t0 = ta.v[0], t1 = ta.v[1], t2 = ta.v[2], u0 = ua.v[0], u1 = ua.v[1], u2 = ua.v[2];
+        uint32_t flags = (u2 > u1 ? 1u : 0u) | ((u1 > u0 && !carried(u0, u1, u2)) ? 2u : 0u) | (t2 > t1 ? 4u : 0u) |
+                         ((t1 > t0 && !carried(t0, t1, t2)) ? 8u : 0u);
+        if (nconts(u1, u2) + nconts(u0, u1) + nconts(t1, t2) + nconts(t0, t1) != 0) flags |= 16u;
+        s_flags[tid] = flags;
+        s_rng[tid][0] = t0, s_rng[tid][1] = t1, s_rng[tid][2] = t2;
+        s_rng[tid][3] = u0, s_rng[tid][4] = u1, s_rng[tid][5] = u2;
+    }
+    __syncthreads();
+    // ---- phase 2 ----
+    const int unit = tid / G, j = tid % G;
     const A *cont = static_cast<const A *>(p.ws_cont) + (size_t)pair * p.cont_cap * 4 * p.D;
     const size_t plane_slots = (size_t)p.I * 4 * p.D * sizeof(A);  // < 2^31 (host check)
     const rsrc_t rs_sc = make_rsrc(static_cast<const unsigned char *>(p.ws_scratch) + (size_t)pair * plane_slots, (uint32_t)plane_slots);
@@ -739,64 +769,75 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
     for (int cc = 0; cc < nchan_chunks; ++cc) {
         const int c0 = (cc * G + j) * VEC;
         if (c0 >= p.D) continue;
-        // the pixels' four slots each: independent range-checked loads through a buffer descriptor; a slot nobody
-        // wrote gets an out-of-range offset and reads 0 without touching memory (no branch)
-        Pack<A, VEC> r[PP][4];
+        for (int r0 = 0; r0 < ROUNDS; r0 += RB) {
+            if (pix_base + r0 * NU >= p.I) break;  // block-uniform: nothing left
+            // the rows' four slots each: independent range-checked loads through a buffer descriptor; a slot nobody
+            // wrote gets an out-of-range offset and reads 0 without touching memory, and an instruction whose lanes
+            // are all masked is not issued at all (it would still occupy the vector-memory path)
+            uint32_t flags[RB];
+            Pack<A, VEC> rr[RB][4];
 #pragma unroll
-        for (int t = 0; t < PP; ++t) {
-            const int pix = min(pix0 + t, p.I - 1);
-            const uint32_t base = ((uint32_t)pix * 4u * (uint32_t)p.D + (uint32_t)c0) * (uint32_t)sizeof(A);
-            const int t0 = tt[t][0], t1 = tt[t][1], t2 = tt[t][2], u0 = uu[t][0], u1 = uu[t][1], u2 = uu[t][2];
-            const bool on[4] = {u2 > u1, u1 > u0 && !carried(u0, u1, u2), t2 > t1, t1 > t0 && !carried(t0, t1, t2)};
+            for (int t = 0; t < RB; ++t) {
+                const int pt = (r0 + t) * NU + unit, pix = pix_base + pt;
+                const bool live = pt < kFinishPixels && pix < p.I;  // (64 lane groups of 4 lanes, 32 pixels: half the groups idle)
+                flags[t] = live ? s_flags[pt] | 32u : 0u;  // bit 5: the row exists
+                const uint32_t base = ((uint32_t)(live ? pix : 0) * 4u * (uint32_t)p.D + (uint32_t)c0) * (uint32_t)sizeof(A);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                r[t][k] = load_acc_pack<A, VEC>(rs_sc, on[k] ? base + (uint32_t)k * (uint32_t)p.D * (uint32_t)sizeof(A) : 0x80000000u);
-        }
+                for (int k = 0; k < 4; ++k) {
 #pragma unroll
-        for (int t = 0; t < PP; ++t) {
-            const int pix = pix0 + t;
-            if (pix >= p.I) break;
-            const int t0 = tt[t][0], t1 = tt[t][1], t2 = tt[t][2], u0 = uu[t][0], u1 = uu[t][1], u2 = uu[t][2];
-            A acc[VEC];
+                    for (int v = 0; v < VEC; ++v) rr[t][k].v[v] = (A)0;
+                    const bool on = ((flags[t] >> k) & 1u) != 0;
+                    if (__builtin_amdgcn_ballot_w64(on) != 0)
+                        rr[t][k] = load_acc_pack<A, VEC>(rs_sc, on ? base + (uint32_t)k * (uint32_t)p.D * (uint32_t)sizeof(A) : 0x80000000u);
+                }
+            }
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] = ((r[t][0].v[v] + r[t][1].v[v]) + r[t][2].v[v]) + r[t][3].v[v];
-            if (nconts(u1, u2) + nconts(u0, u1) + nconts(t1, t2) + nconts(t0, t1) != 0) {
-                auto add = [&](int beg, int end, int corner) {
-                    if (end <= beg) return;
-                    const int g1 = ((end - 1) / kWin) / NUG;
-                    for (int g = (beg / kWin) / NUG + 1; g <= g1; ++g) {
-                        const Pack<A, VEC> rr =
-                            *reinterpret_cast<const Pack<A, VEC> *>(cont + ((size_t)g * 4 + corner) * p.D + c0);
+            for (int t = 0; t < RB; ++t) {
+                if (!(flags[t] & 32u)) continue;
+                const int pt = (r0 + t) * NU + unit, pix = pix_base + pt;
+                A acc[VEC];
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) acc[v] += rr.v[v];
+                for (int v = 0; v < VEC; ++v) acc[v] = ((rr[t][0].v[v] + rr[t][1].v[v]) + rr[t][2].v[v]) + rr[t][3].v[v];
+                if (flags[t] & 16u) {
+                    auto add = [&](int beg, int end, int corner) {
+                        if (end <= beg) return;
+                        const int g1 = (int)(window(end - 1) / (uint32_t)NUG);
+                        for (int g = (int)(window(beg) / (uint32_t)NUG) + 1; g <= g1; ++g) {
+                            const Pack<A, VEC> cr =
+                                *reinterpret_cast<const Pack<A, VEC> *>(cont + ((size_t)g * 4 + corner) * p.D + c0);
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc[v] += cr.v[v];
+                        }
+                    };
+                    const int t0 = s_rng[pt][0], t1 = s_rng[pt][1], t2 = s_rng[pt][2];
+                    const int u0 = s_rng[pt][3], u1 = s_rng[pt][4], u2 = s_rng[pt][5];
+                    add(u1, u2, 0);
+                    add(u0, u1, 1);
+                    add(t1, t2, 2);
+                    add(t0, t1, 3);
+                }
+                // several rounds over the queries: running sums in the accumulate type between them
+                if (p.finish_mode != 0) {
+                    A *run = static_cast<A *>(p.ws_accum) + ((size_t)pair * p.I + pix) * p.D + c0;
+                    if (p.finish_mode != 1) {
+                        const Pack<A, VEC> prev = *reinterpret_cast<const Pack<A, VEC> *>(run);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[v] += prev.v[v];
                     }
-                };
-                add(u1, u2, 0);
-                add(u0, u1, 1);
-                add(t1, t2, 2);
-                add(t0, t1, 3);
-            }
-            // several rounds over the queries: running sums in the accumulate type between them
-            if (p.finish_mode != 0) {
-                A *run = static_cast<A *>(p.ws_accum) + ((size_t)pair * p.I + pix) * p.D + c0;
-                if (p.finish_mode != 1) {
-                    const Pack<A, VEC> prev = *reinterpret_cast<const Pack<A, VEC> *>(run);
+                    if (p.finish_mode != 3) {
+                        Pack<A, VEC> keep;
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[v] += prev.v[v];
+                        for (int v = 0; v < VEC; ++v) keep.v[v] = acc[v];
+                        *reinterpret_cast<Pack<A, VEC> *>(run) = keep;
+                        continue;
+                    }
                 }
-                if (p.finish_mode != 3) {
-                    Pack<A, VEC> keep;
+                Pack<TV, VEC> o;
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) keep.v[v] = acc[v];
-                    *reinterpret_cast<Pack<A, VEC> *>(run) = keep;
-                    continue;
-                }
+                for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
+                TV *dst = static_cast<TV *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
+                store_stream(dst, o);
             }
-            Pack<TV, VEC> o;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) o.v[v] = TR::from_acc(acc[v]);
-            TV *dst = static_cast<TV *>(p.grad_value) + (((size_t)b * p.I + pix) * p.H + h) * p.D + c0;
-            store_stream(dst, o);
         }
     }
 }
