@@ -158,7 +158,8 @@ MSDA_API const char *msda_last_error(void);
  *                   measured to pay (next to the single-launch kernel from ~800k samples; next to the sorted pipeline
  *                   from 4M samples when rows have >= 128 bytes): the fork/join itself costs ~14 us of host time and
  *                   ~19 us of latency;  0: never;  1: always
- *   "cell_slices", "small_ns", "wg_target", "debug": experiment knobs, see msda_triton_amd/csrc/msda_launch.hpp
+ *   "cell_slices", "small_ns", "gather_win", "wg_target", "debug": experiment knobs, see
+ *                msda_triton_amd/csrc/msda_launch.hpp and msda_value_sorted.hpp
  */
 MSDA_API int msda_set_option(const char *key, int value);
 MSDA_API int msda_get_option(const char *key);

@@ -20,6 +20,7 @@ static std::atomic<int> g_debug{0};
 static std::atomic<int> g_small_ns{0};
 static std::atomic<int> g_q_round{0};
 static std::atomic<int> g_overlap{-1};
+static std::atomic<int> g_gather_win{0};
 
 // one side stream + two events per device, created on first use and kept for the life of the process
 struct SideStream {
@@ -77,6 +78,7 @@ int option_debug() { return g_debug.load(std::memory_order_relaxed); }
 int option_small_ns() { return g_small_ns.load(std::memory_order_relaxed); }
 int option_q_round() { return g_q_round.load(std::memory_order_relaxed); }
 int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
+int option_gather_win() { return g_gather_win.load(std::memory_order_relaxed); }
 
 void set_error(const char *fmt, ...)
 {
@@ -142,6 +144,10 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_overlap.store(value < 0 ? -1 : value ? 1 : 0, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "gather_win") == 0 && value >= 0 && value <= 4096 && (value == 0 || value >= 8)) {
+        msda::g_gather_win.store(value, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "cell_slices") == 0 && value >= 0 && value <= 64) {
         msda::g_cell_slices.store(value, std::memory_order_relaxed);
         return 0;
@@ -164,6 +170,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "small_ns") == 0) return msda::option_small_ns();
     if (key && strcmp(key, "q_round") == 0) return msda::option_q_round();
     if (key && strcmp(key, "overlap") == 0) return msda::option_overlap();
+    if (key && strcmp(key, "gather_win") == 0) return msda::option_gather_win();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

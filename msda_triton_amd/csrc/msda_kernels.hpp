@@ -59,6 +59,8 @@ struct Params {
     void *ws_scratch;   // [pairs][I][4][D]   acc-typed partial rows: slot k of a pixel = what the cell having it as corner k left
     void *ws_cont;      // [pairs][cont_cap][4][D] acc-typed continuation rows: one set per gather workgroup
     int nc_cap, nblk_cap, win_cap, cont_cap;
+    int win;          // records per gather window (sorted grad_value)
+    FastDiv div_win;  // ... and the division by it
     int nsplit;         // query slices per plane in the count / place passes
     int cell_cap;       // cells a count / place workgroup holds in LDS at a time
     // query chunking of the sorted path (Q so large that a plane's grad_out rows leave L2): the passes of one round

@@ -297,6 +297,8 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
     p.ws_accum = w.rounds > 1 ? ws + w.off_accum : nullptr;
     p.nc_cap = w.nc_cap;
     p.nblk_cap = w.nblk_cap;
+    p.win = w.win;
+    p.div_win = make_fast_div((uint32_t)w.win);
     p.win_cap = w.win_cap;
     p.cont_cap = w.cont_cap;
     p.nsplit = w.nsplit;

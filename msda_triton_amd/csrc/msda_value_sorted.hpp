@@ -37,7 +37,8 @@
 
 namespace msda {
 
-constexpr int kWin = 64;              // records per gather window
+constexpr int kWinMax = 64;           // records per gather window: at most (chosen per call, sorted_ws_layout)
+constexpr int kWinMin = 16;           // ... and at least
 constexpr int kGatherMinBlock = 256;  // threads per gather workgroup (sizes the continuation rows)
 constexpr int kCellBlock = 1024;      // threads of K1 / K3
 constexpr int kScanCells = 256;       // cells per K2 workgroup (= its thread count)
@@ -380,7 +381,7 @@ template <typename Tag> __global__ __launch_bounds__(kScanCells) void msda_cell_
 }
 
 // ------------------------------------------------------------------------------------------
-// K4: gather.  One G-lane group per window of kWin sorted records, VEC channels per lane.
+// K4: gather.  One G-lane group per window of p.win sorted records, VEC channels per lane.
 // ------------------------------------------------------------------------------------------
 template <typename A> struct alignas(16) CornerW {
     A w[4];  // a * {(1-dx)(1-dy), dx(1-dy), (1-dx)dy, dx dy}: corners 00, 01, 10, 11
@@ -437,12 +438,12 @@ __global__ __launch_bounds__(GB) void msda_value_gather_kernel(const Params p)
     int pair, slot;
     if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
     const int N = p.ws_total[pair];  // records of the plane
-    if ((long long)slot * NU * kWin >= N) return;  // block-uniform
+    if ((long long)slot * NU * p.win >= N) return;  // block-uniform
     const int tid = threadIdx.x;
     const int unit = tid / G, j = tid % G;
     const int win = slot * NU + unit;
-    const int r0 = win * kWin;
-    const int count = max(0, min(kWin, N - r0));  // idle groups (count == 0) still take part in the block barriers
+    const int r0 = win * p.win;
+    const int count = max(0, min(p.win, N - r0));  // idle groups (count == 0) still take part in the block barriers
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int gbase = tid - j;
 
@@ -722,8 +723,8 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
     const int tid = threadIdx.x;
     const int pix_base = slot * kFinishPixels;
-    // (list starts are non-negative: unsigned shifts instead of signed divisions)
-    auto window = [](int r) { return (uint32_t)r / (uint32_t)kWin; };
+    const FastDiv dw = p.div_win;  // record index -> gather window (the window size is chosen per call)
+    auto window = [dw](int r) { return fast_div((uint32_t)r, dw); };
     auto carried = [&](int a0, int a1, int a2) { return a1 > a0 && a2 > a1 && window(a0) == window(a1); };
     // continuation row sets: gather-workgroup boundaries strictly inside a cell's window range
     auto nconts = [&](int beg, int end) {
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
 // workspace layout (host + device agree through these helpers)
 // ------------------------------------------------------------------------------------------
 struct SortedWsLayout {
-    int nc_cap, nblk_cap, win_cap, cont_cap, nsplit;
+    int nc_cap, nblk_cap, win, win_cap, cont_cap, nsplit;
     int q_round, rounds;  // queries per round and rounds over the queries (1: everything at once)
     size_t off_part, off_blocktot, off_off, off_total, off_meta, off_entries, off_scratch, off_cont, off_accum, total;
 };
@@ -854,6 +855,7 @@ struct SortedWsLayout {
 int option_q_round();  // queries per round of the sorted path (0: automatic), msda_api.hip
 
 int option_cell_slices();  // 0: automatic (msda_api.hip)
+int option_gather_win();   // records per gather window (0: automatic)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -896,9 +898,19 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     const size_t samples = (size_t)(q_round * L * P);  // per plane and round
     w.nc_cap = (int)(2 * I + 2 * L);             // (w+1)(h+1) <= 2wh + 2 per level
     w.nblk_cap = (w.nc_cap + kScanCells - 1) / kScanCells;
-    w.win_cap = (int)((samples + kWin - 1) / kWin);
     const int gl = gather_group_lanes(D, elem_bytes, vec);
     const int nug = gl >= kGatherMinBlock ? 1 : kGatherMinBlock / gl;
+    // records per gather window: 64, fewer when that would leave the chip short of workgroups (1024 run at a time; aim
+    // for two rounds of them).  Measured (grad_value, us; 64 / 32 / 16 records): c2 @ 5k 116 / 110 / -, c2 @ 2k 128 /
+    // 125 / 121, a 17 821-pixel pyramid with 900 queries and 16 planes: gather alone 23.2 / 15.3 / 12.0.  At c2-10k
+    // 40..80 records are all the same (64.9-65.8) and more only lengthens the tail (96: 73, 128: 81, 256: 102).
+    {
+        long long win = (long long)(pairs * samples) / (2048LL * nug) / 8 * 8;
+        win = win < kWinMin ? kWinMin : win > kWinMax ? kWinMax : win;
+        if (option_gather_win() >= 8) win = option_gather_win();
+        w.win = (int)win;
+    }
+    w.win_cap = (int)((samples + w.win - 1) / w.win);
     w.cont_cap = (w.win_cap + nug - 1) / nug + 1;
     // query slices per plane: enough workgroups to fill the chip, at least ~2k samples each
     int64_t ns = pairs ? (int64_t)((256 + pairs - 1) / pairs) : 1;
