@@ -243,7 +243,8 @@ template <typename T, int VEC, int G, int GB, typename TV = T> inline int launch
         return MSDA_ERR_TOO_LARGE;
     }
     hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G, GB>), g4, dim3(GB), 0, stream, p);
-    const int fp = finish_pixels(npairs, p.I);
+    // (4-lane groups: 64 of them per workgroup, so 64 pixels keep them all busy)
+    const int fp = kBlock / G > 32 ? 64 : finish_pixels(npairs, p.I);
     if (!plane_grid(p, npairs, (p.I + fp - 1) / fp, g5)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
