@@ -32,6 +32,16 @@ class MultiScaleDeformableAttention(nn.Module):
         elif shapes.device != value.device:
             shapes = shapes.to(value.device)
         dtype = value.dtype
+        if value.device.type == "cuda" and dtype in (torch.bfloat16, torch.float16) and \
+                sampling_locations.dtype == torch.float32 and attention_weights.dtype == torch.float32:
+            # what autocast hands this module: a 16-bit value pyramid (from the value projection) next to fp32
+            # sampling locations / softmaxed weights.  The mixed-storage kernels read the pyramid as it is and keep
+            # the coordinates in fp32 (casting them to 16 bits would cost a quarter pixel on a 64-px level; casting
+            # everything to fp32, which autocast's policy for the plain operator does, copies the pyramid).
+            autocast = torch.is_autocast_enabled("cuda")
+            with torch.autocast("cuda", enabled=False):
+                out = multiscale_deformable_attention(value, shapes, sampling_locations, attention_weights, "zeros", False)
+            return (out if autocast else out.to(dtype)).flatten(2)
         if sampling_locations.dtype != dtype:
             sampling_locations = sampling_locations.to(dtype)
         if attention_weights.dtype != dtype:
