@@ -10,8 +10,10 @@ extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_byte
     // problems the single-launch kernel takes need no workspace at all
     const msda::Dims d{B, I, H, D, Q, L, P};
     const bool small = elem_size == 8 ? msda::small_path_chosen<double>(d) : msda::small_path_chosen<float>(d);
+    const size_t acc = elem_size == 8 ? 8 : 4;
+    if (msda::option_value_path() == 4) return (int64_t)msda::binned_ws_layout(B, I, H, D, Q, L, P, acc, true).total;
     if (small) return 0;
-    return (int64_t)msda::sorted_ws_layout(B, I, H, D, Q, L, P, elem_size == 8 ? 8 : 4, (size_t)elem_size).total;
+    return (int64_t)msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size).total;
 }
 
 // largest L*P the fused-prologue kernels (msda_fwd_fused / msda_bwd_fused) take for this head dimension and

@@ -1,15 +1,13 @@
 #!/bin/bash
-# dev tool: per-kernel times (rocprofv3 kernel trace) of bench.py on the given workloads
+# dev tool: per-kernel times of a workload under option strings ("k=v,k=v"):  WORKLOAD=c3_ddetr_enc bash tools/prof_wl.sh value_path=0 value_path=4
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for wl in "$@"; do
-  rm -rf gpurun_out/prof_wl
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_wl -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload $wl --opt value_path=2 > gpurun_out/prof_wl.log 2>&1
-  echo "== $wl"
-  python - <<'PY'
-import csv,glob
-for f in glob.glob('gpurun_out/prof_wl/*/*kernel_stats.csv'):
-    for r in csv.DictReader(open(f)):
-        if 'msda' in r['Name']:
-            print(f"{r['Name'].split('msda::')[1].split('(')[0]:55s} {float(r['AverageNs'])/1000:9.1f} us  x{r['Calls']}")
-PY
+W=${WORKLOAD:-c2_q10k}
+STEPS=${STEPS:-6}
+for o in "$@"; do
+  args=""
+  for kv in ${o//,/ }; do args="$args --opt $kv"; done
+  rm -rf gpurun_out/prof_dbg
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_dbg -- python bench.py --workload $W --steps $STEPS --warmup 2 --no-cpu-baseline --no-strong-c5 --opt overlap=0 $args > gpurun_out/prof_dbg.log 2>&1
+  echo "== $W $o"
+  bash tools/kstats.sh gpurun_out/prof_dbg | grep -v "fwd_kernel\|bwd_sample"
 done
