@@ -18,7 +18,20 @@ share a batch element (none while N divides B).  `value` = query rows (b, q) pro
 job, fwd+bwd.  The same run also times a STRONG-scaling leg under the key `strong_scaling_c5`: BASELINE configs[4]
 (B=4, Q=100 000, D=64, L=5, P=8, fp16) with its 400 000 rows split over the N ranks.
 
-Rank 0 prints ONE JSON line.
+The N=1 run also carries (same JSON line):
+  * `do_bench`: the reference's timing recipe for this workload (scripts/benchmark.py:38,52-54,90-94 — triton.testing.do_bench:
+    >= 100 ms of warm-up, >= 1 s of repetitions, per-repetition device events, median + p20 / p80), once with the
+    caches flushed between repetitions (cold, as do_bench does) and once back to back (warm);
+  * `configs`: every other BASELINE.json config that fits one GPU (c1, c2 @ 1k / 5k, c3, c4): fwd_ms, fwd_bwd_ms,
+    per-launch-group microseconds with their roofline fraction and measured HBM traffic, peak memory.
+`ms_per_step` stays the K timed steps of the headline workload.
+
+`--backend gloo --device cpu` (with `--workload dryrun`) runs the whole N-rank control flow — sharding, both exchanges,
+the stall guard, the strong-scaling leg's plumbing, the JSON contract — on host tensors over gloo: a rehearsal of the
+multi-GPU path on a box without GPUs (tests/test_distributed_cpu.py runs it at world size 2).  Its numbers mean nothing.
+
+Rank 0 prints ONE JSON line.  An optional leg that fails is reported under its key as {"error": ...} and the process
+exits with status 1 AFTER the line has been printed.
 """
 import argparse
 import json
@@ -115,17 +128,138 @@ def torch_cpu_fallback(wl, budget_s=8.0, q_sample=1000):
             "sample": f"{len(times)} fwd+bwd passes on the first {q_sample} queries per batch element, fp32, median"}
 
 
-def strong_scaling_c5(dev, world, rank, use_dist, chunks=None, steps=5, warmup=2):
-    """BASELINE configs[4] (stress) with its B*Q = 400 000 rows split over the ranks: fwd+bwd ms per step.  Inputs are
-    drawn on the device (torch RNG, same seed on every rank for the replicated value pyramid): only shapes matter."""
+def _quantile(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    k = (len(xs) - 1) * q
+    lo, hi = int(k), min(int(k) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
+
+
+def do_bench(fn, dev, flush, warmup_ms=100.0, rep_ms=1000.0):
+    """triton.testing.do_bench semantics with HIP events (reference scripts/benchmark.py:38,52-54): estimate the
+    cost of one call, run ~warmup_ms of warm-up, then ~rep_ms worth of repetitions, each bracketed by its own event
+    pair; `flush`: a buffer larger than L2 + Infinity Cache is rewritten before every repetition (do_bench's cache
+    clear), so every repetition starts cold.  Returns median / p20 / p80 in ms."""
+    import torch
+
+    cache = torch.empty(512 * 1024 * 1024, dtype=torch.int8, device=dev) if flush else None
+    fn()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        if cache is not None:
+            cache.zero_()
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    est = e0.elapsed_time(e1) / 5
+    n_warm = max(1, int(warmup_ms / est))
+    n_rep = max(10, min(5000, int(rep_ms / est)))
+    for _ in range(n_warm):
+        fn()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_rep)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_rep)]
+    for i in range(n_rep):
+        if cache is not None:
+            cache.zero_()
+        starts[i].record()
+        fn()
+        ends[i].record()
+    torch.cuda.synchronize(dev)
+    t = [a.elapsed_time(b) for a, b in zip(starts, ends)]
+    return {"median_ms": _quantile(t, 0.5), "p20_ms": _quantile(t, 0.2), "p80_ms": _quantile(t, 0.8), "reps": n_rep,
+            "warmup_calls": n_warm}
+
+
+def load_traffic(workload):
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            return json.load(f).get(workload, {})
+    return {}
+
+
+def kernel_table(wl, kern, traffic):
+    """per launch group: launches, mean us (HIP events), algorithmic bytes, achieved GB/s, fraction of the HBM peak,
+    HBM traffic per launch measured by the PMC passes (profiles/hbm_traffic.json; None if not profiled)"""
+    alg = kernel_alg_bytes(wl)
+    out = {}
+    for name, (n, mean_ms) in sorted(kern.items()):
+        gbs = alg[name] / (mean_ms * 1e-3) / 1e9
+        out[name] = {"launches": n, "avg_us": round(mean_ms * 1e3, 2), "alg_bytes": alg[name],
+                     "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                     "traffic": traffic.get(name)}
+    return out
+
+
+def bench_config(name, dev, steps=20, warmup=5):
+    """One BASELINE config on one GPU through the public autograd API: warm mean of `steps` steps (fwd only, fwd+bwd),
+    per-launch-group HIP-event times, peak memory of a fwd+bwd."""
+    import torch
+    from msda_triton_amd import synth
+    from msda_triton_amd.functional import KernelTimer, multiscale_deformable_attention
+
+    wl = synth.WORKLOADS[name]
+    d = synth.make_inputs_torch(wl, dev, seed=0)
+    img, shapes = d["value"].requires_grad_(True), d["shapes"]
+    pts, attn = d["loc"].requires_grad_(True), d["attn"].requires_grad_(True)
+    pm, ac = wl.padding_mode, wl.align_corners
+
+    def step():
+        out = multiscale_deformable_attention(img, shapes, pts, attn, pm, ac)
+        out.backward(torch.rand_like(out))
+        img.grad = pts.grad = attn.grad = None
+
+    def fwd_only():
+        with torch.no_grad():
+            multiscale_deformable_attention(img, shapes, pts, attn, pm, ac)
+
+    def timed(fn, n):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3 / n
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    step()
+    torch.cuda.synchronize(dev)
+    peak = torch.cuda.max_memory_allocated(dev)
+    ms_step = timed(step, steps)
+    for _ in range(warmup):
+        fwd_only()
+    ms_fwd = timed(fwd_only, steps)
+    with KernelTimer() as kt:
+        timed(step, steps)
+    kernels = kernel_table(wl, kt.summary(), load_traffic(name))
+    return {"workload": f"{wl.name}: B={wl.B} Q={wl.Q} H={wl.H} D={wl.D} L={wl.L} levels={list(wl.levels)} P={wl.P} "
+                        f"{wl.dtype} {pm} align_corners={ac}",
+            "steps": steps, "fwd_ms": ms_fwd, "fwd_bwd_ms": ms_step,
+            "alg_fwd_bwd_GBs": round((wl.alg_fwd_bytes + wl.alg_bwd_bytes) / (ms_step * 1e-3) / 1e9, 1),
+            "peak_mem_MB": round(peak / 1e6, 1), "inputs_MB": round(base / 1e6, 1), "kernels": kernels}
+
+
+def strong_scaling_leg(wl_name, dev, world, rank, use_dist, chunks=None, steps=5, warmup=2):
+    """A BASELINE config (configs[4], the stress shape, in real runs) with its B*Q rows split over the ranks: fwd+bwd
+    ms per step.  Inputs are drawn on the device (torch RNG, same seed on every rank for the replicated value pyramid):
+    only shapes matter."""
     import torch
     import torch.distributed as dist
     from msda_triton_amd import synth
     from msda_triton_amd.distributed import row_shard_bounds, row_sharded_multiscale_deformable_attention
     from msda_triton_amd.functional import multiscale_deformable_attention
 
-    wl = synth.WORKLOADS["c5_stress"]
-    dt = getattr(torch, wl.dtype)
+    wl = synth.WORKLOADS[wl_name]
+    on_gpu = torch.device(dev).type == "cuda"
+    dt = getattr(torch, wl.dtype) if on_gpu else torch.float32  # (the host path is a dry run: fp32)
     rows = wl.B * wl.Q
     r0, r1 = row_shard_bounds(rows, world, rank) if use_dist else (0, rows)
     g = torch.Generator(device=dev).manual_seed(1234)
@@ -149,10 +283,12 @@ def strong_scaling_c5(dev, world, rank, use_dist, chunks=None, steps=5, warmup=2
         value.grad = pts.grad = att.grad = None
 
     def barrier():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(warmup):
         step()
@@ -167,10 +303,22 @@ def strong_scaling_c5(dev, world, rank, use_dist, chunks=None, steps=5, warmup=2
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_s = float(t.item())
     ms = dt_s * 1e3 / steps
-    return {"workload": f"c5_stress: B={wl.B} Q={wl.Q} (global) H={wl.H} D={wl.D} L={wl.L} P={wl.P} {wl.dtype}, "
-                        f"{rows} rows over {world} rank(s)", "scaling": "strong", "n_gpus": world, "steps": steps,
-            "warmup": warmup, "ms_per_step": ms, "value": rows / (ms * 1e-3), "unit": "queries/s",
-            "alg_fwd_bwd_GBs": round((wl.alg_fwd_bytes + wl.alg_bwd_bytes) / (ms * 1e-3) / 1e9, 1)}
+    out = {"workload": f"{wl.name}: B={wl.B} Q={wl.Q} (global) H={wl.H} D={wl.D} L={wl.L} P={wl.P} {wl.dtype}, "
+                       f"{rows} rows over {world} rank(s)", "scaling": "strong", "n_gpus": world, "steps": steps,
+           "warmup": warmup, "ms_per_step": ms, "value": rows / (ms * 1e-3), "unit": "queries/s",
+           "alg_fwd_bwd_GBs": round((wl.alg_fwd_bytes + wl.alg_bwd_bytes) / (ms * 1e-3) / 1e9, 1)}
+    # speed-up against the one-GPU time of the same leg: this run's own at N = 1, else the committed N = 1 record
+    ref = os.path.join(ROOT, "profiles", "n1_reference.json")
+    if world == 1:
+        out["speedup_vs_n1"] = 1.0
+    elif os.path.exists(ref):
+        with open(ref) as f:
+            n1 = json.load(f).get(wl_name, {}).get("strong_leg_ms_per_step")
+        if n1:
+            out["n1_ms_per_step"] = n1
+            out["speedup_vs_n1"] = n1 / ms
+            out["n1_source"] = "profiles/n1_reference.json (an earlier --gpus 1 run of this bench on one MI355X)"
+    return out
 
 
 class _StallGuard:
@@ -215,8 +363,13 @@ def main():
     ap.add_argument("--grad-value-sync", default="owners", choices=["owners", "all_reduce", "none"],
                     help="multi-GPU: how grad_value is combined (owners: among the ranks sharing a batch element)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="initialise RCCL and use the sharded code path even with one rank (self-test)")
-    ap.add_argument("--no-strong-c5", action="store_true", help="skip the strong-scaling c5 leg")
+                    help="initialise the process group and use the sharded code path even with one rank (self-test)")
+    ap.add_argument("--no-strong-c5", action="store_true", help="skip the strong-scaling leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (N=1 only)")
+    ap.add_argument("--no-do-bench", action="store_true", help="skip the do_bench (cold / warm quantiles) leg (N=1 only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --device cpu: dry run of the N-rank control flow on host tensors")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="msda_set_option override for A/B runs, e.g. --opt value_path=2 --opt overlap=0")
     args = ap.parse_args()
@@ -235,31 +388,45 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback); --device cpu --backend gloo is "
+                             "a dry run of the control flow only")
+        if args.backend != "nccl":
+            raise SystemExit("--device cuda goes with --backend nccl (RCCL)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        if args.backend != "gloo":
+            raise SystemExit("--device cpu goes with --backend gloo")
+        dev = torch.device("cpu")
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    if args.xcd_map is not None:
-        _lib.set_option("xcd_map", args.xcd_map)
-    for kv in args.opt:
-        key, val = kv.split("=")
-        _lib.set_option(key, int(val))
+        if on_gpu:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if on_gpu:
+        if args.xcd_map is not None:
+            _lib.set_option("xcd_map", args.xcd_map)
+        for kv in args.opt:
+            key, val = kv.split("=")
+            _lib.set_option(key, int(val))
 
     wl = synth.WORKLOADS[args.workload]
     pm, ac = wl.padding_mode, wl.align_corners
     # Weak scaling: the global problem has B batch elements of world*Q queries; rank r owns B*Q contiguous rows of
     # the flattened (b, q) row space — whole batch elements while the ranks divide B.
     gwl = synth.Workload(wl.name, wl.B, wl.Q * world, wl.H, wl.D, wl.levels, wl.P, wl.dtype, pm, ac)
+    in_dt = None if on_gpu else torch.float32
     if use_dist:
         r0, r1 = row_shard_bounds(gwl.B * gwl.Q, world, rank)
-        d = synth.make_inputs_torch(gwl, dev, seed=0, rows=(r0, r1))
+        d = synth.make_inputs_torch(gwl, dev, seed=0, rows=(r0, r1), dtype=in_dt)
     else:
-        d = synth.make_inputs_torch(gwl, dev, seed=0)
+        d = synth.make_inputs_torch(gwl, dev, seed=0, dtype=in_dt)
     img, shapes = d["value"].requires_grad_(True), d["shapes"]
     pts, attn = d["loc"].requires_grad_(True), d["attn"].requires_grad_(True)
 
@@ -282,10 +449,12 @@ def main():
             op()
 
     def barrier():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     def timed(fn, n):
         barrier()
@@ -301,6 +470,7 @@ def main():
         return dt
 
     guard = _StallGuard(rank)
+    failed_legs = []
 
     def measure():
         for _ in range(args.warmup):
@@ -327,26 +497,26 @@ def main():
         ms_step, ms_fwd = measure()
     # ---- the same K steps again with per-launch HIP events (KernelTimer splits the backward into one C-ABI call
     #      per kernel group, so its two halves run back to back here instead of concurrently) ----
-    with KernelTimer() as kt:
-        timed(step, args.steps)
-    kern = kt.summary()
+    kern = {}
+    peak_mem = None
+    if on_gpu:
+        with KernelTimer() as kt:
+            timed(step, args.steps)
+        kern = kt.summary()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        step()
+        torch.cuda.synchronize()
+        peak_mem = torch.cuda.max_memory_allocated(dev)
 
     if rank == 0:
-        alg = kernel_alg_bytes(wl)
-        kernels = {}
-        for name, (n, mean_ms) in sorted(kern.items()):
-            gbs = alg[name] / (mean_ms * 1e-3) / 1e9
-            kernels[name] = {"launches": n, "avg_us": round(mean_ms * 1e3, 2), "alg_bytes": alg[name],
-                             "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-        dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(args.workload, {}).get(dom)
+        kernels = kernel_table(wl, kern, load_traffic(args.workload))
         sum_kernel_us = sum(k["avg_us"] for k in kernels.values())
+        weak_note = ("" if world == 1 else
+                     f" — WEAK scaling: every rank keeps {wl.Q} queries per batch element, the global problem has "
+                     f"Q = {wl.Q} x {world} = {gwl.Q}")
         result = {
-            "metric": "MSDA fwd+bwd @10k queries (fwd_ms / fwd_bwd_ms alongside), 1 MI355X per rank",
+            "metric": "MSDA fwd+bwd @10k queries per GPU (fwd_ms / fwd_bwd_ms alongside), 1 MI355X per rank" + weak_note,
             "value": wl.B * wl.Q * world / (ms_step * 1e-3),
             "unit": "queries/s",
             "n_gpus": world,
@@ -361,12 +531,15 @@ def main():
             "config": {"workload": f"{wl.name}: B={wl.B} Q={wl.Q}/rank H={wl.H} D={wl.D} L={wl.L} "
                                    f"levels={list(wl.levels)} P={wl.P} {wl.dtype} {pm} align_corners={ac}",
                        "global_queries": gwl.Q,
+                       "scaling_note": "weak: global Q = per-rank Q x N (the metric's 10k queries are per GPU); the "
+                                       "strong_scaling leg keeps the global problem fixed",
                        "parallelism": f"row-shard x{world} (B*Q rows per rank, kernels write in place, in-place exchange "
                                       f"overlapped with compute{', grad_value ' + args.grad_value_sync if use_dist else ''})",
                        "step": "public autograd API: fwd + backward(rand_like(out)) + grad reset",
                        "exchange": ("none (one rank)" if world == 1 else
                                     "one in-place all-gather" if exchange["chunks"] == 1 else
-                                    "grouped point-to-point pieces overlapped with compute")},
+                                    "grouped point-to-point pieces overlapped with compute"),
+                       "backend": args.backend, "device": args.device},
             "fwd_ms": ms_fwd,
             "fwd_bwd_ms": ms_step,
             "sum_kernel_us_fwd_bwd": round(sum_kernel_us, 2),
@@ -376,28 +549,53 @@ def main():
             "reference_readme_rtx2060_ms": README_RTX2060_MS,
             "speedup_vs_reference_readme": {"fwd": README_RTX2060_MS["fwd"] / ms_fwd,
                                             "fwd_bwd": README_RTX2060_MS["fwd_bwd"] / ms_step},
-            "roofline": {"kernel": dom + (" (grad_value: cell_pass x2, cell_scan, value_gather, value_finish — or the "
-                                          "single-launch kernel on small problems; timed as one C-ABI call)"
-                                          if dom == "msda_bwd_value" else ""), "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic,
-                         "timing": "HIP events around every launch, same K steps repeated right after the timed region"},
             "kernels": kernels,
-            "options": {k: _lib.get_option(k) for k in ("xcd_map", "value_path", "overlap")},
+            "peak_mem_MB": round(peak_mem / 1e6, 1) if peak_mem is not None else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(wl)
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
+            result["roofline"] = {
+                "kernel": dom + (" (grad_value: cell_pass x2, cell_scan, value_gather, value_finish — or the "
+                                 "single-launch kernel on small problems; timed as one C-ABI call)"
+                                 if dom == "msda_bwd_value" else ""),
+                "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": kernels[dom]["traffic"],
+                "traffic_source": "profiles/hbm_traffic.json: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this "
+                                  "bench, gfx950 corrections applied; not re-measured in this run",
+                "timing": "HIP events around every launch, same K steps repeated right after the timed region"}
+        if on_gpu:
+            result["options"] = {k: _lib.get_option(k) for k in ("xcd_map", "value_path", "overlap")}
     else:
         result = None
     guard.result, guard.have_result = result, True
+
+    # ---- optional legs: none of them may cost rank 0 its JSON line ----
+    def optional(key, fn, collective):
+        """Run one optional leg; an exception is recorded under `key` (collective legs are attempted on every rank: an
+        error in a collective is raised on all of them, a stall trips the guard)."""
+        try:
+            if os.environ.get("MSDA_BENCH_INJECT_FAIL") == key:  # test hook (tests/test_distributed_cpu.py)
+                raise RuntimeError(f"injected failure in optional leg {key}")
+            out = fn()
+        except Exception as e:  # noqa: BLE001
+            out = {"error": repr(e)[:300]}
+            failed_legs.append(key)
+        if rank == 0 and out is not None:
+            result[key] = out
+        return out
+
+    pieces_failed = False
     if exchange_ms is not None:
         guard.arm(240, "piece-wise exchange (weak-scaling leg)")
         exchange["chunks"] = None
         try:
             ms2, fwd2 = measure()
             exchange_ms["pieces"] = {"fwd_bwd_ms": ms2, "fwd_ms": fwd2}
-        except RuntimeError as e:  # every rank sees the same RCCL error; a rank left waiting trips the guard
+        except Exception as e:  # every rank sees the same RCCL error; a rank left waiting trips the guard
             ms2 = None
-            exchange_ms["pieces"] = {"error": repr(e)[:200]}
+            pieces_failed = True
+            failed_legs.append("exchange_ms.pieces")
+            exchange_ms["pieces"] = {"error": repr(e)[:300]}
         guard.disarm()
         if ms2 is not None and ms2 < ms_step:  # the all-reduced max over ranks: the same decision everywhere
             ms_step, ms_fwd = ms2, fwd2
@@ -411,21 +609,60 @@ def main():
                                                        "fwd_bwd": README_RTX2060_MS["fwd_bwd"] / ms_step})
             result["config"]["exchange"] = ("one in-place all-gather" if exchange["chunks"] == 1 else
                                             "grouped point-to-point pieces overlapped with compute")
-    strong = None
-    if not args.no_strong_c5 and args.workload == "c2_q10k":
+    if world == 1 and on_gpu and rank == 0:
+        if not args.no_do_bench:
+            def leg_do_bench():
+                return {"recipe": "triton.testing.do_bench semantics (reference scripts/benchmark.py:38,52-54): >=100 ms "
+                                  "warm-up, >=1 s of repetitions, one HIP-event pair per repetition, median + p20/p80; "
+                                  "cold = a 512 MiB buffer rewritten before every repetition (L2 + Infinity Cache flushed), "
+                                  "warm = back to back",
+                        "fwd": {"cold": do_bench(fwd_only, dev, True), "warm": do_bench(fwd_only, dev, False)},
+                        "fwd_bwd": {"cold": do_bench(step, dev, True), "warm": do_bench(step, dev, False)}}
+            optional("do_bench", leg_do_bench, False)
+        if not args.no_cpu_baseline:
+            optional("cpu_baseline", lambda: cpu_baseline(wl), False)
+    strong_wl = "c5_stress" if on_gpu else "dryrun_strong"
+    run_strong = not args.no_strong_c5 and args.workload in ("c2_q10k", "dryrun")
+    if run_strong and pieces_failed:
+        # the communicator that just raised is not reused (its error state would only raise again)
+        if rank == 0:
+            result["strong_scaling_c5"] = {"skipped": "the piece-wise exchange failed on this communicator"}
+        run_strong = False
+    if run_strong:
         del img, pts, attn, d
-        torch.cuda.empty_cache()
+        if on_gpu:
+            torch.cuda.empty_cache()
         if world > 1:
-            guard.arm(300, "strong-scaling c5 leg")
-        strong = strong_scaling_c5(dev, world, rank, use_dist, exchange["chunks"])  # every rank takes part; rank 0 reports
+            guard.arm(300, "strong-scaling leg")
+        optional("strong_scaling_c5",
+                 lambda: strong_scaling_leg(strong_wl, dev, world, rank, use_dist, exchange["chunks"]), True)
         guard.disarm()
+        if on_gpu:
+            torch.cuda.empty_cache()
+    if world == 1 and on_gpu and rank == 0 and not args.no_configs and args.workload == "c2_q10k":
+        def leg_configs():
+            out = {}
+            for name in ("c1_readme", "c2_q1k", "c2_q5k", "c3_ddetr_enc", "c4_gdino_dec"):
+                try:
+                    out[name] = bench_config(name, dev)
+                except Exception as e:  # noqa: BLE001
+                    out[name] = {"error": repr(e)[:300]}
+                    failed_legs.append(f"configs.{name}")
+                torch.cuda.empty_cache()
+            return out
+        optional("configs", leg_configs, False)
     if rank == 0:
-        if strong is not None:
-            result["strong_scaling_c5"] = strong
+        if failed_legs:
+            result["failed_legs"] = failed_legs
         print(json.dumps(result), flush=True)
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 (a communicator in error state: the line is out, just leave)
+            pass
+    if failed_legs:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -102,6 +102,10 @@ WORKLOADS = {
     # configs[4]: stress
     "c5_stress": Workload("c5_stress", 4, 100000, 8, 64,
                           ((128, 128), (64, 64), (32, 32), (16, 16), (8, 8)), 8, "float16", "zeros", False),
+    # not BASELINE configs: tiny shapes for `bench.py --backend gloo --device cpu` (control-flow rehearsal of the
+    # multi-GPU bench on a box without GPUs; the numbers mean nothing)
+    "dryrun": Workload("dryrun", 2, 48, 2, 8, ((6, 5), (3, 3)), 2, "float32", "border", True),
+    "dryrun_strong": Workload("dryrun_strong", 2, 96, 2, 8, ((6, 5), (3, 3), (2, 2)), 2, "float32", "zeros", False),
 }
 
 

@@ -202,3 +202,51 @@ def test_row_shard_gloo_mixed_storage():
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_row_worker_mixed, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ------------------------------------------------------------------------------------------
+# bench.py's N-rank control flow, rehearsed on host tensors over gloo (no GPU): the JSON contract of the N > 1 line,
+# both exchanges, the strong-scaling leg's plumbing, and that a failing optional leg costs neither the line nor the
+# other legs (an exception in an optional leg must not lose the headline)
+# ------------------------------------------------------------------------------------------
+def _run_bench_dry(world, extra_env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world),
+           "--steps", "2", "--warmup", "1", "--backend", "gloo", "--device", "cpu", "--workload", "dryrun"]
+    res = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res, [json.loads(ln) for ln in lines]
+
+
+def test_bench_dry_run_world2_prints_the_contract_line():
+    res, lines = _run_bench_dry(2)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert len(lines) == 1, res.stdout[-2000:]  # ONE line, from rank 0
+    r = lines[0]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in r, key
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert "WEAK" in r["metric"] and r["config"]["global_queries"] == 2 * 48
+    assert abs(r["value"] - 2 * 2 * 48 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    ex = r["exchange_ms"]  # both exchanges were measured, the line carries the faster one
+    assert ex["all_gather"]["fwd_bwd_ms"] > 0 and ex["pieces"]["fwd_bwd_ms"] > 0
+    assert r["ms_per_step"] == min(ex["all_gather"]["fwd_bwd_ms"], ex["pieces"]["fwd_bwd_ms"])
+    s = r["strong_scaling_c5"]
+    assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["ms_per_step"] > 0
+    assert "failed_legs" not in r
+
+
+def test_bench_dry_run_failing_optional_leg_keeps_the_line():
+    res, lines = _run_bench_dry(2, {"MSDA_BENCH_INJECT_FAIL": "strong_scaling_c5"})
+    assert res.returncode != 0  # the failure is reported through the exit status ...
+    assert len(lines) == 1, res.stdout[-2000:]  # ... after the line has been printed
+    r = lines[0]
+    assert r["ms_per_step"] > 0 and "injected failure" in r["strong_scaling_c5"]["error"]
+    assert r["failed_legs"] == ["strong_scaling_c5"]
