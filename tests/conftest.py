@@ -29,10 +29,35 @@ def mode_key(pm, ac):
 
 
 def golden_cases(dtype_tag=None):
-    files = sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if "digest_" not in os.path.basename(f))
+    files = sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                   if not os.path.basename(f).startswith(("digest_", "module_")))
     if dtype_tag:
         files = [f for f in files if f.endswith(f"_{dtype_tag}.npz")]
     return files
+
+
+def module_cases(dtype_tag=None):
+    """fixtures of the reference's nn.Module (tests/golden/make_golden.py: write_module_cases)"""
+    files = sorted(glob.glob(os.path.join(GOLDEN_DIR, "module_*.npz")))
+    if dtype_tag:
+        files = [f for f in files if f.endswith(f"_{dtype_tag}.npz")]
+    return files
+
+
+def load_module_case(path, device="cpu"):
+    """-> (module built from the fixture's state dict, inputs dict, expected dict) as torch objects on `device`"""
+    import torch
+    from msda_triton_amd import MultiscaleDeformableAttention
+    z = np.load(path)
+    emb, hidden, L, H, P, B, Q, ref_dim, zeros, ac = (int(v) for v in z["meta"])
+    dt = torch.from_numpy(z["img"]).dtype
+    m = MultiscaleDeformableAttention(emb, hidden, L, H, P, "zeros" if zeros else "border", bool(ac)).to(dt)
+    m.load_state_dict({k[len("param__"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param__")})
+    m = m.to(device)
+    inputs = {k: torch.from_numpy(z[k]).to(device) for k in ("img", "shapes", "queries", "reference_points", "grad_out")}
+    expected = {k: torch.from_numpy(z[k]) for k in z.files
+                if k in ("out", "grad_img", "grad_queries", "grad_reference_points") or k.startswith("grad__")}
+    return m, inputs, expected
 
 
 def digest_cases():

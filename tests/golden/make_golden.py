@@ -33,6 +33,7 @@ import msda_triton.frontend as _ref_frontend  # noqa: E402
 
 assert _ref_frontend.__file__.startswith("/root/reference/"), _ref_frontend.__file__
 reference_native = _ref_frontend.native_multiscale_deformable_attention
+ReferenceModule = _ref_frontend.MultiscaleDeformableAttention
 
 from msda_triton_amd import synth  # noqa: E402
 
@@ -151,14 +152,71 @@ def write_digests():
         print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
 
 
+# name -> (emb, hidden, levels, heads, points, B, Q, ref_dim, padding_mode, align_corners)
+MODULE_CASES = {
+    "ref2_nonsquare_zeros": (12, 16, [(5, 3), (2, 4), (1, 2)], 2, 3, 2, 7, 2, "zeros", False),
+    "ref4_nonsquare_border": (12, 16, [(5, 3), (2, 4), (1, 2)], 2, 3, 2, 7, 4, "border", True),
+    "ref2_square_border_false": (16, 32, [(8, 8), (4, 4)], 4, 2, 1, 9, 2, "border", False),
+    "ref4_square_zeros_true": (16, 32, [(8, 8), (4, 4)], 4, 2, 1, 9, 4, "zeros", True),
+    "ref2_d32_vector_path": (16, 64, [(6, 7), (3, 4), (2, 2)], 2, 4, 1, 5, 2, "zeros", False),
+}
+MODULE_PARAMS = ("img_input_proj.weight", "img_input_proj.bias", "query_input_proj.weight", "query_input_proj.bias",
+                 "query_output_proj.weight", "query_output_proj.bias")
+
+
+def write_module_cases():
+    rng = np.random.default_rng(20250118)
+    for name, (emb, hidden, levels, H, P, B, Q, ref_dim, pm, ac) in MODULE_CASES.items():
+        L = len(levels)
+        I = sum(h * w for h, w in levels)  # noqa: E741
+        shapes = torch.tensor(levels, dtype=torch.int64)
+        # parameters and inputs are drawn here (float64), so the fixture does not depend on torch's init RNG
+        state64 = {
+            "img_input_proj.weight": rng.standard_normal((hidden, emb)) / np.sqrt(emb),
+            "img_input_proj.bias": 0.1 * rng.standard_normal(hidden),
+            "query_input_proj.weight": 0.5 * rng.standard_normal((H * L * P * 3, emb)) / np.sqrt(emb),
+            "query_input_proj.bias": 0.5 * rng.standard_normal(H * L * P * 3),
+            "query_output_proj.weight": rng.standard_normal((emb, hidden)) / np.sqrt(hidden),
+            "query_output_proj.bias": 0.1 * rng.standard_normal(emb),
+        }
+        img64 = rng.standard_normal((B, I, emb))
+        q64 = rng.standard_normal((B, Q, emb))
+        ref64 = rng.uniform(0.1, 0.9, size=(B, Q, ref_dim))
+        if ref_dim == 4:
+            ref64[..., 2:] = rng.uniform(0.05, 0.4, size=(B, Q, 2))  # box sizes
+        gout64 = rng.uniform(0.0, 1.0, size=(B, Q, emb))
+        for dt_name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            m = ReferenceModule(emb, hidden, L, H, P, pm, ac).to(dt)
+            m.load_state_dict({k: torch.from_numpy(v).to(dt) for k, v in state64.items()})
+            img = torch.from_numpy(img64).to(dt).requires_grad_(True)
+            q = torch.from_numpy(q64).to(dt).requires_grad_(True)
+            ref = torch.from_numpy(ref64).to(dt).requires_grad_(True)
+            gout = torch.from_numpy(gout64).to(dt)
+            out = m(img, shapes, q, ref)  # CPU tensors: the reference's native path (frontend.py:170-172)
+            out.backward(gout)
+            rec = {"shapes": shapes.numpy(), "img": img.detach().numpy(), "queries": q.detach().numpy(),
+                   "reference_points": ref.detach().numpy(), "grad_out": gout.numpy(), "out": out.detach().numpy(),
+                   "grad_img": img.grad.numpy(), "grad_queries": q.grad.numpy(), "grad_reference_points": ref.grad.numpy(),
+                   "meta": np.array([emb, hidden, L, H, P, B, Q, ref_dim, int(pm == "zeros"), int(ac)], dtype=np.int64)}
+            params = dict(m.named_parameters())
+            for k in MODULE_PARAMS:
+                rec["param__" + k] = params[k].detach().numpy()
+                rec["grad__" + k] = params[k].grad.numpy()
+            path = os.path.join(HERE, f"module_{name}_{dt_name}.npz")
+            np.savez_compressed(path, **rec)
+            print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    what = set(sys.argv[1:]) or {"small", "digests"}
+    what = set(sys.argv[1:]) or {"small", "digests", "module"}
     if "small" in what:
         write_small_cases()
     if "digests" in what:
         write_digests()
+    if "module" in what:
+        write_module_cases()
 
 
 if __name__ == "__main__":

@@ -221,3 +221,33 @@ def test_module_parameter_gradients_match_cpu_host_path_fp64(coords):
     for name in grads["cpu"]:
         torch.testing.assert_close(grads[DEV][name], grads["cpu"][name], atol=1e-9, rtol=1e-7,
                                    msg=lambda m_, n=name: f"{n}: {m_}")
+
+
+# ------------------------------------------------------------------------------------------
+# module path against the REFERENCE's nn.Module: committed fixtures (tests/golden/module_*.npz, written by
+# tests/golden/make_golden.py from /root/reference/src/msda_triton/frontend.py:175-292 in the build container)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", __import__("conftest").module_cases(), ids=__import__("conftest").case_id)
+def test_gpu_module_matches_reference_module_fixtures(path):
+    """The module on the GPU — fused prologue kernels inside (asserted) — DIRECTLY against the reference module's
+    outputs: out, the input gradients and all six parameter gradients.  fp64 fixtures at 1e-9, fp32 at fp32 round-off
+    (1e-4, the north-star bar, on out)."""
+    from conftest import load_module_case
+    from msda_triton_amd.functional import KernelTimer
+    m, x, want = load_module_case(path, DEV)
+    f64 = x["img"].dtype == torch.float64
+    tol = dict(atol=1e-9, rtol=1e-8) if f64 else dict(atol=1e-4, rtol=1e-3)
+    img, q, ref = (x[k].clone().requires_grad_(True) for k in ("img", "queries", "reference_points"))
+    with KernelTimer() as kt:
+        out = m(img, x["shapes"], q, ref)
+        out.backward(x["grad_out"])
+        torch.cuda.synchronize()
+    assert set(kt.summary()) == {"msda_fwd_fused", "msda_bwd_fused"}, kt.summary()
+    torch.testing.assert_close(out.detach().cpu(), want["out"], **tol)
+    torch.testing.assert_close(img.grad.cpu(), want["grad_img"], **tol)
+    torch.testing.assert_close(q.grad.cpu(), want["grad_queries"], **tol)
+    torch.testing.assert_close(ref.grad.cpu(), want["grad_reference_points"], **tol)
+    got = dict(m.named_parameters())
+    assert len(got) == 6
+    for name, prm in got.items():
+        torch.testing.assert_close(prm.grad.cpu(), want["grad__" + name], msg=lambda s, n=name: f"{n}: {s}", **tol)

@@ -244,3 +244,24 @@ def test_module_value_dtype_is_validated_and_ignored_on_host_tensors():
     shapes = torch.tensor([[4, 3], [2, 2]])
     img, q, ref = torch.randn(1, 16, 16), torch.randn(1, 5, 16), torch.rand(1, 5, 2)
     torch.testing.assert_close(a(img, shapes, q, ref), b(img, shapes, q, ref))
+
+
+# ---------------------------------------------------------------- module fixtures ----------------
+@pytest.mark.parametrize("path", __import__("conftest").module_cases(), ids=__import__("conftest").case_id)
+def test_host_module_matches_reference_module_fixtures(path):
+    """The nn.Module on host tensors against the REFERENCE's MultiscaleDeformableAttention (frontend.py:175-292)
+    run in the build container (tests/golden/make_golden.py): same state dict, same inputs -> out, the input
+    gradients and all six parameter gradients.  2-d and 4-d reference points, non-square levels, both padding modes."""
+    from conftest import load_module_case
+    m, x, want = load_module_case(path)
+    f64 = x["img"].dtype == torch.float64
+    tol = dict(atol=1e-11, rtol=1e-9) if f64 else dict(atol=2e-5, rtol=1e-4)
+    img, q, ref = (x[k].clone().requires_grad_(True) for k in ("img", "queries", "reference_points"))
+    out = m(img, x["shapes"], q, ref)
+    out.backward(x["grad_out"])
+    torch.testing.assert_close(out.detach(), want["out"], **tol)
+    torch.testing.assert_close(img.grad, want["grad_img"], **tol)
+    torch.testing.assert_close(q.grad, want["grad_queries"], **tol)
+    torch.testing.assert_close(ref.grad, want["grad_reference_points"], **tol)
+    for name, prm in m.named_parameters():
+        torch.testing.assert_close(prm.grad, want["grad__" + name], msg=lambda s, n=name: f"{n}: {s}", **tol)
