@@ -1,0 +1,117 @@
+"""Model-level parity with Hugging Face transformers (the reference README's demo, README.md:25-37: a detection model
+gives the same results with either implementation): a tiny random-init DeformableDetrModel built from a config (no
+download), every MultiScaleDeformableAttention swapped by replace_hf_msda, outputs and parameter gradients against
+transformers' own pure-PyTorch path."""
+import pytest
+import torch
+
+transformers = pytest.importorskip("transformers")
+
+
+def tiny_deformable_detr(seed=0):
+    from transformers import DeformableDetrConfig, DeformableDetrModel, ResNetConfig
+    bb = ResNetConfig(num_channels=3, embedding_size=16, hidden_sizes=[16, 32, 64, 128], depths=[1, 1, 1, 1],
+                      layer_type="basic", out_features=["stage2", "stage3", "stage4"])
+    cfg = DeformableDetrConfig(use_timm_backbone=False, use_pretrained_backbone=False, backbone_config=bb, backbone=None,
+                               d_model=64, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                               decoder_attention_heads=4, encoder_ffn_dim=128, decoder_ffn_dim=128, num_queries=30,
+                               num_feature_levels=4, encoder_n_points=4, decoder_n_points=4, dropout=0.0,
+                               attention_dropout=0.0, activation_dropout=0.0)
+    torch.manual_seed(seed)
+    model = DeformableDetrModel(cfg)
+    with torch.no_grad():  # HF zero-initialises the sampling offsets' weights: make the sampling pattern data-dependent
+        for name, prm in model.named_parameters():
+            if name.endswith("sampling_offsets.weight"):
+                prm.normal_(0, 0.05)
+    return model.train()  # (dropout is 0: train mode only so that every parameter takes part in backward)
+
+
+WATCHED = ("encoder.layers.0.self_attn.value_proj.weight", "encoder.layers.1.self_attn.sampling_offsets.weight",
+           "encoder.layers.0.self_attn.attention_weights.bias", "decoder.layers.1.encoder_attn.value_proj.weight",
+           "decoder.layers.0.encoder_attn.sampling_offsets.weight", "decoder.layers.1.encoder_attn.output_proj.weight",
+           "input_proj.0.0.weight")
+
+
+def run_model(model, x, mask, autocast_dtype=None):
+    model.zero_grad(set_to_none=True)
+    ctx = torch.autocast(x.device.type, dtype=autocast_dtype) if autocast_dtype is not None else torch.autocast(x.device.type, enabled=False)
+    with ctx:
+        out = model(pixel_values=x, pixel_mask=mask)
+    hs = out.last_hidden_state
+    # a fixed random linear functional of the decoder states (NOT mean(hs^2): behind the final LayerNorm that is
+    # nearly constant, its gradient is pure cancellation noise in fp32)
+    w = torch.randn(hs.shape, generator=torch.Generator().manual_seed(11)).to(hs.device)
+    (hs.float() * w).sum().backward()
+    named = dict(model.named_parameters())
+    return hs.detach().float(), out.encoder_last_hidden_state.detach().float(), {k: named[k].grad.detach().float().clone() for k in WATCHED}
+
+
+def _inputs(device):
+    torch.manual_seed(3)
+    x = torch.randn(2, 3, 96, 128, device=device)
+    mask = torch.ones(2, 96, 128, dtype=torch.long, device=device)
+    mask[1, :, 100:] = 0  # one padded image: the valid-ratio / padding-mask logic feeds the reference points
+    return x, mask
+
+
+def test_tiny_deformable_detr_matches_hf_on_cpu():
+    from msda_triton_amd.hf_adapter import replace_hf_msda
+    model = tiny_deformable_detr()
+    x, mask = _inputs("cpu")
+    hs0, enc0, g0 = run_model(model, x, mask)
+    assert replace_hf_msda(model) == 4  # 2 encoder self-attentions + 2 decoder cross-attentions
+    hs1, enc1, g1 = run_model(model, x, mask)
+    torch.testing.assert_close(enc1, enc0, atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(hs1, hs0, atol=1e-5, rtol=1e-4)
+    for k in WATCHED:  # relative L2 error per gradient tensor (fp32 round-off of two summation orders)
+        err = float((g1[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30))
+        assert err < 1e-4, (k, err)
+
+
+@pytest.mark.gpu
+def test_tiny_deformable_detr_matches_hf_on_gpu_fp32():
+    """fp32: the whole model's outputs (encoder memory, decoder states) and a spread of parameter gradients — value
+    projections (grad_value path), sampling offsets (grad_loc path), attention weights (grad_attn path), the input
+    projection below the first encoder layer — against transformers' own grid_sample implementation on the same GPU."""
+    from msda_triton_amd.functional import KernelTimer
+    from msda_triton_amd.hf_adapter import replace_hf_msda
+    dev = "cuda:0"
+    model = tiny_deformable_detr().to(dev)
+    x, mask = _inputs(dev)
+    hs0, enc0, g0 = run_model(model, x, mask)
+    assert replace_hf_msda(model) == 4
+    with KernelTimer() as kt:
+        hs1, enc1, g1 = run_model(model, x, mask)
+        torch.cuda.synchronize()
+    s = kt.summary()
+    assert s["msda_fwd"][0] == 4 and s["msda_bwd_sample"][0] == 4 and s["msda_bwd_value"][0] == 4, s  # the HIP kernels ran
+    torch.testing.assert_close(enc1, enc0, atol=1e-4, rtol=1e-3)
+    torch.testing.assert_close(hs1, hs0, atol=1e-4, rtol=1e-3)
+    for k in WATCHED:  # relative L2 error per gradient tensor (fp32 round-off of two different summation orders)
+        err = float((g1[k] - g0[k]).norm() / g0[k].norm().clamp_min(1e-30))
+        assert err < 2e-3, (k, err)
+
+
+@pytest.mark.gpu
+def test_tiny_deformable_detr_matches_hf_on_gpu_bf16_autocast():
+    """Under bf16 autocast both implementations carry bf16 round-off; they agree to bf16 accuracy (relative L2 error of
+    the decoder states and of every watched gradient), and the adapter keeps the value pyramid in 16 bits (mixed-storage
+    kernels)."""
+    from msda_triton_amd.hf_adapter import replace_hf_msda
+    dev = "cuda:0"
+    model = tiny_deformable_detr().to(dev)
+    x, mask = _inputs(dev)
+    hs0, enc0, g0 = run_model(model, x, mask, torch.bfloat16)
+    hs_fp32, _, _ = run_model(model, x, mask)  # the yardstick: how far bf16 autocast itself is from fp32
+    assert replace_hf_msda(model) == 4
+    hs1, enc1, g1 = run_model(model, x, mask, torch.bfloat16)
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+    noise = rel(hs0, hs_fp32)
+    assert rel(hs1, hs0) < max(3 * noise, 3e-2), (rel(hs1, hs0), noise)
+    assert rel(enc1, enc0) < 3e-2
+    for k in WATCHED:
+        assert torch.isfinite(g1[k]).all()
+        assert rel(g1[k], g0[k]) < 0.15, (k, rel(g1[k], g0[k]))
