@@ -6,7 +6,6 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
-#include <mutex>
 
 #include "../../include/msda_hip.h"
 
@@ -22,21 +21,23 @@ static std::atomic<int> g_q_round{0};
 static std::atomic<int> g_overlap{-1};
 static std::atomic<int> g_gather_win{0};
 
-// one side stream + two events per device, created on first use and kept for the life of the process
+// One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
+// Per THREAD, because the fork (record on the user's stream, wait on the side stream) and the join are two calls
+// each: with a stream / event pair shared by all callers, two threads issuing backwards on one device (autograd's
+// worker threads, different user streams) could interleave record(A) record(B) wait(.) and make the sample kernel wait
+// for the wrong work.  Inside one thread everything is in program order, whatever streams the caller alternates.
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     bool tried = false;
 };
-static SideStream g_side[64];
-static std::mutex g_side_mutex;
+static thread_local SideStream t_side[64];
 
 static SideStream *side_for_current_device()
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    SideStream &s = g_side[dev];
-    std::lock_guard<std::mutex> lock(g_side_mutex);
+    SideStream &s = t_side[dev];
     if (!s.tried) {
         s.tried = true;
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||

@@ -13,7 +13,12 @@ extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_byte
     const size_t acc = elem_size == 8 ? 8 : 4;
     if (msda::option_value_path() == 4) return (int64_t)msda::binned_ws_layout(B, I, H, D, Q, L, P, acc, true).total;
     if (small) return 0;
-    return (int64_t)msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size).total;
+    // the larger of the 16-byte-vector and the scalar layout: which one a call takes depends on the alignment of its
+    // grad_out / grad_value pointers (a slice of a shard's buffers can be misaligned), and a workspace that is too
+    // small would silently drop grad_value to the LDS-tile kernel
+    const size_t vec = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, true).total;
+    const size_t sca = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, false).total;
+    return (int64_t)(vec > sca ? vec : sca);
 }
 
 // largest L*P the fused-prologue kernels (msda_fwd_fused / msda_bwd_fused) take for this head dimension and

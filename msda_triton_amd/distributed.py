@@ -175,10 +175,21 @@ _OWNER_GROUPS: dict = {}
 
 
 def _owner_groups(B: int, Q: int, group):
-    """For every batch element touched by more than one rank: (ranks, process group).  Every rank of
-    ``group`` must call this with the same (B, Q) (new_group is collective); results are cached."""
+    """For every batch element touched by more than one rank: (ranks, process group).
+
+    ``dist.new_group`` is collective over the DEFAULT process group: every rank of the job has to enter it, in the
+    same order.  So the sub-groups are only made when ``group`` is the default group (every rank of the job runs the
+    operator); for a caller-supplied sub-group the function returns None and the caller falls back to an all-reduce on
+    ``group`` (ranks outside it never call the operator, so they could not take part in the group creation).
+    The cache is keyed on the default group's identity, so groups made before a ``destroy_process_group`` /
+    ``init_process_group`` cycle are never handed out again."""
+    default = dist.group.WORLD
+    if group is not None and group is not default:
+        return None
     world = dist.get_world_size(group)
-    key = (id(group), B, Q, world)
+    key = (id(default), B, Q, world)
+    for stale in [k for k in _OWNER_GROUPS if k[0] != id(default)]:
+        del _OWNER_GROUPS[stale]
     if key in _OWNER_GROUPS:
         return _OWNER_GROUPS[key]
     rows = B * Q
@@ -411,6 +422,8 @@ def row_sharded_multiscale_deformable_attention(
         pts_rows = sampling_points.reshape(rows, *sampling_points.shape[2:])[r0:r1]
         att_rows = attention_weights.reshape(rows, *attention_weights.shape[2:])[r0:r1]
     owners = _owner_groups(B, Q, group) if (grad_value_sync == "owners" and img.requires_grad) else None
+    if grad_value_sync == "owners" and img.requires_grad and owners is None:
+        grad_value_sync = "all_reduce"  # a caller-supplied sub-group: see _owner_groups
     if overlap_chunks is None:  # exchange piece by piece only when a piece is worth a message (>= ~2k rows); the
         # count must be the same on every rank, so it follows the nominal shard size, not this rank's
         overlap_chunks = max(1, min(4, -(-rows // world) // 2048)) if world > 1 else 1

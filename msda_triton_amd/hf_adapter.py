@@ -16,7 +16,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from .functional import multiscale_deformable_attention
+from .functional import _autocast_on, multiscale_deformable_attention
 
 
 class MultiScaleDeformableAttention(nn.Module):
@@ -38,7 +38,7 @@ class MultiScaleDeformableAttention(nn.Module):
             # sampling locations / softmaxed weights.  The mixed-storage kernels read the pyramid as it is and keep
             # the coordinates in fp32 (casting them to 16 bits would cost a quarter pixel on a 64-px level; casting
             # everything to fp32, which autocast's policy for the plain operator does, copies the pyramid).
-            autocast = torch.is_autocast_enabled("cuda")
+            autocast = _autocast_on()
             with torch.autocast("cuda", enabled=False):
                 out = multiscale_deformable_attention(value, shapes, sampling_locations, attention_weights, "zeros", False)
             return (out if autocast else out.to(dtype)).flatten(2)

@@ -512,6 +512,79 @@ def test_graph_capture_replays():
     assert torch.equal(grads[1], eager_g[1]) and torch.equal(grads[2], eager_g[2])
 
 
+def test_graph_capture_replays_at_c4_size_with_the_side_stream_fork():
+    """Grounding-DINO decoder size (c4: 921 600 samples): the backward forks the sample-gradient kernel onto the side
+    stream next to the single-launch grad_value kernel (overlap on by default from 800k samples).  The fork / join is
+    event-based, so the pair still captures into one hipGraph; replays give the eager results."""
+    from msda_triton_amd import _lib, synth
+    ops = _ops()
+    assert _lib.get_option("overlap") == -1  # automatic: on at this size
+    wl = synth.WORKLOADS["c4_gdino_dec"]
+    d = synth.make_inputs_torch(wl, DEV, seed=3)
+    v, l, a, g, s = d["value"], d["loc"], d["attn"], d["grad_out"], d["shapes"]
+    eager = ops.msda_hip_fwd(v, s, l, a, wl.padding_mode, wl.align_corners)
+    eager_g = ops.msda_hip_bwd(g, v, s, l, a, wl.padding_mode, wl.align_corners)  # (also creates this thread's side stream)
+    torch.cuda.synchronize()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        ops.msda_hip_bwd(g, v, s, l, a, wl.padding_mode, wl.align_corners)  # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(cap)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = ops.msda_hip_fwd(v, s, l, a, wl.padding_mode, wl.align_corners)
+        grads = ops.msda_hip_bwd(g, v, s, l, a, wl.padding_mode, wl.align_corners)
+    for _ in range(3):
+        out.zero_()
+        for t in grads:
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager)
+        torch.testing.assert_close(grads[0], eager_g[0], atol=1e-4, rtol=1e-4)
+        assert torch.equal(grads[1], eager_g[1]) and torch.equal(grads[2], eager_g[2])
+
+
+def test_two_host_threads_run_backwards_on_one_device():
+    """Autograd worker threads / user threads with their own streams: each host thread has its own side stream and
+    event pair (msda_api.hip), so concurrent backwards cannot wait on each other's fork records.  Two threads, each on
+    its own stream, c4-sized problems (fork/join on) with different data: both get their own eager results."""
+    import threading
+    from msda_triton_amd import synth
+    ops = _ops()
+    wl = synth.WORKLOADS["c4_gdino_dec"]
+    data = [synth.make_inputs_torch(wl, DEV, seed=20 + i) for i in range(2)]
+    want = [ops.msda_hip_bwd(d["grad_out"], d["value"], d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
+            for d in data]
+    torch.cuda.synchronize()
+    got, errs = [None, None], []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            d = data[i]
+            with torch.cuda.stream(st):
+                for _ in range(20):
+                    # the producer of grad_out runs on this thread's stream right before the backward: a missed
+                    # fork dependency would read a stale / half-written buffer
+                    go = d["grad_out"] * 1.0
+                    res = ops.msda_hip_bwd(go, d["value"], d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
+                st.synchronize()
+            got[i] = res
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        torch.testing.assert_close(got[i][0], want[i][0], atol=1e-4, rtol=1e-4)
+        assert torch.equal(got[i][1], want[i][1]) and torch.equal(got[i][2], want[i][2])
+
+
 # ------------------------------------------------------------------------------------------
 # backward grad_value: both implementations, and the shapes that stress the sorted gather
 # ------------------------------------------------------------------------------------------

@@ -189,7 +189,9 @@ def test_backward_workspace_sizes_stay_within_budget():
         return int(lib.msda_bwd_workspace_bytes(wl.B, wl.I, wl.H, wl.D, wl.Q, wl.L, wl.P, wl.elem_size))
 
     assert ws("c2_q10k") <= 200 * 2**20          # entries 82 MB + partial rows 89 MB + cell tables
-    assert ws("c5_stress") <= 2 * 2**30           # two rounds over the queries: records 1.02 GB + partial rows 0.72 GB + running sums
+    # two rounds over the queries: records 1.02 GB + partial rows 0.72 GB + running sums; sized for the scalar
+    # (misaligned-pointer) layout too, whose continuation rows add ~70 MB here
+    assert ws("c5_stress") <= int(2.1 * 2**30)
     assert ws("c1_readme") == 0 and ws("c4_gdino_dec") == 0 and ws("c2_q1k") == 0
     wl = synth.WORKLOADS["c2_q10k"]
     assert ws("c2_q10k") >= wl.B * wl.H * wl.Q * wl.L * wl.P * 16  # at least the sorted records
