@@ -126,7 +126,7 @@ extern "C" int msda_set_option(const char *key, int value)
         return 0;
     }
     if (key && strcmp(key, "value_path") == 0) {
-        msda::g_value_path.store(value < 0 || value > 4 ? 0 : value, std::memory_order_relaxed);
+        msda::g_value_path.store(value < 0 || value > 3 ? 0 : value, std::memory_order_relaxed);
         return 0;
     }
     if (key && strcmp(key, "debug") == 0) {

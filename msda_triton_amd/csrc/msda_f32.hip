@@ -11,7 +11,6 @@ extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_byte
     const msda::Dims d{B, I, H, D, Q, L, P};
     const bool small = elem_size == 8 ? msda::small_path_chosen<double>(d) : msda::small_path_chosen<float>(d);
     const size_t acc = elem_size == 8 ? 8 : 4;
-    if (msda::option_value_path() == 4) return (int64_t)msda::binned_ws_layout(B, I, H, D, Q, L, P, acc, true).total;
     if (small) return 0;
     // the larger of the 16-byte-vector and the scalar layout: which one a call takes depends on the alignment of its
     // grad_out / grad_value pointers (a slice of a shard's buffers can be misaligned), and a workspace that is too

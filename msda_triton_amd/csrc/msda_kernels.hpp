@@ -70,16 +70,6 @@ struct Params {
     void *ws_accum;     // [pairs][I][D] acc-typed running sums between rounds (nullptr: a single round)
     int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
     int small_ns;       // ... workgroups per (plane, level)
-    // tile-binned grad_value path (msda_value_binned.hpp); ws_entries / ent_cap / nsplit / q_begin.. are shared with the above
-    int *ws_toff;       // [pairs][nsplit][nbin_cap + 1]  first record of every bin inside the slice's record range (+ end)
-    void *ws_ptile;     // [pairs][part_cap][D] acc-typed partial rows of the levels whose tiles are split over slice groups
-    int nbin_cap, part_cap;
-    int bin_lds_cap;    // bins a K1 workgroup keeps in LDS at a time
-    int bin_cached;     // K1: a thread's samples of the slice fit its registers (read once)
-    unsigned long long *dbg_out;  // dev-only phase clock of the tile kernel (debug bit 256): [workgroup][8]
-    int tile_slots;     // workgroup slots of the tile kernel per plane and channel chunk
-    int ncc;            // channel chunks (D / (G * VEC), rounded up)
-    int reduce_chunks;  // 64-pixel chunks per level the reduce kernel provides workgroups for
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char msda_smem[];

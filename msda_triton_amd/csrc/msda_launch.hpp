@@ -7,7 +7,6 @@
 #include <atomic>
 
 #include "msda_value_sorted.hpp"
-#include "msda_value_binned.hpp"
 #include "msda_value_small.hpp"
 #include "msda_value_tile.hpp"
 
@@ -349,101 +348,6 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
     return 0;
 }
 
-// ---- tile-binned grad_value: K1..K3 of msda_value_binned.hpp ----
-template <typename T, int VEC, int G, typename TV = T>
-inline int launch_value_binned(Params &p, const BinnedWsLayout &w, hipStream_t stream)
-{
-    const int npairs = p.B * p.H;
-    p.ncc = (p.D + G * VEC - 1) / (G * VEC);
-    dim3 g1, g2, g3;
-    if (!plane_grid(p, npairs, p.nsplit, g1)) {
-        set_error("grid too large");
-        return MSDA_ERR_TOO_LARGE;
-    }
-    const int grid3d_1 = p.grid3d;
-    const size_t bin_lds = sizeof(LevelTab) + sizeof(TileTab) + (size_t)p.bin_lds_cap * sizeof(int);
-    static std::atomic<uint64_t> big_lds_bin{0};
-    allow_big_lds(msda_bin_pass_kernel<T, TV>, big_lds_bin);
-    for (int r = 0; r < w.rounds; ++r) {
-        p.q_begin = r * w.q_round;
-        p.q_end = p.q_begin + w.q_round < p.Q ? p.q_begin + w.q_round : p.Q;
-        p.finish_mode = w.rounds == 1 ? 0 : r == 0 ? 1 : r == w.rounds - 1 ? 3 : 2;
-        p.grid3d = grid3d_1;
-        hipLaunchKernelGGL((msda_bin_pass_kernel<T, TV>), g1, dim3(kBinBlock), bin_lds, stream, p);
-        // persistent tile workgroups, a multiple of 8 (workgroup -> XCD by blockIdx & 7)
-        {
-            const int64_t target = option_wg_target() < (1 << 30) ? option_wg_target() : 512;
-            const int per_xcd = (int)((target + 7) / 8);
-            g2 = dim3((unsigned)(8 * (per_xcd < 1 ? 1 : per_xcd)));
-        }
-        bool stamped = false;
-        if constexpr (sizeof(T) == 4 && sizeof(TV) == 4 && VEC == 4) {  // dev-only phase clock: one instantiation
-            if ((p.debug & 256) && p.dbg_out != nullptr) {
-                hipLaunchKernelGGL((msda_tile_gather_kernel<T, VEC, G, TV, true>), g2, dim3(kGatherBlock), 0, stream, p);
-                stamped = true;
-            }
-        }
-        if (!stamped) hipLaunchKernelGGL((msda_tile_gather_kernel<T, VEC, G, TV>), g2, dim3(kGatherBlock), 0, stream, p);
-        {   // a split level has fewer than (round's queries) * P * 64 / kSplitRecords pixels
-            const int64_t qp = (int64_t)(p.q_end - p.q_begin) * p.P;
-            int64_t px = qp * (kTile * kTile) / kSplitRecords + 1;
-            if (px > p.I) px = p.I;
-            p.reduce_chunks = (int)((px + 63) / 64);
-        }
-        if (!plane_grid(p, npairs, (int64_t)p.L * p.reduce_chunks, g3)) {
-            set_error("grid too large");
-            return MSDA_ERR_TOO_LARGE;
-        }
-        hipLaunchKernelGGL((msda_tile_reduce_kernel<T, VEC, G, TV>), g3, dim3(kTileBlock), 0, stream, p);
-        const int rc = (int)hipGetLastError();
-        if (rc) return rc;
-    }
-    return 0;
-}
-
-// G = 8 lanes per row piece always (64 lane groups = the 64 interior cells of a tile); VEC = the widest piece (<= 16
-// bytes) that still gives all 8 lanes channels to work on
-template <typename T, int VEC, typename TV = T>
-inline int dispatch_value_binned_vec(Params &p, const BinnedWsLayout &w, hipStream_t stream)
-{
-    if constexpr (VEC > 1) {
-        if (8 * (VEC / 2) >= p.D) return dispatch_value_binned_vec<T, VEC / 2, TV>(p, w, stream);
-    }
-    return launch_value_binned<T, VEC, 8, TV>(p, w, stream);
-}
-
-inline bool binned_fits(const Dims &d) { return d.Q < ((int64_t)1 << 24) && d.I < ((int64_t)1 << 24); }
-
-template <typename T, typename TV = T> inline int run_value_binned(Params &p, const Dims &d, void *workspace, hipStream_t stream)
-{
-    using A = typename Traits<T>::acc;
-    const BinnedWsLayout w = binned_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), true);
-    unsigned char *ws = static_cast<unsigned char *>(workspace);
-    p.ws_toff = reinterpret_cast<int *>(ws + w.off_toff);
-    p.ws_entries = ws + w.off_entries;
-    p.ws_ptile = ws + w.off_part;
-    p.ws_accum = w.rounds > 1 ? ws + w.off_accum : nullptr;
-    p.dbg_out = reinterpret_cast<unsigned long long *>(ws + w.off_dbg);
-    p.nbin_cap = w.nbin_cap;
-    p.part_cap = w.part_cap;
-    p.nsplit = w.nsplit;
-    p.tile_slots = w.tile_slots;
-    p.ent_cap = (int)((int64_t)w.nsplit * ((w.q_round + w.nsplit - 1) / w.nsplit) * d.L * d.P);
-    {
-        const long long room = ((long long)kMaxDynLds - (long long)sizeof(LevelTab) - (long long)sizeof(TileTab)) / 4;
-        const long long cap = room < kBinLdsInts ? room : kBinLdsInts;
-        p.bin_lds_cap = w.nbin_cap < cap ? (w.nbin_cap > 1 ? w.nbin_cap : 1) : (int)cap;
-    }
-    {
-        const int64_t qper = (w.q_round + w.nsplit - 1) / w.nsplit;
-        const int64_t dq = p.LP <= kBinBlock ? kBinBlock / p.LP : 0;
-        p.bin_cached = dq > 0 && (qper + dq - 1) / dq <= (sizeof(A) == 8 ? 8 : 16) && !(p.debug & 1);
-    }
-    constexpr int VECF = 16 / sizeof(T);
-    return value_vec_ok<T>(p) ? dispatch_value_binned_vec<T, VECF, TV>(p, w, stream)
-                              : launch_value_binned<T, 1, 8, TV>(p, w, stream);
-}
-
 inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_corners)
 {
     p.B = (int)d.B;
@@ -627,14 +531,11 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
     const bool sorted = sorted_fits<T>(d) && option_value_path() != 1 && workspace != nullptr && aligned_to(workspace, 256) &&
                         (uint64_t)workspace_bytes >=
                             sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p)).total;
-    const bool binned = option_value_path() == 4 && binned_fits(d) && workspace != nullptr && aligned_to(workspace, 256) &&
-                        (uint64_t)workspace_bytes >= binned_ws_layout(B, I, H, D, Q, L, P, sizeof(A), true).total;
-    const bool small_path = !binned && (small_path_chosen<T>(d) || (option_value_path() == 0 && !sorted && small_fits<T>(d)));
+    const bool small_path = small_path_chosen<T>(d) || (option_value_path() == 0 && !sorted && small_fits<T>(d));
     // (no workspace: the single-launch kernel is still better than the LDS-tile kernel whenever it fits)
-    const int rc = binned       ? run_value_binned<T, TV>(p, d, workspace, stream)
-                   : small_path ? run_value_small<T, TV>(p, d, stream)
-                   : sorted     ? run_value_sorted<T, TV>(p, d, workspace, stream)
-                                : dispatch_value<T, TV>(p, stream);
+    const int rc = small_path ? run_value_small<T, TV>(p, d, stream)
+                   : sorted   ? run_value_sorted<T, TV>(p, d, workspace, stream)
+                              : dispatch_value<T, TV>(p, stream);
     if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

@@ -588,7 +588,7 @@ def test_two_host_threads_run_backwards_on_one_device():
 # ------------------------------------------------------------------------------------------
 # backward grad_value: both implementations, and the shapes that stress the sorted gather
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("value_path", [4, 2, 1, 3], ids=["binned", "sorted_gather", "lds_tiles", "single_launch"])
+@pytest.mark.parametrize("value_path", [2, 1, 3], ids=["sorted_gather", "lds_tiles", "single_launch"])
 @pytest.mark.parametrize("pm,ac", MODES, ids=[mode_key(*m) for m in MODES])
 def test_grad_value_both_paths_and_hot_pixels(oracle, value_path, pm, ac):
     """Every query samples the same few pixels (lists far longer than one work-item chunk, so pixels are
@@ -608,7 +608,7 @@ def test_grad_value_both_paths_and_hot_pixels(oracle, value_path, pm, ac):
 @pytest.mark.parametrize("D,Q,td", [(32, 3000, torch.float32), (512, 700, torch.float32), (32, 3000, torch.float64),
                                     (32, 3000, torch.bfloat16)],
                          ids=["f32_d32", "f32_d512_two_channel_chunks", "f64_d32", "bf16_d32"])
-@pytest.mark.parametrize("value_path", [4, 2, 3], ids=["binned", "sorted_gather", "single_launch"])
+@pytest.mark.parametrize("value_path", [2, 3], ids=["sorted_gather", "single_launch"])
 def test_grad_value_cell_flood_spans_gather_workgroups(oracle, D, Q, td, value_path):
     """A 1x1 level: every sample falls into one of four cells, so a cell's list is cut into far more work items
     than one gather workgroup holds — items are merged inside workgroups, the finish kernel adds one row per
@@ -819,7 +819,7 @@ def test_fused_backward_partial_needs_and_large_lp_fallback():
     assert torch.isfinite(pr.grad).all()
 
 
-@pytest.mark.parametrize("value_path", [4, 2, 1, 3], ids=["binned", "sorted_gather", "lds_tiles", "single_launch"])
+@pytest.mark.parametrize("value_path", [2, 1, 3], ids=["sorted_gather", "lds_tiles", "single_launch"])
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_random_shapes_against_oracle(oracle, seed, value_path):
     """Differential test over random shapes / modes / coordinate ranges (fixed seeds), with the sorted-gather
@@ -843,9 +843,8 @@ def test_random_shapes_against_oracle(oracle, seed, value_path):
         _lib.set_option("value_path", 0)
 
 
-@pytest.mark.parametrize("value_path", [4, 2], ids=["binned", "sorted_gather"])
 @pytest.mark.parametrize("td", [torch.float32, torch.float64, torch.bfloat16], ids=["f32", "f64", "bf16"])
-def test_sorted_grad_value_in_query_rounds(oracle, td, value_path):
+def test_sorted_grad_value_in_query_rounds(oracle, td):
     """Very large Q is served in rounds over the queries (a plane's grad_out rows stay in L2; running sums in the
     accumulate type between rounds).  Forced here with tiny rounds: first / middle / last round paths, ragged last
     round, every storage class of the running sums."""
@@ -857,7 +856,7 @@ def test_sorted_grad_value_in_query_rounds(oracle, td, value_path):
         for k in ("value", "loc", "attn", "grad_out"):
             c[k] = torch.from_numpy(c[k]).to(td).float().numpy()
     try:
-        _lib.set_option("value_path", value_path)
+        _lib.set_option("value_path", 2)
         for q_round in (7, 20, 52):
             _lib.set_option("q_round", q_round)
             for pm, ac in (("zeros", False), ("border", True)):

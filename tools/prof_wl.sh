@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev tool: per-kernel times of a workload under option strings ("k=v,k=v"):  WORKLOAD=c3_ddetr_enc bash tools/prof_wl.sh value_path=0 value_path=4
+# dev tool: per-kernel times of a workload under option strings ("k=v,k=v"):  WORKLOAD=c3_ddetr_enc bash tools/prof_wl.sh value_path=0 value_path=2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 W=${WORKLOAD:-c2_q10k}
 STEPS=${STEPS:-6}
