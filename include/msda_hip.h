@@ -55,8 +55,9 @@
  * records sorted by bilinear cell), which lives in caller-provided device memory so that the
  * library never allocates: pass `workspace` (256-byte aligned) of at least
  * msda_bwd_workspace_bytes(...) bytes; its contents are scratch and need no initialisation.
- * With workspace == NULL (or too small) grad_value falls back to an LDS-tile kernel that needs no
- * workspace but is slower and scales worse with pyramid size.
+ * msda_bwd_workspace_bytes(...) is 0 for small problems (Grounding-DINO / Deformable-DETR decoder shapes): they take a
+ * single-launch kernel that keeps its inverted index in LDS.  A larger problem without (enough) workspace is rejected
+ * with MSDA_ERR_BAD_ARG when grad_value is wanted (grad_loc / grad_attn never need workspace).
  * Calls are asynchronous on `stream`; there is no host synchronisation and no allocation
  * inside, so a call sequence can be captured into a hipGraph.
  *
@@ -73,7 +74,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 6
+#define MSDA_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define MSDA_API __attribute__((visibility("default")))
@@ -150,14 +151,18 @@ MSDA_API const char *msda_last_error(void);
  *   "xcd_map"    1 (default): blockIdx -> (batch, head) mapping keeps each (b,h) plane on one XCD's L2
  *                0: plain linear mapping
  *   "value_path" 0 (default): grad_value by the single-launch LDS kernel when a (plane, level) fits one workgroup
- *                   (small problems; no workspace needed), else by the sorted gather when a workspace is supplied,
- *                   else by the LDS-tile kernel
- *                1: always the LDS-tile kernel   2: the sorted gather (if a workspace is supplied)
- *                3: the single-launch kernel whenever it fits
+ *                   (small problems; no workspace needed), else by the sorted gather in the caller's workspace
+ *                2: the sorted gather always   3: the single-launch kernel whenever it fits
  *   "overlap"    -1 (default): grad_loc/grad_attn run on a forked side stream next to grad_value where that was
  *                   measured to pay (next to the single-launch kernel from ~800k samples; next to the sorted pipeline
  *                   from 4M samples when rows have >= 128 bytes): the fork/join itself costs ~14 us of host time and
  *                   ~19 us of latency;  0: never;  1: always
+ *   "deterministic" 0 (default): grad_value may differ in the last bit from run to run (the order of the records inside
+ *                   a cell's list follows the order in which LDS atomics retire; the reference's global atomics have
+ *                   the same property); out, grad_loc and grad_attn are always bitwise reproducible
+ *                1: bitwise reproducible grad_value: the place pass runs one wave per query slice and ranks the samples
+ *                   of a cell by index (no atomics at all); small problems take the sorted pipeline too (workspace
+ *                   needed); slower
  *   "cell_slices", "small_ns", "gather_win", "wg_target", "debug": experiment knobs, see
  *                msda_triton_amd/csrc/msda_launch.hpp and msda_value_sorted.hpp
  */

@@ -15,7 +15,7 @@ LIB_NAME = "libmsda_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PADDING_MODES = {"border": 0, "zeros": 1}
 # one storage type for every tensor, then the mixed ones: value / grad_value in 16 bits, everything else fp32
 DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64", "f32_vbf16", "f32_vf16")

@@ -20,6 +20,7 @@ static std::atomic<int> g_small_ns{0};
 static std::atomic<int> g_q_round{0};
 static std::atomic<int> g_overlap{-1};
 static std::atomic<int> g_gather_win{0};
+static std::atomic<int> g_deterministic{0};
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
 // Per THREAD, because the fork (record on the user's stream, wait on the side stream) and the join are two calls
@@ -80,6 +81,7 @@ int option_small_ns() { return g_small_ns.load(std::memory_order_relaxed); }
 int option_q_round() { return g_q_round.load(std::memory_order_relaxed); }
 int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
 int option_gather_win() { return g_gather_win.load(std::memory_order_relaxed); }
+int option_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
 
 void set_error(const char *fmt, ...)
 {
@@ -126,7 +128,7 @@ extern "C" int msda_set_option(const char *key, int value)
         return 0;
     }
     if (key && strcmp(key, "value_path") == 0) {
-        msda::g_value_path.store(value < 0 || value > 3 ? 0 : value, std::memory_order_relaxed);
+        msda::g_value_path.store(value == 2 || value == 3 ? value : 0, std::memory_order_relaxed);
         return 0;
     }
     if (key && strcmp(key, "debug") == 0) {
@@ -147,6 +149,10 @@ extern "C" int msda_set_option(const char *key, int value)
     }
     if (key && strcmp(key, "gather_win") == 0 && value >= 0 && value <= 4096 && (value == 0 || value >= 8)) {
         msda::g_gather_win.store(value, std::memory_order_relaxed);
+        return 0;
+    }
+    if (key && strcmp(key, "deterministic") == 0) {
+        msda::g_deterministic.store(value ? 1 : 0, std::memory_order_relaxed);
         return 0;
     }
     if (key && strcmp(key, "cell_slices") == 0 && value >= 0 && value <= 64) {
@@ -172,6 +178,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "q_round") == 0) return msda::option_q_round();
     if (key && strcmp(key, "overlap") == 0) return msda::option_overlap();
     if (key && strcmp(key, "gather_win") == 0) return msda::option_gather_win();
+    if (key && strcmp(key, "deterministic") == 0) return msda::option_deterministic();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

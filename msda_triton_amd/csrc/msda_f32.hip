@@ -14,7 +14,7 @@ extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_byte
     if (small) return 0;
     // the larger of the 16-byte-vector and the scalar layout: which one a call takes depends on the alignment of its
     // grad_out / grad_value pointers (a slice of a shard's buffers can be misaligned), and a workspace that is too
-    // small would silently drop grad_value to the LDS-tile kernel
+    // small would be rejected (MSDA_ERR_BAD_ARG)
     const size_t vec = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, true).total;
     const size_t sca = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, false).total;
     return (int64_t)(vec > sca ? vec : sca);

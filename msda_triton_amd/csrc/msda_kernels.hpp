@@ -2,7 +2,7 @@
 //
 //   msda_fwd_kernel         out = sum_{l,p} attn * bilinear(value_l, loc)        (kernels.py:259-348)
 //   msda_bwd_sample_kernel  grad_loc, grad_attn (private per sample, no atomics)  (kernels.py:494-537)
-//   (grad_value lives in msda_value_sorted.hpp / msda_value_tile.hpp)
+//   (grad_value lives in msda_value_sorted.hpp / msda_value_small.hpp)
 //
 // Work decomposition: a workgroup owns ONE (batch, head) plane of `value` and a run of query
 // chunks, so every row it gathers comes from one 2-D plane.  A *unit* = one (b, q, h); a unit is
@@ -45,10 +45,6 @@ struct Params {
     int grid3d;       // this launch uses the division-free 3-D grid (see decode_block)
     int debug;        // dev-only ablation mask (msda_set_option("debug", m)); 0 in normal use
     FastDiv div_h;    // pair -> (b, h)
-    // grad_value tile kernel
-    int nchunks;   // channel chunks (D / CH)
-    int nranges;   // pixel ranges
-    int range_px;  // pixels per range
     // sorted (gather-formulated) grad_value path: caller-provided workspace, see msda_value_sorted.hpp
     int *ws_part;       // [pairs][nsplit][nc_cap]   per-slice cell counts, then each slice's first slot per cell
     int *ws_blocktot;   // [pairs][nsplit][nblk_cap] per slice and block of 256 cells: records

@@ -8,13 +8,12 @@
 
 #include "msda_value_sorted.hpp"
 #include "msda_value_small.hpp"
-#include "msda_value_tile.hpp"
 
 namespace msda {
 
 // ---- process-wide options and per-thread error text (defined in msda_api.hip) ----
 int option_xcd_map();
-int option_value_path();  // 0: auto (single-launch LDS kernel when a plane-level fits, else sorted gather), 1: LDS tile kernel, 2: sorted, 3: single-launch
+int option_value_path();  // 0: auto (single-launch LDS kernel when a plane-level fits, else sorted gather), 2: sorted, 3: single-launch
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
 int option_small_ns();      // workgroups per (plane, level) of the single-launch grad_value kernel (0: automatic)
 int option_q_round();       // queries per round of the sorted grad_value path (0: automatic)
@@ -26,7 +25,6 @@ int side_stream_join(hipStream_t user);            // `user` waits for everythin
 void set_error(const char *fmt, ...);
 
 constexpr int kRecordLdsBudget = 48 * 1024;                // per workgroup, parked sample records
-constexpr int kValueLdsBudget = 160 * 1024 - 2048;         // per workgroup, grad_value tiles
 constexpr int kMaxDynLds = 160 * 1024 - 2048;  // leaves room for small static __shared__ objects
 
 inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -199,39 +197,6 @@ template <typename T, int MODE, typename TV = T> inline int dispatch_gather(Para
     return dispatch_group<T, 1, MODE, TV>(p, stream);
 }
 
-template <typename T, int CH, typename TV = T> inline int launch_value(Params &p, hipStream_t stream)
-{
-    const size_t px_bytes = (size_t)CH * sizeof(TileAcc);
-    const size_t room = kValueLdsBudget - sizeof(LevelTab);
-    p.nchunks = p.D / CH;
-    p.nranges = (int)(((size_t)p.I * px_bytes + room - 1) / room);
-    if (p.nranges < 1) p.nranges = 1;
-    p.range_px = (p.I + p.nranges - 1) / p.nranges;
-    const size_t lds = sizeof(LevelTab) + (size_t)p.range_px * px_bytes;
-    const int npairs = p.B * p.H;
-    dim3 grid;
-    if (!plane_grid(p, npairs, (int64_t)p.nchunks * p.nranges, grid)) {
-        set_error("grid too large");
-        return MSDA_ERR_TOO_LARGE;
-    }
-    static std::atomic<uint64_t> big_lds_done{0};
-    allow_big_lds(msda_bwd_value_kernel<T, CH, TV>, big_lds_done);
-    hipLaunchKernelGGL((msda_bwd_value_kernel<T, CH, TV>), grid, dim3(kValueBlock), lds, stream, p);
-    return (int)hipGetLastError();
-}
-
-template <typename T, typename TV = T> inline int dispatch_value(Params &p, hipStream_t stream)
-{
-    const size_t room = kValueLdsBudget - sizeof(LevelTab);
-    auto fits = [&](int ch) {
-        return (p.D % ch) == 0 && aligned_to(p.grad_out, ch * sizeof(T)) && aligned_to(p.grad_value, ch * sizeof(TV)) &&
-               (size_t)p.I * ch * sizeof(TileAcc) <= room;
-    };
-    if (fits(4)) return launch_value<T, 4, TV>(p, stream);
-    if (fits(2)) return launch_value<T, 2, TV>(p, stream);
-    return launch_value<T, 1, TV>(p, stream);
-}
-
 // ---- sorted (gather-formulated) grad_value: K1..K5 of msda_value_sorted.hpp ----
 template <typename T, int VEC, int G, int GB, typename TV = T> inline int launch_value_gather_block(Params &p, hipStream_t stream)
 {
@@ -327,6 +292,8 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
     static std::atomic<uint64_t> big_lds_count{0}, big_lds_place{0};
     allow_big_lds(msda_cell_pass_kernel<T, false>, big_lds_count);
     allow_big_lds(msda_cell_pass_kernel<T, true>, big_lds_place);
+    static std::atomic<uint64_t> big_lds_place_det{0};
+    allow_big_lds(msda_cell_place_det_kernel<T>, big_lds_place_det);
     const int64_t scan_blocks = (int64_t)p.nblk_cap * npairs;
     if (scan_blocks >= ((int64_t)1 << 31)) {
         set_error("grid too large");
@@ -339,7 +306,10 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
         p.finish_mode = w.rounds == 1 ? 0 : r == 0 ? 1 : r == w.rounds - 1 ? 3 : 2;
         hipLaunchKernelGGL((msda_cell_pass_kernel<T, false>), gcell, dim3(kCellBlock), cell_lds, stream, p);
         hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)scan_blocks), dim3(kScanCells), 0, stream, p);
-        hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
+        if (option_deterministic())
+            hipLaunchKernelGGL((msda_cell_place_det_kernel<T>), gcell, dim3(kWave), cell_lds, stream, p);
+        else
+            hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
         int rc = (int)hipGetLastError();
         if (rc) return rc;
         rc = vec_ok ? dispatch_value_gather_group<T, VECF, TV>(p, stream) : dispatch_value_gather_group<T, 1, TV>(p, stream);
@@ -361,7 +331,7 @@ inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_co
     p.zeros = padding_mode == MSDA_PADDING_ZEROS;
     p.align = align_corners != 0;
     p.xcd_map = option_xcd_map();
-    p.nqc = p.sc = p.nchunks = p.nranges = p.range_px = 0;
+    p.nqc = p.sc = 0;
     p.qw = 1;
     p.grid3d = 0;
     p.ref = nullptr;
@@ -518,24 +488,43 @@ template <typename T> inline bool small_fits(const Dims &d)
 }
 template <typename T> inline bool small_path_chosen(const Dims &d)
 {
+    if (option_deterministic()) return false;  // (its LDS placing order follows the atomics)
     return small_fits<T>(d) && (option_value_path() == 3 || (option_value_path() == 0 && d.Q * d.P <= 4096));
 }
 
-// grad_value: the sorted-gather pipeline when the caller's workspace allows it, else (or for small problems) the
-// LDS-tile kernel.
+// grad_value: the single-launch kernel for small problems (no workspace), else the sorted-gather pipeline in the
+// caller's workspace.  There is no third path: a large problem without (enough) workspace is an argument error, and
+// shapes beyond the sorted pipeline's record format (more than 16 levels, I >= 2^23, D beyond 32-bit slot offsets) are
+// unsupported for grad_value when they are also too large for the single-launch kernel.
 template <typename T, typename TV = T>
 inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspace_bytes, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
     const int64_t B = d.B, I = d.I, H = d.H, D = d.D, Q = d.Q, L = d.L, P = d.P;
-    const bool sorted = sorted_fits<T>(d) && option_value_path() != 1 && workspace != nullptr && aligned_to(workspace, 256) &&
-                        (uint64_t)workspace_bytes >=
-                            sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p)).total;
-    const bool small_path = small_path_chosen<T>(d) || (option_value_path() == 0 && !sorted && small_fits<T>(d));
-    // (no workspace: the single-launch kernel is still better than the LDS-tile kernel whenever it fits)
-    const int rc = small_path ? run_value_small<T, TV>(p, d, stream)
-                   : sorted   ? run_value_sorted<T, TV>(p, d, workspace, stream)
-                              : dispatch_value<T, TV>(p, stream);
+    const bool fits = sorted_fits<T>(d);
+    const size_t need = fits ? sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p)).total : 0;
+    const bool sorted = fits && workspace != nullptr && aligned_to(workspace, 256) && (uint64_t)workspace_bytes >= need;
+    const bool small_path = small_path_chosen<T>(d) ||
+                            (option_value_path() != 2 && !option_deterministic() && !sorted && small_fits<T>(d));
+    // (no workspace: the single-launch kernel serves whatever fits its LDS)
+    int rc;
+    if (small_path) {
+        rc = run_value_small<T, TV>(p, d, stream);
+    } else if (sorted) {
+        rc = run_value_sorted<T, TV>(p, d, workspace, stream);
+    } else if (!fits) {
+        set_error("grad_value: this shape is beyond the sorted pipeline's record format (L <= %d, I < 2^23, "
+                  "16*D*sizeof(acc) < 2^24, I*4*D*sizeof(acc) < 2^31) and too large for the single-launch kernel",
+                  kSortedMaxLevels);
+        return MSDA_ERR_UNSUPPORTED;
+    } else {
+        // (the size msda_bwd_workspace_bytes reports: the larger of the vector and the scalar layout)
+        const size_t v1 = sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), true).total;
+        const size_t v0 = sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), false).total;
+        set_error("grad_value needs a 256-byte aligned workspace of msda_bwd_workspace_bytes(...) = %zu bytes (got %lld)",
+                  v1 > v0 ? v1 : v0, (long long)(workspace ? workspace_bytes : 0));
+        return MSDA_ERR_BAD_ARG;
+    }
     if (rc > 0) set_error("backward (grad_value) launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

@@ -65,9 +65,9 @@ def test_mixed_storage_matches_oracle_shape_matrix(oracle, name, vdt):
         check_mixed(oracle, c, pm, ac, vdt)
 
 
-@pytest.mark.parametrize("value_path", [1, 2, 3], ids=["tile", "sorted", "small"])
+@pytest.mark.parametrize("value_path", [2, 3], ids=["sorted", "small"])
 def test_mixed_storage_every_grad_value_path(oracle, value_path):
-    """The three grad_value kernels all store the 16-bit rows (LDS tile, sorted pipeline's finish, single launch)."""
+    """Both grad_value paths store the 16-bit rows (sorted pipeline's finish kernel, single-launch kernel)."""
     from msda_triton_amd import _lib
     rng = np.random.default_rng(77 + value_path)
     c = rand_case(rng, 2, 300, 4, 32, [(12, 10), (6, 5), (3, 3)], 4)

@@ -588,7 +588,7 @@ def test_two_host_threads_run_backwards_on_one_device():
 # ------------------------------------------------------------------------------------------
 # backward grad_value: both implementations, and the shapes that stress the sorted gather
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("value_path", [2, 1, 3], ids=["sorted_gather", "lds_tiles", "single_launch"])
+@pytest.mark.parametrize("value_path", [2, 3], ids=["sorted_gather", "single_launch"])
 @pytest.mark.parametrize("pm,ac", MODES, ids=[mode_key(*m) for m in MODES])
 def test_grad_value_both_paths_and_hot_pixels(oracle, value_path, pm, ac):
     """Every query samples the same few pixels (lists far longer than one work-item chunk, so pixels are
@@ -632,22 +632,43 @@ def test_grad_value_cell_flood_spans_gather_workgroups(oracle, D, Q, td, value_p
         _lib.set_option("value_path", 0)
 
 
-def test_grad_value_without_workspace_uses_tile_kernel(oracle):
-    """The C ABI accepts workspace == NULL and then runs the LDS-tile kernel."""
+def test_grad_value_without_workspace(oracle):
+    """The C ABI accepts workspace == NULL for problems the single-launch kernel takes (its inverted index lives in
+    LDS); a larger problem without workspace is an argument error for grad_value — nothing is launched, the message
+    names the size — while grad_loc / grad_attn alone never need one."""
     from msda_triton_amd import _lib
+    lib = _lib.load()
     c = rand_case(np.random.default_rng(32), 1, 40, 2, 32, [(6, 6), (3, 3)], 3)
     v, l, a, g = (torch.from_numpy(c[k]).to(DEV) for k in ("value", "loc", "attn", "grad_out"))
     s = torch.from_numpy(c["shapes"]).to(DEV)
     gv, gl, ga = torch.empty_like(v), torch.empty_like(l), torch.empty_like(a)
     B, I, H, D = v.shape
     _, Q, _, L, P, _ = l.shape
-    rc = _lib.load().msda_bwd_f32(g.data_ptr(), v.data_ptr(), s.data_ptr(), l.data_ptr(), a.data_ptr(),
-                                  gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, I, H, D, Q, L, P, 1, 0,
-                                  None, 0, torch.cuda.current_stream().cuda_stream)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.msda_bwd_f32(g.data_ptr(), v.data_ptr(), s.data_ptr(), l.data_ptr(), a.data_ptr(),
+                          gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, I, H, D, Q, L, P, 1, 0, None, 0, st)
     assert rc == 0
     torch.cuda.synchronize()
     r_gv, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
     np.testing.assert_allclose(gv.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
+    np.testing.assert_allclose(ga.cpu().numpy(), r_ga, **BWD_TOL[torch.float32])
+    # a problem beyond the single-launch kernel (Q * P > 4096 samples per plane and level)
+    c = rand_case(np.random.default_rng(33), 1, 3000, 2, 32, [(6, 6), (3, 3)], 3)
+    v, l, a, g = (torch.from_numpy(c[k]).to(DEV) for k in ("value", "loc", "attn", "grad_out"))
+    gv, gl, ga = torch.empty_like(v), torch.empty_like(l), torch.empty_like(a)
+    B, I, H, D = v.shape
+    _, Q, _, L, P, _ = l.shape
+    need = lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, 4)
+    assert need > 0
+    args = (g.data_ptr(), v.data_ptr(), s.data_ptr(), l.data_ptr(), a.data_ptr())
+    dims = (B, I, H, D, Q, L, P, 1, 0)
+    assert lib.msda_bwd_f32(*args, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), *dims, None, 0, st) == -1
+    assert str(need) in lib.msda_last_error().decode()
+    small_ws = torch.empty(need // 2, dtype=torch.uint8, device=DEV)
+    assert lib.msda_bwd_f32(*args, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), *dims, small_ws.data_ptr(), need // 2, st) == -1
+    assert lib.msda_bwd_f32(*args, None, gl.data_ptr(), ga.data_ptr(), *dims, None, 0, st) == 0  # no grad_value: no workspace
+    torch.cuda.synchronize()
+    _, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
     np.testing.assert_allclose(ga.cpu().numpy(), r_ga, **BWD_TOL[torch.float32])
 
 
@@ -819,7 +840,7 @@ def test_fused_backward_partial_needs_and_large_lp_fallback():
     assert torch.isfinite(pr.grad).all()
 
 
-@pytest.mark.parametrize("value_path", [2, 1, 3], ids=["sorted_gather", "lds_tiles", "single_launch"])
+@pytest.mark.parametrize("value_path", [2, 3], ids=["sorted_gather", "single_launch"])
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_random_shapes_against_oracle(oracle, seed, value_path):
     """Differential test over random shapes / modes / coordinate ranges (fixed seeds), with the sorted-gather
@@ -867,6 +888,41 @@ def test_sorted_grad_value_in_query_rounds(oracle, td):
     finally:
         _lib.set_option("q_round", 0)
         _lib.set_option("value_path", 0)
+
+
+def test_deterministic_option_gives_bitwise_reproducible_grad_value(oracle):
+    """msda_set_option("deterministic", 1): the place pass ranks the samples of a cell by index instead of by the
+    order LDS atomics retire in, so the whole backward is bitwise reproducible — across repeated calls, with other
+    work interleaved on the device, and against a run under a different workgroup -> plane mapping.  Checked on a
+    shape with long cell lists (a 1 x 1 level takes a quarter of all samples) and on a c2-sized problem; the result
+    still matches the oracle."""
+    from msda_triton_amd import _lib, synth
+    ops = _ops()
+    rng = np.random.default_rng(515)
+    c = rand_case(rng, 2, 700, 4, 32, [(9, 7), (4, 4), (1, 1)], 4, lo=-0.2, hi=1.2)
+    small = tuple(torch.from_numpy(c[k]).to(DEV) for k in ("grad_out", "value", "shapes", "loc", "attn"))
+    wl = synth.WORKLOADS["c2_q5k"]
+    d = synth.make_inputs_torch(wl, DEV, seed=8)
+    big = (d["grad_out"], d["value"], d["shapes"], d["loc"], d["attn"])
+    try:
+        _lib.set_option("deterministic", 1)
+        for args, pm, ac in ((small, "zeros", False), (small, "border", True), (big, wl.padding_mode, wl.align_corners)):
+            runs = []
+            for k in range(4):
+                if k == 2:  # different scheduling: other kernels in flight, plain block mapping
+                    _lib.set_option("xcd_map", 0)
+                    noise = torch.randn(1 << 22, device=DEV).sin_()
+                runs.append(ops.msda_hip_bwd(*args, pm, ac))
+                torch.cuda.synchronize()
+                _lib.set_option("xcd_map", 1)
+            for r in runs[1:]:
+                assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+        gv = runs and ops.msda_hip_bwd(*small, "zeros", False)[0]
+        r_gv, _, _ = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
+        np.testing.assert_allclose(gv.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
+    finally:
+        _lib.set_option("deterministic", 0)
+        _lib.set_option("xcd_map", 1)
 
 
 def test_make_graphed_callables_replays_forward_and_backward():
