@@ -556,11 +556,39 @@ def native_multiscale_deformable_attention(
     padding_mode: Literal["border", "zeros"],
     align_corners: bool,
 ) -> torch.Tensor:
-    """Plain-PyTorch formulation for host tensors, differentiable through autograd.
+    """Plain-PyTorch path for host tensors, differentiable through autograd (the reference's documented CPU
+    behaviour, frontend.py:15-68).
 
-    An independent statement of the operator (index arithmetic + ``gather``; the reference loops
-    ``F.grid_sample`` over levels).  Like the reference's it reads ``img_shapes`` on the host.
+    Per level, every (batch, head) plane is one ``[D, h, w]`` image for ``F.grid_sample`` — PyTorch's vectorised
+    bilinear sampler, forward and backward — and the level's samples are folded into the result straight away by a
+    contraction with the attention weights over the point axis, so the ``[B, Q, H, L, P, D]`` sample tensor is never
+    built.  Like the reference it reads ``img_shapes`` on the host.  ``_gather_multiscale_deformable_attention`` below
+    states the same operator without ``grid_sample`` (tests hold the two to each other and to the reference's golden
+    vectors).
     """
+    _padding_code(padding_mode)
+    B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
+    dt = torch.result_type(img, sampling_points)
+    planes = img.to(dt).permute(0, 2, 3, 1).reshape(B * H, D, I)          # [B*H, D, I]: a plane's channels as images
+    grid = (2 * sampling_points.to(dt) - 1).permute(0, 2, 3, 1, 4, 5)      # [B, H, L, Q, P, 2] in grid_sample's [-1, 1]
+    weights = attention_weights.to(dt).permute(0, 2, 3, 1, 4)              # [B, H, L, Q, P]
+    out = None
+    start = 0
+    for lvl, (h, w) in enumerate(img_shapes.tolist()):
+        level = planes[:, :, start:start + h * w].reshape(B * H, D, h, w)
+        sampled = torch.nn.functional.grid_sample(level, grid[:, :, lvl].reshape(B * H, Q, P, 2), mode="bilinear",
+                                                  padding_mode=padding_mode, align_corners=align_corners)  # [B*H, D, Q, P]
+        part = torch.einsum("ndqp,nqp->nqd", sampled, weights[:, :, lvl].reshape(B * H, Q, P))
+        out = part if out is None else out + part
+        start += h * w
+    if out is None:
+        out = planes.new_zeros((B * H, Q, D))
+    return out.reshape(B, H, Q, D).permute(0, 2, 1, 3).contiguous()
+
+
+def _gather_multiscale_deformable_attention(img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners):
+    """The operator as index arithmetic + ``gather`` (no ``grid_sample``): an independent statement of SURVEY 9.1, kept
+    as a cross-check of the host path (slow: its backward is four ``scatter_add`` per level)."""
     _padding_code(padding_mode)
     B, I, H, D, Q, L, P = _dims(img, sampling_points, attention_weights, img_shapes)
     planes = img.permute(0, 2, 1, 3)  # [B, H, I, D]

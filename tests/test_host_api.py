@@ -267,3 +267,31 @@ def test_host_module_matches_reference_module_fixtures(path):
     torch.testing.assert_close(ref.grad, want["grad_reference_points"], **tol)
     for name, prm in m.named_parameters():
         torch.testing.assert_close(prm.grad, want["grad__" + name], msg=lambda s, n=name: f"{n}: {s}", **tol)
+
+
+def test_host_path_and_gather_formulation_agree():
+    """Two statements of the operator on host tensors — per-level grid_sample + contraction (the product's host path)
+    and index arithmetic + gather (no grid_sample) — agree in fp64 on out and all three gradients, all four modes,
+    non-square levels, out-of-range points (location gradients compared away from the pixel-grid kinks)."""
+    from conftest import MODES, kink_mask
+    from msda_triton_amd.functional import _gather_multiscale_deformable_attention, native_multiscale_deformable_attention
+    g = torch.Generator().manual_seed(99)
+    levels = [(7, 5), (3, 4), (1, 2)]
+    B, Q, H, D, P = 2, 19, 3, 6, 3
+    shapes = torch.tensor(levels)
+    value = torch.randn(B, sum(h * w for h, w in levels), H, D, generator=g, dtype=torch.float64)
+    loc = torch.rand(B, Q, H, len(levels), P, 2, generator=g, dtype=torch.float64) * 1.6 - 0.3
+    attn = torch.rand(B, Q, H, len(levels), P, generator=g, dtype=torch.float64)
+    gout = torch.rand(B, Q, H, D, generator=g, dtype=torch.float64)
+    for pm, ac in MODES:
+        res = []
+        for fn in (native_multiscale_deformable_attention, _gather_multiscale_deformable_attention):
+            v, l, a = (t.clone().requires_grad_(True) for t in (value, loc, attn))
+            out = fn(v, shapes, l, a, pm, ac)
+            out.backward(gout)
+            res.append((out.detach(), v.grad, l.grad, a.grad))
+        keep = torch.from_numpy(~kink_mask(loc.numpy(), shapes.numpy(), ac, tol=1e-9))
+        for name, x, y in zip(("out", "grad_value", "grad_loc", "grad_attn"), res[0], res[1]):
+            if name == "grad_loc":
+                x, y = x * keep, y * keep
+            torch.testing.assert_close(x, y, atol=1e-11, rtol=1e-9, msg=lambda m, n=name: f"{pm} {ac} {n}: {m}")
