@@ -3,14 +3,15 @@
 The reference has no multi-device code; every (b, q, h) of the operator is independent
 (/root/reference/src/msda_triton/kernels.py:18-21), so the queries shard trivially:
 
-  forward   each rank runs the HIP kernels on its contiguous slice of the query axis against the
-            (replicated) value pyramid, then ONE all-gather assembles ``[B, Q, H, D]`` on every rank;
+  forward   each rank runs the HIP kernels on its rows against the (replicated) value pyramid and writes them
+            straight into their place in the full ``[B, Q, H, D]`` result; the peers' rows arrive in place too —
+            one in-place all-gather, or grouped point-to-point pieces that overlap the next piece's kernels;
   backward  grad_sampling_points / grad_attention_weights are shard-local (no communication);
-            grad_value is a sum over all queries, so it is all-reduced across the ranks.
+            grad_value is a sum over the queries of a batch element: summed among the ranks that share that
+            batch element (nothing to do while the ranks divide B), or all-reduced.
 
-With 8 GPUs on one node the all-gather moves ``B*Q*H*D*s/8`` bytes per peer over point-to-point
-xGMI links; the collectives are issued once per call on whole tensors (no bucketing needed at
-these sizes: c4 0.9 MB, c5 51 MB per rank).
+With 8 GPUs on one node a rank sends ``B*Q*H*D*s/8`` bytes to every peer over its own point-to-point xGMI link
+(c4 0.9 MB, c5 51 MB per rank); the collectives are issued on whole tensors or on up to four pieces.
 
 Two partitions are offered:
 

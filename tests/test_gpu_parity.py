@@ -339,7 +339,7 @@ def test_forward_is_bitwise_deterministic_and_backward_stable():
         outs.append(o.detach()); gvs.append(v.grad); gls.append((l.grad, a.grad))
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(gls[0][0], gls[1][0]) and torch.equal(gls[0][1], gls[1][1])  # private per sample: exact
-    torch.testing.assert_close(gvs[0], gvs[1], atol=1e-4, rtol=1e-4)  # LDS float adds: order may vary
+    torch.testing.assert_close(gvs[0], gvs[1], atol=1e-4, rtol=1e-4)  # the order of the records inside a cell list may vary (last bit)
 
 
 def test_xcd_map_on_off_same_results():
