@@ -248,6 +248,36 @@ def bench_config(name, dev, steps=20, warmup=5):
             "peak_mem_MB": round(peak / 1e6, 1), "inputs_MB": round(base / 1e6, 1), "kernels": kernels}
 
 
+def triton_comparator_leg(wl_name, dev):
+    """A Triton kernel WRITTEN FOR THIS REPO (scripts/triton_comparator.py: the reference's parallelisation — a program
+    per (query, batch, head), tl.atomic_add grad_value, num_warps autotuned — but not its code, which cannot travel to
+    the GPU box) timed next to the HIP operator on the same GPU, SURVEY.md 8d.  A comparator, not a product path: any
+    failure (no Triton, compile error) is reported here and costs the bench nothing."""
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location(
+            "msda_triton_comparator", os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "triton_comparator.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if not mod.HAVE_TRITON:
+            return {"unavailable": "Triton is not importable"}
+        import triton
+        r = mod.compare(wl_name, dev)
+        return {"what": "builder-authored Triton comparator (scripts/triton_comparator.py), NOT the reference's kernel; "
+                        "same inputs, same GPU, warm mean of 20 steps each",
+                "triton_version": triton.__version__,
+                "triton_fwd_ms": r["triton"]["fwd_ms"], "triton_fwd_bwd_ms": r["triton"]["fwd_bwd_ms"],
+                "triton_fwd_bwd_ms_relaxed_atomics": r["triton_relaxed_atomics"]["fwd_bwd_ms"],
+                "hip_fwd_ms": r["hip"]["fwd_ms"], "hip_fwd_bwd_ms": r["hip"]["fwd_bwd_ms"],
+                "hip_speedup": {"fwd": r["hip_speedup"]["fwd_ms"], "fwd_bwd": r["hip_speedup"]["fwd_bwd_ms"],
+                                "fwd_bwd_vs_relaxed_atomics": r["hip_speedup"]["fwd_bwd_ms_vs_relaxed_atomics"]},
+                "atomics": "tl.atomic_add with its default acq_rel ordering, as the reference calls it "
+                           "(kernels.py:550-553); the relaxed figure is the same kernel with sem='relaxed'",
+                "triton_num_warps": r["triton_num_warps"], "max_abs_diff_vs_hip": r["max_abs_diff"]}
+    except Exception as e:  # noqa: BLE001
+        return {"unavailable": repr(e)[:300]}
+
+
 def strong_scaling_leg(wl_name, dev, world, rank, use_dist, chunks=None, steps=5, warmup=2):
     """A BASELINE config (configs[4], the stress shape, in real runs) with its B*Q rows split over the ranks: fwd+bwd
     ms per step.  Inputs are drawn on the device (torch RNG, same seed on every rank for the replicated value pyramid):
@@ -368,6 +398,8 @@ def main():
     ap.add_argument("--no-strong-c5", action="store_true", help="skip the strong-scaling leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (N=1 only)")
     ap.add_argument("--no-do-bench", action="store_true", help="skip the do_bench (cold / warm quantiles) leg (N=1 only)")
+    ap.add_argument("--no-triton", action="store_true",
+                    help="skip the Triton comparator leg (scripts/triton_comparator.py; N=1 only)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --device cpu: dry run of the N-rank control flow on host tensors")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"])
@@ -653,6 +685,8 @@ def main():
                 torch.cuda.empty_cache()
             return out
         optional("configs", leg_configs, False)
+    if world == 1 and on_gpu and rank == 0 and not args.no_triton and args.workload == "c2_q10k":
+        result["triton_comparator"] = triton_comparator_leg(args.workload, dev)
     if rank == 0:
         if failed_legs:
             result["failed_legs"] = failed_legs
