@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Long differential fuzz of the HIP operator against the C oracle (fp64 cases at 1e-8, fp32 at the test suite's
+tolerances): wider than tests/test_gpu_parity.py::test_random_shapes_against_oracle — more queries (cells that span
+many gather windows and workgroups), 1 x N levels, hot spots, far out-of-range coordinates, both grad_value paths, the
+deterministic option, query rounds.  Usage: fuzz_parity.py [seconds] [first_seed]; prints one line per failure and a
+summary; exit status 1 if anything failed."""
+import json
+import os
+import sys
+import time
+import traceback
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+
+import test_gpu_parity as tp
+from msda_triton_amd import _lib
+from oracle import msda_oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+msda_oracle.build()
+t0 = time.time()
+n = fails = 0
+seen = {}
+seed = seed0
+while time.time() - t0 < budget:
+    rng = np.random.default_rng(77000 + seed)
+    kind = seed % 6
+    B, H = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+    D = int(rng.choice([1, 2, 3, 7, 8, 16, 24, 32, 40, 64, 80]))
+    L, P = int(rng.integers(1, 7)), int(rng.integers(1, 9))
+    Q = int(rng.choice([1, 2, 17, 64, 200, 700, 1500, 3000])) if kind != 5 else int(rng.integers(1, 60))
+    big = int(rng.choice([6, 12, 25, 40]))
+    levels = [(int(rng.integers(1, big + 1)), int(rng.integers(1, big + 1))) for _ in range(L)]
+    if kind == 1:
+        levels[int(rng.integers(0, L))] = (1, int(rng.integers(1, 50)))  # a one-row level
+    if kind == 2:
+        levels[int(rng.integers(0, L))] = (int(rng.integers(1, 50)), 1)  # a one-column level
+    lo, hi = [(-0.4, 1.4), (0.0, 1.0), (0.45, 0.55), (-30.0, 31.0), (0.0, 1.0), (-0.1, 1.1)][kind]
+    pm, ac = tp.MODES[int(rng.integers(0, len(tp.MODES)))]
+    f64 = bool(rng.integers(0, 2))
+    # keep the oracle's work bounded: samples * D
+    while B * Q * H * L * P * D > 6e7 and Q > 1:
+        Q //= 2
+    c = tp.rand_case(rng, B, Q, H, D, levels, P, lo=lo, hi=hi, dtype=np.float64 if f64 else np.float32)
+    if kind == 4:  # a hot spot: most samples of one level in one cell
+        hot = rng.uniform(0.2, 0.8, size=2)
+        m = rng.uniform(size=c["loc"].shape[:-1]) < 0.8
+        c["loc"][m] = (hot + rng.normal(0, 0.002, size=(int(m.sum()), 2))).astype(c["loc"].dtype)
+    td = torch.float64 if f64 else torch.float32
+    opts = {"value_path": int(rng.choice([0, 2, 3])), "deterministic": int(rng.integers(0, 2)),
+            "q_round": int(rng.choice([0, 0, 0, max(1, Q // 3)]))}
+    desc = dict(seed=seed, B=B, Q=Q, H=H, D=D, levels=levels, P=P, range=(lo, hi), pm=pm, ac=ac, f64=f64, **opts)
+    try:
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        tp.check_against_oracle(msda_oracle, c, pm, ac, tp.FWD_TOL[td], tp.BWD_TOL[td])
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        print("FAIL", json.dumps(desc), "::", str(e).strip().splitlines()[0:6], flush=True)
+        if not isinstance(e, AssertionError):
+            traceback.print_exc()
+    finally:
+        for k in opts:
+            _lib.set_option(k, 0)
+    n += 1
+    seen[kind] = seen.get(kind, 0) + 1
+    seed += 1
+    if n % 50 == 0:
+        print(f"... {n} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
+print(f"fuzz: {n} cases (seeds {seed0}..{seed - 1}), {fails} failures, kinds {seen}, {time.time() - t0:.0f} s")
+sys.exit(1 if fails else 0)
