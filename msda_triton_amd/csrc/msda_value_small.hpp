@@ -7,10 +7,12 @@
 //   1 count    every sample of the level -> its bilinear cell (msda_value_sorted.hpp: sample_cell); LDS histogram
 //   2 scan     exclusive scan of the histogram in place: first record of every cell's list; the longest list
 //   3 place    samples again -> records {q, dx, dy, a} at their cell list's cursor (LDS)
-//   4 gather   PIXEL-major: a G-lane group owns a pixel (or 1/S of a busy pixel's records), walks the lists of the
-//              pixel's four incident cells, loads each record's grad_out row (16 bytes per lane) and FMAs it with the
-//              corner weight into ONE accumulator row; S > 1: the S partial rows are summed through LDS.  The pixel's
-//              grad_value row is stored once — complete, so there are no partial rows in memory and no finish pass.
+//   4 gather   PIXEL-major: a G-lane group owns a 2 x 2 block of pixels (or 1/S of a busy block's records), walks the
+//              lists of the nine cells around it, loads each record's grad_out row (16 bytes per lane) and FMAs it with
+//              the corner weights into the block's four accumulator rows; S > 1: the S partial row sets are summed with
+//              shuffles.  Blocks are handed out heaviest first (the groups of a wave then need the same number of
+//              batches).  A pixel's grad_value row is stored once — complete, so there are no partial rows in memory
+//              and no finish pass.
 //
 // Every grad_value row of the level is written exactly once by plain stores (rows nobody samples: zeros).
 // Replaces tl.atomic_add of the reference (kernels.py:543-553) for these shapes.
@@ -35,6 +37,7 @@ inline size_t small_lds_bytes(size_t cells, size_t samples, size_t acc_bytes, si
     o = (o + 15) / 16 * 16 + (cells + 1) * 4;              // counters / cell list starts
     o = (o + 15) / 16 * 16 + samples * rec;                // records sorted by cell
     o = (o + 15) / 16 * 16 + (size_t)kSmallBlock * (4 + 4 * acc_bytes);  // converted (row offset, four weights) hand-off
+    o = (o + 15) / 16 * 16 + (cells / 4 + 2) * 2;          // the level's 2 x 2-pixel blocks, ordered by their work
     (void)vec;
     return o + 64;
 }
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     constexpr int NG = kSmallBlock / G;  // lane groups per workgroup
     constexpr int UB = G < 8 ? G : 8;    // row loads in flight per lane
     // p.small_ns workgroups per (plane, level): each builds the level's sorted records for itself (cheap) and takes
-    // every small_ns-th round of the gather, so few planes still fill the chip and busy levels get more CUs' time
+    // every small_ns-th 2 x 2-pixel block of the gather, so few planes still fill the chip
     int pair, slot;
     if (!decode_block(p.grid3d, p.B * p.H, p.L * p.small_ns, p.xcd_map, pair, slot)) return;
     const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
@@ -74,12 +77,13 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     o = (o + 15) / 16 * 16;
     uint32_t *s_q = reinterpret_cast<uint32_t *>(sm + o);  // [kSmallBlock] row byte offsets
     CornerW<A> *s_w = reinterpret_cast<CornerW<A> *>(sm + o + (size_t)kSmallBlock * 4);  // [kSmallBlock] weights per block pixel
+    o += (size_t)kSmallBlock * (4 + sizeof(CornerW<A>));
+    o = (o + 15) / 16 * 16;
+    uint16_t *s_order = reinterpret_cast<uint16_t *>(sm + o);  // [blocks of the level] heaviest first
 
     __shared__ int s_red[kSmallBlock / kWave];
-    __shared__ int s_max;
 
     for (int i = tid; i <= ncl; i += kSmallBlock) s_off[i] = 0;
-    if (tid == 0) s_max = 0;
     __syncthreads();
 
     // ---- samples of this (plane, level): thread t serves point t % P of the queries t / P + k * (threads / P) ----
@@ -136,16 +140,12 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     // 1 count
     walk([&](int, A, int cell, A, A) { atomicAdd(&s_off[cell], 1); });
     __syncthreads();
-    // 2 exclusive scan in place (each thread a contiguous run of cells), and the longest list
+    // 2 exclusive scan in place (each thread a contiguous run of cells)
     {
         const int per = (ncl + kSmallBlock - 1) / kSmallBlock;
         const int c_beg = min(ncl, tid * per), c_end = min(ncl, c_beg + per);
-        int sum = 0, mx = 0;
-        for (int c = c_beg; c < c_end; ++c) {
-            const int n = s_off[c];
-            sum += n;
-            mx = max(mx, n);
-        }
+        int sum = 0;
+        for (int c = c_beg; c < c_end; ++c) sum += s_off[c];
         const int lane = tid & (kWave - 1), wid = tid / kWave;
         int inc = sum;
 #pragma unroll
@@ -153,10 +153,7 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
             const int nn = __shfl_up(inc, d, kWave);
             if (lane >= d) inc += nn;
         }
-#pragma unroll
-        for (int m = 1; m < kWave; m <<= 1) mx = max(mx, __shfl_xor(mx, m, kWave));
         if (lane == kWave - 1) s_red[wid] = inc;
-        if (lane == 0) atomicMax(&s_max, mx);
         __syncthreads();
         int base = inc - sum;
         for (int i = 0; i < wid; ++i) base += s_red[i];
@@ -184,10 +181,7 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     // ---- 4 gather: a lane group owns a 2 x 2 block of pixels (or 1/S of a busy block's records).  The block's
     // pixels are corners of the 3 x 3 cells around it, so each record's grad_out row is loaded ONCE per block (9 cell
     // lists for 4 pixels; a pixel alone would walk 4 lists) and FMAed into up to four accumulator rows. ----
-    const int maxcell = s_max;
     constexpr int SMAX = kWave / G;  // lane groups of one wave: their partial rows meet through shuffles
-    int S = 1;
-    while (S < SMAX && (9 * maxcell + S - 1) / S > 64) S <<= 1;
     const int unit = tid / G, j = tid % G;
     const int gbase = tid - j;
     const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;
@@ -195,25 +189,99 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     const rsrc_t rs_go = make_rsrc(gout, (uint32_t)(((size_t)p.Q * p.H * p.D - (size_t)h * p.D) * sizeof(T)));
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
     const int nbx = (lw + 1) / 2, nby = (lh + 1) / 2;
-    const int items = nbx * nby * S;
-    const int rounds = (items + NG - 1) / NG;
-    for (int r = share; r < rounds; r += nshare) {
-        const int item = r * NG + unit;
-        const bool live = item < items;
-        const int blk = live ? item / S : 0, part = live ? item % S : 0;
-        const int by = blk / max(nbx, 1), bx = blk - by * nbx;
-        // cumulative lengths of the nine lists: cell (2 bx - 1 + ci, 2 by - 1 + cj), list index ci + 3 cj
-        int lcum[10];
+    const int nblk = min(nbx * nby, p.small_cells / 4 + 2);  // (<= cells / 4; the cap only bites for shapes that disagree with I)
+    // this workgroup's blocks: share, share + nshare, ...  (the order below is built with atomics, so it differs from
+    // workgroup to workgroup: what a workgroup serves must not depend on it)
+    const int nown = share < nblk ? (nblk - share + nshare - 1) / nshare : 0;
+    // cumulative lengths of a block's nine lists: cell (2 bx - 1 + ci, 2 by - 1 + cj), list index ci + 3 cj
+    const float inv_nbx = 1.0f / (float)max(nbx, 1);
+    auto block_lists = [&](int blk, bool live, int(&lcum)[10]) {
+        const int by = div_small(blk, max(nbx, 1), inv_nbx), bx = blk - by * nbx;  // (blk < 2^16)
+        // cell (cx, cy) has id (cy + 1) * cw + cx + 1 and its list is [s_off[id - 1], s_off[id]): a row of three cells
+        // needs four consecutive list ends.  All twelve are read unconditionally at clamped addresses (conditional reads
+        // cost one LDS round trip each: 1.9 of a round's 6.4 thousand cycles on the 64 x 64 level of the c4 shape).
+        int e[3][4];
+#pragma unroll
+        for (int cj = 0; cj < 3; ++cj) {
+            const int id0 = (2 * by + cj) * cw + 2 * bx;  // id of the row's first cell (cx = 2 bx - 1)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) e[cj][t] = s_off[min(max(id0 - 1 + t, 0), ncl)];
+        }
         lcum[0] = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int cx = 2 * bx - 1 + (k % 3), cy = 2 * by - 1 + (k / 3);  // in [-1, lw - 1] x [-1, lh - 1] when valid
+            const int ci = k % 3, cj = k / 3;
+            const int cx = 2 * bx - 1 + ci, cy = 2 * by - 1 + cj;  // in [-1, lw - 1] x [-1, lh - 1] when valid
             const int cid = (cy + 1) * cw + (cx + 1);
             const bool ok = live && cx < lw && cy < lh && cid < ncl;
-            lcum[k + 1] = lcum[k] + (ok ? s_off[cid] - (cid > 0 ? s_off[cid - 1] : 0) : 0);
+            lcum[k + 1] = lcum[k] + (ok ? e[cj][ci + 1] - (cid > 0 ? e[cj][ci] : 0) : 0);
         }
+    };
+    // The lane groups of a wave run as many batches as the busiest of them needs (the gather is bound by the
+    // instructions it issues, not by the rows it waits for), and the records per block scatter widely (sparse level:
+    // Poisson around 8 for batches of 8 — nearly every wave paid a second, almost empty batch).  So the blocks are
+    // handed out in order of the batches they need, heaviest first: a counting sort over 16 classes.  Which block a
+    // group serves changes; the order of the additions inside a pixel does not.
+    // A busy block is split over S lane groups (S a power of two, the groups of one wave) so that no group walks more
+    // than 64 records: S from the busiest BLOCK of the level (from the longest cell list times nine it was 2 for one
+    // plane in 64 of the c4 shape — one cell with 8 samples — and that workgroup, with twice the rounds, set the
+    // kernel's time: 78 against 49 thousand cycles).
+    constexpr int kClasses = 16;
+    __shared__ int s_cls[kClasses];
+    __shared__ int s_maxtot;
+    if (tid < kClasses) s_cls[tid] = 0;
+    if (tid == 0) s_maxtot = 0;
+    __syncthreads();
+    {
+        int mx = 0;
+        for (int i = tid; i < nown; i += kSmallBlock) {
+            int lcum[10];
+            block_lists(share + i * nshare, true, lcum);
+            mx = max(mx, lcum[9]);
+        }
+#pragma unroll
+        for (int m = 1; m < kWave; m <<= 1) mx = max(mx, __shfl_xor(mx, m, kWave));
+        if ((tid & (kWave - 1)) == 0 && mx > 0) atomicMax(&s_maxtot, mx);
+    }
+    __syncthreads();
+    int lgS = 0;  // S = 1 << lgS
+    while ((1 << lgS) < SMAX && ((s_maxtot + (1 << lgS) - 1) >> lgS) > 64) ++lgS;
+    const int S = 1 << lgS;
+    const int items = nown * S;
+    const int rounds = (items + NG - 1) / NG;
+    {
+        auto block_class = [&](int blk) {
+            int lcum[10];
+            block_lists(blk, true, lcum);
+            const int per_group = (lcum[9] + S - 1) >> lgS;
+            return kClasses - 1 - min(kClasses - 1, (per_group + G - 1) / G);  // 0: most batches
+        };
+        for (int i = tid; i < nown; i += kSmallBlock) atomicAdd(&s_cls[block_class(share + i * nshare)], 1);
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int c = 0; c < kClasses; ++c) {
+                const int n = s_cls[c];
+                s_cls[c] = run;
+                run += n;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nown; i += kSmallBlock) {
+            const int blk = share + i * nshare;
+            s_order[atomicAdd(&s_cls[block_class(blk)], 1)] = (uint16_t)blk;
+        }
+        __syncthreads();
+    }
+    for (int r = 0; r < rounds; ++r) {
+        const int item = r * NG + unit;
+        const bool live = item < items;
+        const int blk = live ? (int)s_order[item >> lgS] : 0, part = live ? item & (S - 1) : 0;
+        const int by = div_small(blk, max(nbx, 1), inv_nbx), bx = blk - by * nbx;
+        int lcum[10];
+        block_lists(blk, live, lcum);
         const int ntot = lcum[9];
-        const int mine = ntot > part ? (ntot - part + S - 1) / S : 0;  // virtual positions part, part + S, ...
+        const int mine = ntot > part ? (ntot - part + S - 1) >> lgS : 0;  // virtual positions part, part + S, ...
         for (int cc = 0; cc < nchan_chunks; ++cc) {
             const int c0 = (cc * G + j) * VEC;
             const bool lane_ok = c0 < p.D;
@@ -228,7 +296,7 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
                 {
                     const int v = v0 + j;
                     const bool ok = v < mine;
-                    const int vp = part + v * S;
+                    const int vp = part + (v << lgS);
                     int k = 0;
 #pragma unroll
                     for (int t = 1; t < 9; ++t) k += (vp >= lcum[t]) ? 1 : 0;

@@ -864,6 +864,27 @@ def test_random_shapes_against_oracle(oracle, seed, value_path):
         _lib.set_option("value_path", 0)
 
 
+@pytest.mark.parametrize("small_ns", [1, 2, 3, 4, 7])
+def test_single_launch_kernel_with_several_workgroups_per_level(oracle, small_ns):
+    """The single-launch grad_value kernel with its (plane, level) work split over small_ns workgroups (chosen by the
+    launcher when few planes would leave CUs idle; forced here): every 2 x 2-pixel block is served by exactly one of
+    them whatever order each workgroup walks its blocks in — levels with fewer blocks than workgroups, odd sizes, a
+    hot cell that makes one level split its blocks over lane groups."""
+    from msda_triton_amd import _lib
+    rng = np.random.default_rng(515 + small_ns)
+    levels = [(13, 9), (6, 7), (3, 2), (1, 1)]
+    c = rand_case(rng, 2, 97, 2, 32, levels, 3, lo=-0.1, hi=1.1)
+    c["loc"][:, ::3, :, 0, :, :] = (0.41 + rng.normal(0, 0.004, size=c["loc"][:, ::3, :, 0, :, :].shape)).astype(np.float32)
+    try:
+        _lib.set_option("value_path", 3)
+        _lib.set_option("small_ns", small_ns)
+        for pm, ac in (("zeros", False), ("border", True)):
+            check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float32], BWD_TOL[torch.float32])
+    finally:
+        _lib.set_option("small_ns", 0)
+        _lib.set_option("value_path", 0)
+
+
 @pytest.mark.parametrize("td", [torch.float32, torch.float64, torch.bfloat16], ids=["f32", "f64", "bf16"])
 def test_sorted_grad_value_in_query_rounds(oracle, td):
     """Very large Q is served in rounds over the queries (a plane's grad_out rows stay in L2; running sums in the

@@ -52,7 +52,7 @@ while time.time() - t0 < budget:
         c["loc"][m] = (hot + rng.normal(0, 0.002, size=(int(m.sum()), 2))).astype(c["loc"].dtype)
     td = torch.float64 if f64 else torch.float32
     opts = {"value_path": int(rng.choice([0, 2, 3])), "deterministic": int(rng.integers(0, 2)),
-            "q_round": int(rng.choice([0, 0, 0, max(1, Q // 3)]))}
+            "q_round": int(rng.choice([0, 0, 0, max(1, Q // 3)])), "small_ns": int(rng.choice([0, 0, 1, 2, 3, 5]))}
     desc = dict(seed=seed, B=B, Q=Q, H=H, D=D, levels=levels, P=P, range=(lo, hi), pm=pm, ac=ac, f64=f64, **opts)
     try:
         for k, v in opts.items():
