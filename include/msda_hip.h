@@ -154,9 +154,9 @@ MSDA_API const char *msda_last_error(void);
  *                   (small problems; no workspace needed), else by the sorted gather in the caller's workspace
  *                2: the sorted gather always   3: the single-launch kernel whenever it fits
  *   "overlap"    -1 (default): grad_loc/grad_attn run on a forked side stream next to grad_value where that was
- *                   measured to pay (next to the single-launch kernel from ~800k samples; next to the sorted pipeline
- *                   from 4M samples when rows have >= 128 bytes): the fork/join itself costs ~14 us of host time and
- *                   ~19 us of latency;  0: never;  1: always
+ *                   measured to pay (next to the sorted pipeline from 4M samples when rows have >= 128 bytes; never
+ *                   next to the single-launch kernel): the fork/join itself costs ~14 us of host time and ~19 us of
+ *                   latency;  0: never;  1: always
  *   "deterministic" 0 (default): grad_value may differ in the last bit from run to run (the order of the records inside
  *                   a cell's list follows the order in which LDS atomics retire; the reference's global atomics have
  *                   the same property); out, grad_loc and grad_attn are always bitwise reproducible

@@ -580,13 +580,14 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     // The fork/join is not free: two event record/wait pairs cost ~14 us of host time and ~19 us of GPU-side
     // latency per backward on this runtime (tools/anyorder_probe.hip; hipExtAnyOrderLaunch, the in-stream
     // alternative, is ignored on gfx9), more under the autograd engine.  Measured fwd+bwd with / without (us,
-    // tools/overlap_matrix.sh): c1 85 / 44, c2 @ 1k 116 / 77, c4 with B=4 76 / 70, c2 @ 2k 138 / 134, @ 3k and
-    // @ 5k equal, c4 (B=8) 116 / 129, c4 with B=16 221 / 225, c2 @ 10k -3.5 %, c5 -0.3 %; with 64-byte rows (c3)
-    // +2 %.  So by default: next to the single-launch grad_value kernel (which leaves most CUs idle most of its
-    // time) from ~800k samples, next to the sorted pipeline (place pass bound by L2 write requests, sample kernel by
-    // the vector-memory path) from 4M samples when rows are at least 128 bytes.
+    // tools/overlap_matrix.sh, round 3 kernels): c2 @ 1k 83 / 65, c4 with B=4 82 / 72, c4 (B=8) 115 / 105, c2 @ 2k
+    // 132 / 127, @ 3k 165 / 163, @ 5k equal, c4 with B=16 196 / 194, B=32 equal, B=64 938 / 925; c2 @ 10k -3.5 %,
+    // c5 -0.3 %; with 64-byte rows (c3) +2 %.  So by default: never next to the single-launch grad_value kernel
+    // (until round 3 it left most CUs idle behind one slow workgroup and the fork paid from ~800k samples), next to
+    // the sorted pipeline (place pass bound by L2 write requests, sample kernel by the vector-memory path) from 4M
+    // samples when rows are at least 128 bytes.
     const int ov = option_overlap();
-    const bool ov_auto = small_path_chosen<T>(d) ? ns >= 800000 : (ns >= 4000000 && D * (int64_t)sizeof(T) >= 128);
+    const bool ov_auto = !small_path_chosen<T>(d) && ns >= 4000000 && D * (int64_t)sizeof(T) >= 128;
     if (want_sample && want_value && (ov == 1 || (ov < 0 && ov_auto))) {
         hipStream_t side = side_stream_fork(stream);
         if (side != nullptr) {

@@ -512,46 +512,54 @@ def test_graph_capture_replays():
     assert torch.equal(grads[1], eager_g[1]) and torch.equal(grads[2], eager_g[2])
 
 
-def test_graph_capture_replays_at_c4_size_with_the_side_stream_fork():
-    """Grounding-DINO decoder size (c4: 921 600 samples): the backward forks the sample-gradient kernel onto the side
-    stream next to the single-launch grad_value kernel (overlap on by default from 800k samples).  The fork / join is
-    event-based, so the pair still captures into one hipGraph; replays give the eager results."""
+@pytest.mark.parametrize("wl_name,force", [("c4_gdino_dec", True), ("c2_q10k", False)], ids=["c4_forced", "c2_q10k_default"])
+def test_graph_capture_replays_with_the_side_stream_fork(wl_name, force):
+    """The backward with the sample-gradient kernel forked onto the side stream still captures into one hipGraph (the
+    fork / join is event-based); replays give the eager results.  At the Grounding-DINO decoder size (c4: 921 600
+    samples, single-launch grad_value kernel) the fork is forced — since round 3 it no longer pays there and is off by
+    default; at c2 @ 10k (5.1 M samples, sorted pipeline with its caller-side workspace) it is on by default."""
     from msda_triton_amd import _lib, synth
     ops = _ops()
-    assert _lib.get_option("overlap") == -1  # automatic: on at this size
-    wl = synth.WORKLOADS["c4_gdino_dec"]
+    assert _lib.get_option("overlap") == -1  # automatic
+    wl = synth.WORKLOADS[wl_name]
     d = synth.make_inputs_torch(wl, DEV, seed=3)
     v, l, a, g, s = d["value"], d["loc"], d["attn"], d["grad_out"], d["shapes"]
-    eager = ops.msda_hip_fwd(v, s, l, a, wl.padding_mode, wl.align_corners)
-    eager_g = ops.msda_hip_bwd(g, v, s, l, a, wl.padding_mode, wl.align_corners)  # (also creates this thread's side stream)
-    torch.cuda.synchronize()
-    cap = torch.cuda.Stream()
-    cap.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(cap):
-        ops.msda_hip_bwd(g, v, s, l, a, wl.padding_mode, wl.align_corners)  # warm-up on the capture stream
-    torch.cuda.current_stream().wait_stream(cap)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        out = ops.msda_hip_fwd(v, s, l, a, wl.padding_mode, wl.align_corners)
-        grads = ops.msda_hip_bwd(g, v, s, l, a, wl.padding_mode, wl.align_corners)
-    for _ in range(3):
-        out.zero_()
-        for t in grads:
-            t.zero_()
-        graph.replay()
+    try:
+        if force:
+            _lib.set_option("overlap", 1)
+        eager = ops.msda_hip_fwd(v, s, l, a, wl.padding_mode, wl.align_corners)
+        eager_g = ops.msda_hip_bwd(g, v, s, l, a, wl.padding_mode, wl.align_corners)  # (also creates this thread's side stream)
         torch.cuda.synchronize()
-        assert torch.equal(out, eager)
-        torch.testing.assert_close(grads[0], eager_g[0], atol=1e-4, rtol=1e-4)
-        assert torch.equal(grads[1], eager_g[1]) and torch.equal(grads[2], eager_g[2])
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            ops.msda_hip_bwd(g, v, s, l, a, wl.padding_mode, wl.align_corners)  # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(cap)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = ops.msda_hip_fwd(v, s, l, a, wl.padding_mode, wl.align_corners)
+            grads = ops.msda_hip_bwd(g, v, s, l, a, wl.padding_mode, wl.align_corners)
+        for _ in range(3):
+            out.zero_()
+            for t in grads:
+                t.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, eager)
+            torch.testing.assert_close(grads[0], eager_g[0], atol=1e-4, rtol=1e-4)
+            assert torch.equal(grads[1], eager_g[1]) and torch.equal(grads[2], eager_g[2])
+    finally:
+        _lib.set_option("overlap", -1)
 
 
 def test_two_host_threads_run_backwards_on_one_device():
     """Autograd worker threads / user threads with their own streams: each host thread has its own side stream and
     event pair (msda_api.hip), so concurrent backwards cannot wait on each other's fork records.  Two threads, each on
-    its own stream, c4-sized problems (fork/join on) with different data: both get their own eager results."""
+    its own stream, c4-sized problems (fork/join forced on) with different data: both get their own eager results."""
     import threading
-    from msda_triton_amd import synth
+    from msda_triton_amd import _lib, synth
     ops = _ops()
+    _lib.set_option("overlap", 1)
     wl = synth.WORKLOADS["c4_gdino_dec"]
     data = [synth.make_inputs_torch(wl, DEV, seed=20 + i) for i in range(2)]
     want = [ops.msda_hip_bwd(d["grad_out"], d["value"], d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
@@ -575,10 +583,13 @@ def test_two_host_threads_run_backwards_on_one_device():
             errs.append(e)
 
     ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
+    try:
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        _lib.set_option("overlap", -1)
     assert not errs, errs
     for i in range(2):
         torch.testing.assert_close(got[i][0], want[i][0], atol=1e-4, rtol=1e-4)
