@@ -238,12 +238,26 @@ def bench_config(name, dev, steps=20, warmup=5):
     for _ in range(warmup):
         fwd_only()
     ms_fwd = timed(fwd_only, steps)
+    # the same kernels through the launcher API (msda_hip_fwd / msda_hip_bwd: no autograd engine, grad_out given):
+    # what the step costs a caller that drives the C ABI itself; the difference to fwd_bwd_ms is PyTorch's engine
+    # start-up, three AccumulateGrad nodes and rand_like
+    from msda_triton_amd.functional import msda_hip_bwd, msda_hip_fwd
+    go = torch.rand_like(d["grad_out"])
+    iv, ip, ia = img.detach(), pts.detach(), attn.detach()
+
+    def launchers():
+        msda_hip_fwd(iv, shapes, ip, ia, pm, ac)
+        msda_hip_bwd(go, iv, shapes, ip, ia, pm, ac)
+
+    for _ in range(warmup):
+        launchers()
+    ms_launchers = timed(launchers, steps)
     with KernelTimer() as kt:
         timed(step, steps)
     kernels = kernel_table(wl, kt.summary(), load_traffic(name))
     return {"workload": f"{wl.name}: B={wl.B} Q={wl.Q} H={wl.H} D={wl.D} L={wl.L} levels={list(wl.levels)} P={wl.P} "
                         f"{wl.dtype} {pm} align_corners={ac}",
-            "steps": steps, "fwd_ms": ms_fwd, "fwd_bwd_ms": ms_step,
+            "steps": steps, "fwd_ms": ms_fwd, "fwd_bwd_ms": ms_step, "launcher_api_fwd_bwd_ms": ms_launchers,
             "alg_fwd_bwd_GBs": round((wl.alg_fwd_bytes + wl.alg_bwd_bytes) / (ms_step * 1e-3) / 1e9, 1),
             "peak_mem_MB": round(peak / 1e6, 1), "inputs_MB": round(base / 1e6, 1), "kernels": kernels}
 
