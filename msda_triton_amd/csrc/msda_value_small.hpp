@@ -61,10 +61,36 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     LevelTab *tab = reinterpret_cast<LevelTab *>(sm);
     size_t o = (sizeof(LevelTab) + 15) / 16 * 16;
     int *s_off = reinterpret_cast<int *>(sm + o);  // [ncl + 1]
-    load_level_table(tab, p.shapes, p.L);
-    __syncthreads();
     // slot -> (level, share of the level's gather rounds)
     const int lvl = slot / p.small_ns, share = slot - lvl * p.small_ns, nshare = p.small_ns;
+    // ---- samples of this (plane, level): thread t serves point t % P of the queries t / P + k * (threads / P) ----
+    const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
+    const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
+    const T *attn = static_cast<const T *>(p.attn) + plane_s0;
+    const int HLP = p.H * p.LP;
+    const int dq = p.P <= kSmallBlock ? kSmallBlock / p.P : 1;
+    const bool active = p.P <= kSmallBlock && tid < dq * p.P;
+    const int pt = active ? tid % p.P : 0, q0 = active ? tid / p.P : 0;
+    // This thread's samples, fetched ONCE and up front — before the level table is waited for, their addresses do not
+    // need it — (both walks below reuse them): the kernel is a chain of latencies inside one workgroup, so every
+    // global round trip saved counts.  Problems this kernel is chosen for have at most kPre samples per thread;
+    // longer walks load on the spot.
+    constexpr int kPre = 4;
+    const bool pre = active && (p.Q + dq - 1) / dq <= kPre;
+    Pack<T, 2> pre_xy[kPre];
+    T pre_a[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+        pre_xy[k].v[0] = pre_xy[k].v[1] = pre_a[k] = TR::from_acc((A)0);
+        const int q = q0 + k * dq;
+        if (pre && q < p.Q) {
+            const int sidx = q * HLP + lvl * p.P + pt;
+            pre_xy[k] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+            pre_a[k] = attn[sidx];
+        }
+    }
+    load_level_table(tab, p.shapes, p.L);
+    __syncthreads();
     const int lw = tab->w[lvl], lh = tab->h[lvl], cw = lw + 1;
     const int ncl_true = (lh + 1) * cw;
     const int ncl = min(ncl_true, p.small_cells);  // (shapes that disagree with I: never index past the LDS table)
@@ -86,31 +112,6 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     for (int i = tid; i <= ncl; i += kSmallBlock) s_off[i] = 0;
     __syncthreads();
 
-    // ---- samples of this (plane, level): thread t serves point t % P of the queries t / P + k * (threads / P) ----
-    const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
-    const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
-    const T *attn = static_cast<const T *>(p.attn) + plane_s0;
-    const int HLP = p.H * p.LP;
-    const int dq = p.P <= kSmallBlock ? kSmallBlock / p.P : 1;
-    const bool active = p.P <= kSmallBlock && tid < dq * p.P;
-    const int pt = active ? tid % p.P : 0, q0 = active ? tid / p.P : 0;
-    // This thread's samples, fetched ONCE and up front (both walks below reuse them): the kernel is a chain of
-    // latencies inside one workgroup, so every global round trip saved counts.  Problems this kernel is chosen for
-    // have at most kPre samples per thread; longer walks load on the spot.
-    constexpr int kPre = 4;
-    const bool pre = active && (p.Q + dq - 1) / dq <= kPre;
-    Pack<T, 2> pre_xy[kPre];
-    T pre_a[kPre];
-#pragma unroll
-    for (int k = 0; k < kPre; ++k) {
-        pre_xy[k].v[0] = pre_xy[k].v[1] = pre_a[k] = TR::from_acc((A)0);
-        const int q = q0 + k * dq;
-        if (pre && q < p.Q) {
-            const int sidx = q * HLP + lvl * p.P + pt;
-            pre_xy[k] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
-            pre_a[k] = attn[sidx];
-        }
-    }
     auto walk = [&](auto &&visit) {  // visit(q, attention weight, in-level cell, dx, dy)
         auto one = [&](int q, const Pack<T, 2> &xy, T at) {
             int cell;
@@ -156,7 +157,11 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
         if (lane == kWave - 1) s_red[wid] = inc;
         __syncthreads();
         int base = inc - sum;
-        for (int i = 0; i < wid; ++i) base += s_red[i];
+#pragma unroll
+        for (int i = 0; i < kSmallBlock / kWave; ++i) {  // (fixed trip count: the 16 reads go out together)
+            const int n = s_red[i];
+            base += i < wid ? n : 0;
+        }
         for (int c = c_beg; c < c_end; ++c) {
             const int n = s_off[c];
             s_off[c] = base;
