@@ -274,7 +274,7 @@ def compare(wl_name, dev, steps=20, warmup=5):
     from msda_triton_amd import synth
     from msda_triton_amd.functional import multiscale_deformable_attention as hip_msda
 
-    wl = synth.WORKLOADS[wl_name]
+    wl = synth.WORKLOADS[wl_name] if isinstance(wl_name, str) else wl_name  # (a synth.Workload works too)
     d = synth.make_inputs_torch(wl, dev, dtype=torch.float32)
     go = d.pop("grad_out")
     args = (d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
