@@ -74,7 +74,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 7
+#define MSDA_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define MSDA_API __attribute__((visibility("default")))
@@ -138,6 +138,19 @@ MSDA_API int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H,
  * MSDA_ERR_UNSUPPORTED and the caller composes the prologue around msda_fwd_/msda_bwd_<dtype>). */
 MSDA_API int64_t msda_fused_lp_limit(int64_t D, int elem_size);
 
+/*
+ * The pyramid's level sizes live on the device (`shapes`), so the library sizes the single-launch grad_value kernel's
+ * LDS cell table for the worst level `I` pixels can form, (2 I + 2 L) cells — which rules that kernel out for the
+ * pyramids of real images (a 100 x 134 ... 13 x 17 pyramid: 35.6 k cells by the bound, 13.6 k in its largest level) and
+ * sends decoder-sized calls on them to the sorted pipeline, 1.4x slower there.  A caller that knows the level sizes on
+ * the host (Hugging Face models carry `spatial_shapes_list`) can promise a bound: no level of the calls that follow ON
+ * THIS THREAD has more than `max_level_cells` bilinear cells, (h + 1) * (w + 1).  0 withdraws the promise (default).
+ * msda_bwd_workspace_bytes and msda_bwd_<dtype> must see the same promise (autograd runs the backward on its own
+ * thread: set it there).  A broken promise cannot be reported from the kernel: the affected level's grad_value rows
+ * are returned as NaN.  msda_set_option("level_cells", n) is the same promise process-wide (a thread's own wins).
+ */
+MSDA_API void msda_hint_level_cells(int64_t max_level_cells);
+
 /* ABI version of the loaded library (== MSDA_ABI_VERSION it was built with). */
 MSDA_API int msda_abi_version(void);
 
@@ -163,6 +176,7 @@ MSDA_API const char *msda_last_error(void);
  *                1: bitwise reproducible grad_value: the place pass runs one wave per query slice and ranks the samples
  *                   of a cell by index (no atomics at all); small problems take the sorted pipeline too (workspace
  *                   needed); slower
+ *   "level_cells" 0 (default): unknown;  n: process-wide form of msda_hint_level_cells(n)
  *   "cell_slices", "small_ns", "gather_win", "wg_target", "debug": experiment knobs, see
  *                msda_triton_amd/csrc/msda_launch.hpp and msda_value_sorted.hpp
  */

@@ -15,7 +15,7 @@ LIB_NAME = "libmsda_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PADDING_MODES = {"border": 0, "zeros": 1}
 # one storage type for every tensor, then the mixed ones: value / grad_value in 16 bits, everything else fp32
 DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64", "f32_vbf16", "f32_vf16")
@@ -24,7 +24,7 @@ DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64", "f32_vbf16", "f32_vf16")
 EXPORTED_SYMBOLS = tuple(
     [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused", "bwd_fused") for s in DTYPE_SUFFIXES]
     + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option", "msda_bwd_workspace_bytes",
-       "msda_bwd_fused_workspace_bytes", "msda_fused_lp_limit"]
+       "msda_bwd_fused_workspace_bytes", "msda_fused_lp_limit", "msda_hint_level_cells"]
 )
 
 _lib = None
@@ -84,6 +84,8 @@ def load():
         lib.msda_bwd_fused_workspace_bytes.argtypes = [i64] * 7 + [ci]
         lib.msda_fused_lp_limit.restype = i64
         lib.msda_fused_lp_limit.argtypes = [i64, ci]
+        lib.msda_hint_level_cells.restype = None
+        lib.msda_hint_level_cells.argtypes = [i64]
         lib.msda_abi_version.restype = ci
         lib.msda_last_error.restype = ctypes.c_char_p
         lib.msda_set_option.restype = ci

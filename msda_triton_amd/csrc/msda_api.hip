@@ -18,6 +18,7 @@ static std::atomic<int> g_cell_slices{0};
 static std::atomic<int> g_debug{0};
 static std::atomic<int> g_small_ns{0};
 static std::atomic<int> g_q_round{0};
+static std::atomic<int> g_level_cells{0};
 static std::atomic<int> g_overlap{-1};
 static std::atomic<int> g_gather_win{0};
 static std::atomic<int> g_deterministic{0};
@@ -79,6 +80,14 @@ int option_cell_slices() { return g_cell_slices.load(std::memory_order_relaxed);
 int option_debug() { return g_debug.load(std::memory_order_relaxed); }
 int option_small_ns() { return g_small_ns.load(std::memory_order_relaxed); }
 int option_q_round() { return g_q_round.load(std::memory_order_relaxed); }
+static thread_local int64_t t_level_cells = 0;  // msda_hint_level_cells: this thread's promise for the calls that follow
+int option_level_cells()
+{
+    const int64_t t = t_level_cells;
+    if (t > 0) return t > 0x7fffffff ? 0x7fffffff : (int)t;
+    return g_level_cells.load(std::memory_order_relaxed);
+}
+void set_thread_level_cells(int64_t n) { t_level_cells = n > 0 ? n : 0; }
 int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
 int option_gather_win() { return g_gather_win.load(std::memory_order_relaxed); }
 int option_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
@@ -94,6 +103,8 @@ void set_error(const char *fmt, ...)
 }  // namespace msda
 
 extern "C" int msda_abi_version(void) { return MSDA_ABI_VERSION; }
+
+extern "C" void msda_hint_level_cells(int64_t max_level_cells) { msda::set_thread_level_cells(max_level_cells); }
 
 // the layout lives in a device header (msda_value_sorted.hpp); msda_f32.hip exposes its size formula
 extern "C" int64_t msda_bwd_workspace_bytes_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
@@ -133,6 +144,10 @@ extern "C" int msda_set_option(const char *key, int value)
     }
     if (key && strcmp(key, "debug") == 0) {
         msda::g_debug.store(value, std::memory_order_relaxed);
+        return 0;
+    }
+    if (key && strcmp(key, "level_cells") == 0 && value >= 0) {
+        msda::g_level_cells.store(value, std::memory_order_relaxed);
         return 0;
     }
     if (key && strcmp(key, "q_round") == 0 && value >= 0) {
@@ -176,6 +191,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "debug") == 0) return msda::option_debug();
     if (key && strcmp(key, "small_ns") == 0) return msda::option_small_ns();
     if (key && strcmp(key, "q_round") == 0) return msda::option_q_round();
+    if (key && strcmp(key, "level_cells") == 0) return msda::option_level_cells();
     if (key && strcmp(key, "overlap") == 0) return msda::option_overlap();
     if (key && strcmp(key, "gather_win") == 0) return msda::option_gather_win();
     if (key && strcmp(key, "deterministic") == 0) return msda::option_deterministic();

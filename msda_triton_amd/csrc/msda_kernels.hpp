@@ -66,6 +66,7 @@ struct Params {
     void *ws_accum;     // [pairs][I][D] acc-typed running sums between rounds (nullptr: a single round)
     int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
     int small_ns;       // ... workgroups per (plane, level)
+    int small_hinted;   // ... small_cells is the caller's promise (msda_hint_level_cells), not the bound from I
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char msda_smem[];

@@ -16,6 +16,7 @@ int option_xcd_map();
 int option_value_path();  // 0: auto (single-launch LDS kernel when a plane-level fits, else sorted gather), 2: sorted, 3: single-launch
 int option_wg_target();     // gather workgroups to aim for when choosing query chunks per workgroup
 int option_small_ns();      // workgroups per (plane, level) of the single-launch grad_value kernel (0: automatic)
+int option_level_cells();   // caller's promise: no level has more than this many bilinear cells (0: unknown)
 int option_q_round();       // queries per round of the sorted grad_value path (0: automatic)
 int option_debug();         // dev-only ablation mask
 int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream; 0: never; -1: automatic
@@ -423,11 +424,18 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
 }
 
 // ---- single-launch grad_value for small problems (msda_value_small.hpp) ----
+// Cells the kernel's LDS table must hold: the largest level's (h + 1)(w + 1).  The level sizes live on the device, so
+// without a promise from the caller the bound is what I pixels can make of one level: 2 I + 2 L.
+inline int64_t small_cell_cap(const Dims &d)
+{
+    const int64_t bound = 2 * d.I + 2 * d.L, hint = option_level_cells();
+    return hint > 0 && hint < bound ? hint : bound;
+}
 template <typename T> inline size_t small_need_bytes(const Dims &d, bool vec)
 {
     using A = typename Traits<T>::acc;
     const size_t vecw = vec ? 16 / sizeof(T) : 1;
-    return small_lds_bytes((size_t)(2 * d.I + 2 * d.L), (size_t)(d.Q * d.P), sizeof(A), vecw);
+    return small_lds_bytes((size_t)small_cell_cap(d), (size_t)(d.Q * d.P), sizeof(A), vecw);
 }
 
 template <typename T, int VEC, int G, typename TV = T> inline int launch_value_small(Params &p, size_t lds, hipStream_t stream)
@@ -459,7 +467,8 @@ template <typename T, typename TV = T> inline int run_value_small(Params &p, con
 {
     constexpr int VECF = 16 / sizeof(T);
     const bool vec_ok = value_vec_ok<T>(p);
-    p.small_cells = (int)(2 * d.I + 2 * d.L);
+    p.small_cells = (int)small_cell_cap(d);
+    p.small_hinted = p.small_cells < 2 * d.I + 2 * d.L;
     // workgroups per (plane, level): fill the 256 CUs when there are few planes; two when the planes just fill them
     // (a level's workgroups then finish at different times and the busiest level no longer sets the pace)
     const int64_t wgs = d.B * d.H * d.L;

@@ -79,12 +79,27 @@ torch::autograd::variable_list once_differentiable(const torch::autograd::variab
     return (*err)(std::move(outs));
 }
 
+struct LevelCellsHint {
+    const int64_t n;
+    explicit LevelCellsHint(int64_t cells) : n(cells)
+    {
+        if (n > 0) msda_hint_level_cells(n);
+    }
+    ~LevelCellsHint()
+    {
+        if (n > 0) msda_hint_level_cells(0);
+    }
+    LevelCellsHint(const LevelCellsHint &) = delete;
+    LevelCellsHint &operator=(const LevelCellsHint &) = delete;
+};
+
 void *current_stream(const at::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
 class MSDAFunction : public torch::autograd::Function<MSDAFunction> {
 public:
     static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &img_, const at::Tensor &shapes_,
-                              const at::Tensor &pts_, const at::Tensor &att_, int64_t padding_mode, bool align_corners)
+                              const at::Tensor &pts_, const at::Tensor &att_, int64_t padding_mode, bool align_corners,
+                              int64_t level_cells)
     {
         const at::Tensor img = img_.contiguous(), pts = pts_.contiguous(), att = att_.contiguous();
         const at::Tensor shapes = shapes_.to(at::kLong).contiguous();  // stays on the device
@@ -99,6 +114,7 @@ public:
         ctx->save_for_backward({img, shapes, pts, att});
         ctx->saved_data["padding_mode"] = padding_mode;
         ctx->saved_data["align_corners"] = align_corners;
+        ctx->saved_data["level_cells"] = level_cells;
         return out;
     }
 
@@ -109,6 +125,9 @@ public:
         const at::Tensor &img = saved[0], &shapes = saved[1], &pts = saved[2], &att = saved[3];
         const int padding_mode = (int)ctx->saved_data["padding_mode"].toInt();
         const bool align_corners = ctx->saved_data["align_corners"].toBool();
+        // the caller's promise about the level sizes (msda_hint_level_cells): for the workspace query and the launch
+        // on THIS thread (the autograd engine's), withdrawn when the scope ends
+        const LevelCellsHint hint(ctx->saved_data["level_cells"].toInt());
         at::Tensor gout = grads[0].contiguous();
         if (gout.scalar_type() != pts.scalar_type()) gout = gout.to(pts.scalar_type());
         const bool want_value = ctx->needs_input_grad(0);
@@ -136,7 +155,8 @@ public:
                      "msda_bwd");
         }
         return once_differentiable(grads, {g_img, at::Tensor(), ctx->needs_input_grad(2) ? g_pts : at::Tensor(),
-                                           ctx->needs_input_grad(3) ? g_att : at::Tensor(), at::Tensor(), at::Tensor()});
+                                           ctx->needs_input_grad(3) ? g_att : at::Tensor(), at::Tensor(), at::Tensor(),
+                                           at::Tensor()});
     }
 };
 
@@ -202,9 +222,9 @@ public:
 };
 
 at::Tensor msda(const at::Tensor &img, const at::Tensor &shapes, const at::Tensor &pts, const at::Tensor &att,
-                int64_t padding_mode, bool align_corners)
+                int64_t padding_mode, bool align_corners, int64_t level_cells)
 {
-    return MSDAFunction::apply(img, shapes, pts, att, padding_mode, align_corners);
+    return MSDAFunction::apply(img, shapes, pts, att, padding_mode, align_corners, level_cells);
 }
 
 at::Tensor msda_fused(const at::Tensor &img, const at::Tensor &shapes, const at::Tensor &proj, const at::Tensor &ref,
@@ -218,7 +238,9 @@ at::Tensor msda_fused(const at::Tensor &img, const at::Tensor &shapes, const at:
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "C++ autograd glue over libmsda_hip.so (same C ABI as the ctypes route)";
-    m.def("msda", &msda, "multi-scale deformable attention (forward; differentiable)");
+    m.def("msda", &msda, "multi-scale deformable attention (forward; differentiable)", pybind11::arg("img"),
+          pybind11::arg("shapes"), pybind11::arg("sampling_points"), pybind11::arg("attention_weights"),
+          pybind11::arg("padding_mode"), pybind11::arg("align_corners"), pybind11::arg("level_cells") = 0);
     m.def("msda_fused", &msda_fused, "module core with the softmax / sampling-point prologue fused in (differentiable)");
     m.def("fused_lp_limit", [](int64_t D, int64_t elem_size) { return msda_fused_lp_limit(D, (int)elem_size); });
     m.def("abi_version", []() { return msda_abi_version(); });

@@ -96,6 +96,19 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     const int ncl = min(ncl_true, p.small_cells);  // (shapes that disagree with I: never index past the LDS table)
     const int npix = lw * lh;
     const int pstart = tab->start[lvl];
+    if (p.small_hinted && ncl_true > p.small_cells) {
+        // The caller promised smaller levels than this one (msda_hint_level_cells) and the table was sized on that
+        // promise: there is no way to report it from here, so the level's rows come back as NaN instead of wrong.
+        if (share == 0) {
+            const A nan = (A)__builtin_nanf("");
+            for (long long e = tid; e < (long long)npix * p.D; e += kSmallBlock) {
+                const int px = (int)(e / p.D), c = (int)(e - (long long)px * p.D);
+                if (pstart + px < p.I)
+                    static_cast<TV *>(p.grad_value)[(((size_t)b * p.I + pstart + px) * p.H + h) * p.D + c] = TVR::from_acc(nan);
+            }
+        }
+        return;  // (uniform in the workgroup)
+    }
     o += ((size_t)p.small_cells + 1) * 4;
     o = (o + 15) / 16 * 16;
     SmallRec<A> *s_rec = reinterpret_cast<SmallRec<A> *>(sm + o);
@@ -252,8 +265,7 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     int lgS = 0;  // S = 1 << lgS
     while ((1 << lgS) < SMAX && ((s_maxtot + (1 << lgS) - 1) >> lgS) > 64) ++lgS;
     const int S = 1 << lgS;
-    const int items = nown * S;
-    const int rounds = (items + NG - 1) / NG;
+    __shared__ int s_busy;  // blocks of this workgroup with at least one record: the gather's share of s_order
     {
         auto block_class = [&](int blk) {
             int lcum[10];
@@ -270,6 +282,7 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
                 s_cls[c] = run;
                 run += n;
             }
+            s_busy = s_cls[kClasses - 1];  // the last class: no batch at all, i.e. no record
         }
         __syncthreads();
         for (int i = tid; i < nown; i += kSmallBlock) {
@@ -278,6 +291,26 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
         }
         __syncthreads();
     }
+    // Blocks nobody sampled (most of a fine level when the queries are few: a 100 x 134 level under 900 x 4 samples)
+    // take no part in the gather rounds: their rows are zeros, stored here by all threads, 16 bytes at a time.
+    const int nbusy = s_busy;
+    {
+        const int cpr = (p.D + VEC - 1) / VEC;  // stores per row
+        const int total = (nown - nbusy) * 4 * cpr;  // (< 2^16 blocks, rows of at most a few hundred stores)
+        Pack<TV, VEC> zero;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) zero.v[i] = TVR::from_acc((A)0);
+        for (int e = tid; e < total; e += kSmallBlock) {
+            const int row = (int)((unsigned)e / (unsigned)cpr), c0 = (e - row * cpr) * VEC;
+            const int blk = (int)s_order[nbusy + (row >> 2)], k = row & 3;
+            const int by = div_small(blk, max(nbx, 1), inv_nbx), bx = blk - by * nbx;
+            const int px = 2 * bx + (k & 1), py = 2 * by + (k >> 1);
+            if (px < lw && py < lh && pstart + py * lw + px < p.I && c0 < p.D)
+                store_stream(static_cast<TV *>(p.grad_value) + (((size_t)b * p.I + pstart + py * lw + px) * p.H + h) * p.D + c0, zero);
+        }
+    }
+    const int items = nbusy * S;
+    const int rounds = (items + NG - 1) / NG;
     for (int r = 0; r < rounds; ++r) {
         const int item = r * NG + unit;
         const bool live = item < items;

@@ -206,11 +206,29 @@ def msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mo
     return out
 
 
+def level_cells_of(level_shapes) -> int:
+    """``level_shapes``: the pyramid's (height, width) pairs AS HOST NUMBERS (e.g. Hugging Face's
+    ``spatial_shapes_list``), or None.  Returns the bound ``msda_hint_level_cells`` takes — the bilinear cells of the
+    largest level, (h + 1) * (w + 1) — or 0 for "unknown".  With it the backward can use its single-launch grad_value
+    kernel on decoder-sized calls over real-image pyramids (include/msda_hip.h); it must describe the same pyramid as
+    the ``img_shapes`` tensor (a level larger than promised gets NaN gradients)."""
+    if level_shapes is None:
+        return 0
+    if isinstance(level_shapes, torch.Tensor):
+        if level_shapes.device.type != "cpu":
+            raise ValueError("`level_shapes` should be host numbers (a device tensor would need a synchronisation); "
+                             "pass e.g. `spatial_shapes_list`")
+        level_shapes = level_shapes.tolist()
+    return max(((int(h) + 1) * (int(w) + 1) for h, w in level_shapes), default=0)
+
+
 def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners,
                  needs: Tuple[bool, bool, bool] = (True, True, True),
                  out: Optional[Tuple[Optional[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]] = None,
+                 level_cells: int = 0,
                  ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
     """Returns ``(img_grad, sampling_points_grad, attention_weights_grad)``; entries not in ``needs`` are None.
+    ``level_cells``: see :func:`level_cells_of` (0: unknown).
 
     Gradients are allocated contiguous (the reference's ``zeros_like(...).contiguous()`` would write
     into a temporary for permuted inputs, kernels.py:570-578) and are fully written by the kernels,
@@ -250,8 +268,11 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
         lib = _lib.load()
         fn = getattr(lib, f"msda_bwd_{suf}")
         ws, ws_bytes = None, 0
+        level_cells = int(level_cells)
+        if level_cells > 0:  # this thread's promise for the size query and the launch below; withdrawn afterwards
+            lib.msda_hint_level_cells(level_cells)
         if want_value:  # scratch for the inverted index; the caching allocator makes this cheap
-            key = (B, I, H, D, Q, L, P, sampling_points.element_size(), _lib.OPTION_EPOCH)
+            key = (B, I, H, D, Q, L, P, sampling_points.element_size(), _lib.OPTION_EPOCH, level_cells)
             ws_bytes = _WS_BYTES.get(key)
             if ws_bytes is None:
                 ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes(*key[:8]))
@@ -267,16 +288,20 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
                       ws.data_ptr() if (ws is not None and value_part) else None, ws_bytes,
                       _stream_ptr(img.device))
 
-        with _OnDevice(img.device):
-            timer = KernelTimer.active
-            if timer is None:
-                rc = call(want_value, want_sample)
-            else:  # one C-ABI call per kernel so each gets its own event pair
-                rc = 0
-                if want_sample:
-                    rc = timer.launch("msda_bwd_sample", img.device, lambda: call(False, True))
-                if rc == 0 and want_value:
-                    rc = timer.launch("msda_bwd_value", img.device, lambda: call(True, False))
+        try:
+            with _OnDevice(img.device):
+                timer = KernelTimer.active
+                if timer is None:
+                    rc = call(want_value, want_sample)
+                else:  # one C-ABI call per kernel so each gets its own event pair
+                    rc = 0
+                    if want_sample:
+                        rc = timer.launch("msda_bwd_sample", img.device, lambda: call(False, True))
+                    if rc == 0 and want_value:
+                        rc = timer.launch("msda_bwd_value", img.device, lambda: call(True, False))
+        finally:
+            if level_cells > 0:
+                lib.msda_hint_level_cells(0)
         _lib.check(rc, f"msda_bwd_{suf}")
     return g_img, (g_pts if needs[1] else None), (g_att if needs[2] else None)
 
@@ -288,10 +313,11 @@ class _HipMultiscaleDeformableAttentionFunction(Function):
 
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # under autocast the op runs in fp32 (frontend.py:111)
-    def forward(ctx, img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners):
+    def forward(ctx, img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners, level_cells=0):
         ctx.save_for_backward(img, img_shapes, sampling_points, attention_weights)
         ctx.padding_mode = padding_mode
         ctx.align_corners = align_corners
+        ctx.level_cells = int(level_cells)
         return msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners)
 
     @staticmethod
@@ -302,8 +328,8 @@ class _HipMultiscaleDeformableAttentionFunction(Function):
         needs = (ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3])
         g_img, g_pts, g_att = msda_hip_bwd(
             out_grad, img, img_shapes, sampling_points, attention_weights,
-            ctx.padding_mode, ctx.align_corners, needs)
-        return g_img, None, g_pts, g_att, None, None
+            ctx.padding_mode, ctx.align_corners, needs, level_cells=ctx.level_cells)
+        return g_img, None, g_pts, g_att, None, None, None
 
 
 def hip_multiscale_deformable_attention(
@@ -313,9 +339,11 @@ def hip_multiscale_deformable_attention(
     attention_weights: torch.Tensor,
     padding_mode: Literal["border", "zeros"],
     align_corners: bool,
+    level_shapes=None,
 ) -> torch.Tensor:
     """GPU path.  Same contract as the reference's ``triton_multiscale_deformable_attention``
-    (frontend.py:71-105): ``ValueError`` on unsupported dtype or non-GPU inputs."""
+    (frontend.py:71-105): ``ValueError`` on unsupported dtype or non-GPU inputs.  ``level_shapes`` (an addition): the
+    pyramid's (h, w) pairs as host numbers, see :func:`level_cells_of`."""
     for name, t in (("img", img), ("sampling_points", sampling_points), ("attention_weights", attention_weights)):
         if t.dtype not in VALID_DTYPES:
             raise ValueError(f"Dtype of `{name}` should be in {list(VALID_DTYPES)}, but got {t.dtype}.")
@@ -337,9 +365,10 @@ def hip_multiscale_deformable_attention(
         _dims(img, sampling_points, attention_weights, img_shapes)
         _shapes_i64(img_shapes)
         return ext.msda(img, img_shapes, sampling_points, attention_weights, _padding_code(padding_mode),
-                        bool(align_corners))
+                        bool(align_corners), level_cells_of(level_shapes))
     return _HipMultiscaleDeformableAttentionFunction.apply(
-        img, img_shapes, sampling_points, attention_weights, padding_mode, bool(align_corners))
+        img, img_shapes, sampling_points, attention_weights, padding_mode, bool(align_corners),
+        level_cells_of(level_shapes))
 
 
 # ------------------------------------------------------------------------------------------
@@ -624,6 +653,7 @@ def multiscale_deformable_attention(
     attention_weights: torch.Tensor,
     padding_mode: Literal["border", "zeros"],
     align_corners: bool,
+    level_shapes=None,
 ) -> torch.Tensor:
     """Differentiable multiscale deformable attention.
 
@@ -636,6 +666,10 @@ def multiscale_deformable_attention(
         attention_weights: ``[batch, num_queries, num_heads, num_levels, num_points]``.
         padding_mode: ``"border"`` (clamp to the nearest pixel) or ``"zeros"``.
         align_corners: grid alignment, as in ``torch.nn.functional.grid_sample``.
+        level_shapes: optional, not in the reference — the same (height, width) pairs as HOST numbers (e.g. Hugging
+            Face's ``spatial_shapes_list``).  ``img_shapes`` lives on the device and is never read back, so without
+            this the backward must assume the largest level ``num_image`` pixels can form; with it, decoder-sized
+            calls over real-image pyramids take the single-launch grad_value kernel (see :func:`level_cells_of`).
 
     Returns:
         ``[batch, num_queries, num_heads, num_channels]``.
@@ -645,6 +679,6 @@ def multiscale_deformable_attention(
     """
     if img.device.type == "cuda":
         return hip_multiscale_deformable_attention(
-            img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners)
+            img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners, level_shapes)
     return native_multiscale_deformable_attention(
         img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners)

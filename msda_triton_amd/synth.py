@@ -102,6 +102,9 @@ WORKLOADS = {
     # configs[4]: stress
     "c5_stress": Workload("c5_stress", 4, 100000, 8, 64,
                           ((128, 128), (64, 64), (32, 32), (16, 16), (8, 8)), 8, "float16", "zeros", False),
+    # not a BASELINE config: the c4 decoder shape on the pyramid of an 800 x 1066 image (c3's levels) — what a
+    # Grounding-DINO / Deformable-DETR decoder layer sees at COCO size (tools/, profiles/: "dec_coco")
+    "dec_coco": Workload("dec_coco", 8, 900, 8, 32, ((100, 134), (50, 67), (25, 34), (13, 17)), 4, "float32", "zeros", False),
     # not BASELINE configs: tiny shapes for `bench.py --backend gloo --device cpu` (control-flow rehearsal of the
     # multi-GPU bench on a box without GPUs; the numbers mean nothing)
     "dryrun": Workload("dryrun", 2, 48, 2, 8, ((6, 5), (3, 3)), 2, "float32", "border", True),

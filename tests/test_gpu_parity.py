@@ -896,6 +896,70 @@ def test_single_launch_kernel_with_several_workgroups_per_level(oracle, small_ns
         _lib.set_option("value_path", 0)
 
 
+def test_level_shapes_hint_opens_the_single_launch_kernel_on_image_sized_pyramids(oracle):
+    """`level_shapes=` (the pyramid's sizes as host numbers, e.g. Hugging Face's spatial_shapes_list) promises the
+    library a bound on the largest level's bilinear cells (msda_hint_level_cells): a decoder-sized call over a pyramid
+    whose 2 I + 2 L worst case does not fit the single-launch grad_value kernel's LDS then takes that kernel (no
+    workspace) instead of the sorted pipeline — same results, both routes (C++ binding and ctypes), and the promise is
+    withdrawn after the call."""
+    from msda_triton_amd import _lib
+    from msda_triton_amd.functional import level_cells_of, msda_hip_bwd
+    ops = _ops()
+    levels = [(100, 134), (50, 67), (25, 34), (13, 17)]  # an 800 x 1066 image; I = 17 821
+    B, Q, H, D, P = 1, 60, 2, 32, 4
+    rng = np.random.default_rng(77)
+    c = rand_case(rng, B, Q, H, D, levels, P, lo=-0.05, hi=1.05)
+    lib = _lib.load()
+    dims = (B, sum(h * w for h, w in levels), H, D, Q, len(levels), P, 4)
+    cells = level_cells_of(levels)
+    assert cells == 101 * 135
+    assert lib.msda_bwd_workspace_bytes(*dims) > 0           # worst case from I: the sorted pipeline
+    lib.msda_hint_level_cells(cells)
+    try:
+        assert lib.msda_bwd_workspace_bytes(*dims) == 0      # with the promise: the single-launch kernel
+    finally:
+        lib.msda_hint_level_cells(0)
+    assert lib.msda_bwd_workspace_bytes(*dims) > 0
+    r_gv, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in c.items()}
+    # launcher API
+    gv, gl, ga = msda_hip_bwd(t["grad_out"], t["value"], t["shapes"], t["loc"], t["attn"], "zeros", False,
+                              level_cells=cells)
+    np.testing.assert_allclose(gv.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
+    np.testing.assert_allclose(ga.cpu().numpy(), r_ga, **BWD_TOL[torch.float32])
+    assert lib.msda_bwd_workspace_bytes(*dims) > 0           # withdrawn
+    # public API (the C++ autograd node when the binding is built) and the Python Function over ctypes
+    from msda_triton_amd.functional import _HipMultiscaleDeformableAttentionFunction as PyFn
+    for route in ("public", "py"):
+        v, l, a = (t[k].clone().requires_grad_(True) for k in ("value", "loc", "attn"))
+        if route == "public":
+            out = ops.multiscale_deformable_attention(v, t["shapes"], l, a, "zeros", False, level_shapes=levels)
+        else:
+            out = PyFn.apply(v, t["shapes"], l, a, "zeros", False, cells)
+        out.backward(t["grad_out"])
+        np.testing.assert_allclose(v.grad.cpu().numpy(), r_gv, err_msg=route, **BWD_TOL[torch.float32])
+        np.testing.assert_allclose(a.grad.cpu().numpy(), r_ga, err_msg=route, **BWD_TOL[torch.float32])
+        assert lib.msda_bwd_workspace_bytes(*dims) > 0       # withdrawn again (this thread; the engine's thread set its own)
+
+
+def test_broken_level_shapes_promise_gives_nan_rows_not_wrong_ones():
+    """A level larger than promised cannot be served by the table sized on the promise and cannot be reported from the
+    kernel: its grad_value rows come back NaN, the other levels' rows are right."""
+    from msda_triton_amd.functional import msda_hip_bwd
+    levels = [(40, 50), (9, 7)]
+    B, Q, H, D, P = 1, 30, 2, 16, 2
+    rng = np.random.default_rng(5)
+    c = rand_case(rng, B, Q, H, D, levels, P, lo=0.0, hi=1.0)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in c.items()}
+    good, _, _ = msda_hip_bwd(t["grad_out"], t["value"], t["shapes"], t["loc"], t["attn"], "border", True)
+    bad, gl, ga = msda_hip_bwd(t["grad_out"], t["value"], t["shapes"], t["loc"], t["attn"], "border", True,
+                               level_cells=20 * 20)  # level 0 has 41 * 51 cells
+    n0 = 40 * 50
+    assert torch.isnan(bad[:, :n0]).all()
+    torch.testing.assert_close(bad[:, n0:], good[:, n0:], atol=1e-5, rtol=1e-5)
+    assert torch.isfinite(gl).all() and torch.isfinite(ga).all()
+
+
 @pytest.mark.parametrize("td", [torch.float32, torch.float64, torch.bfloat16], ids=["f32", "f64", "bf16"])
 def test_sorted_grad_value_in_query_rounds(oracle, td):
     """Very large Q is served in rounds over the queries (a plane's grad_out rows stay in L2; running sums in the

@@ -295,3 +295,13 @@ def test_host_path_and_gather_formulation_agree():
             if name == "grad_loc":
                 x, y = x * keep, y * keep
             torch.testing.assert_close(x, y, atol=1e-11, rtol=1e-9, msg=lambda m, n=name: f"{pm} {ac} {n}: {m}")
+
+
+def test_level_cells_of_host_shapes():
+    """The bound msda_hint_level_cells takes, from host numbers only (a device tensor would need a synchronisation)."""
+    from msda_triton_amd.functional import level_cells_of
+    assert level_cells_of(None) == 0
+    assert level_cells_of([]) == 0
+    assert level_cells_of([(100, 134), (50, 67)]) == 101 * 135
+    assert level_cells_of(torch.tensor([[8, 8], [64, 3]])) == 65 * 4
+    assert level_cells_of(((1, 1),)) == 4
