@@ -165,7 +165,8 @@ public:
 class MSDAFusedFunction : public torch::autograd::Function<MSDAFusedFunction> {
 public:
     static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &img_, const at::Tensor &shapes_,
-                              const at::Tensor &proj_, const at::Tensor &ref_, int64_t padding_mode, bool align_corners)
+                              const at::Tensor &proj_, const at::Tensor &ref_, int64_t padding_mode, bool align_corners,
+                              int64_t level_cells)
     {
         const at::Tensor img = img_.contiguous(), proj = proj_.contiguous(), ref = ref_.contiguous();
         const at::Tensor shapes = shapes_.to(at::kLong).contiguous();
@@ -181,6 +182,7 @@ public:
         ctx->save_for_backward({img, shapes, proj, ref});
         ctx->saved_data["padding_mode"] = padding_mode;
         ctx->saved_data["align_corners"] = align_corners;
+        ctx->saved_data["level_cells"] = level_cells;
         return out;
     }
 
@@ -191,6 +193,7 @@ public:
         const at::Tensor &img = saved[0], &shapes = saved[1], &proj = saved[2], &ref = saved[3];
         const int padding_mode = (int)ctx->saved_data["padding_mode"].toInt();
         const bool align_corners = ctx->saved_data["align_corners"].toBool();
+        const LevelCellsHint hint(ctx->saved_data["level_cells"].toInt());
         at::Tensor gout = grads[0].contiguous();
         if (gout.scalar_type() != proj.scalar_type()) gout = gout.to(proj.scalar_type());
         const bool want_value = ctx->needs_input_grad(0);
@@ -217,7 +220,7 @@ public:
         }
         return once_differentiable(grads, {g_img, at::Tensor(), ctx->needs_input_grad(2) ? g_proj : at::Tensor(),
                                            ctx->needs_input_grad(3) ? g_ref_part.sum(2) : at::Tensor(), at::Tensor(),
-                                           at::Tensor()});
+                                           at::Tensor(), at::Tensor()});
     }
 };
 
@@ -228,9 +231,9 @@ at::Tensor msda(const at::Tensor &img, const at::Tensor &shapes, const at::Tenso
 }
 
 at::Tensor msda_fused(const at::Tensor &img, const at::Tensor &shapes, const at::Tensor &proj, const at::Tensor &ref,
-                      int64_t padding_mode, bool align_corners)
+                      int64_t padding_mode, bool align_corners, int64_t level_cells)
 {
-    return MSDAFusedFunction::apply(img, shapes, proj, ref, padding_mode, align_corners);
+    return MSDAFusedFunction::apply(img, shapes, proj, ref, padding_mode, align_corners, level_cells);
 }
 
 }  // namespace
@@ -241,7 +244,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("msda", &msda, "multi-scale deformable attention (forward; differentiable)", pybind11::arg("img"),
           pybind11::arg("shapes"), pybind11::arg("sampling_points"), pybind11::arg("attention_weights"),
           pybind11::arg("padding_mode"), pybind11::arg("align_corners"), pybind11::arg("level_cells") = 0);
-    m.def("msda_fused", &msda_fused, "module core with the softmax / sampling-point prologue fused in (differentiable)");
+    m.def("msda_fused", &msda_fused, "module core with the softmax / sampling-point prologue fused in (differentiable)",
+          pybind11::arg("img"), pybind11::arg("shapes"), pybind11::arg("proj"), pybind11::arg("reference_points"),
+          pybind11::arg("padding_mode"), pybind11::arg("align_corners"), pybind11::arg("level_cells") = 0);
     m.def("fused_lp_limit", [](int64_t D, int64_t elem_size) { return msda_fused_lp_limit(D, (int)elem_size); });
     m.def("abi_version", []() { return msda_abi_version(); });
 }

@@ -431,7 +431,7 @@ def msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, al
 
 
 def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, padding_mode, align_corners,
-                       need_img: bool = True):
+                       need_img: bool = True, level_cells: int = 0):
     """Backward of the module core with the prologue's chain rule done in the kernel: returns
     ``(img_grad | None, proj_grad, reference_points_grad)``, or None when the library declines (L*P too large
     for one pass; nothing was launched)."""
@@ -454,19 +454,26 @@ def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, paddin
     lib = _lib.load()
     fn = getattr(lib, f"msda_bwd_fused_{suf}")
     ws, ws_bytes = None, 0
-    if need_img:
-        ws_bytes = int(lib.msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, proj.element_size()))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
+    level_cells = int(level_cells)
+    if level_cells > 0:  # this thread's promise (level_cells_of) for the size query and the launch; withdrawn below
+        lib.msda_hint_level_cells(level_cells)
+    try:
+        if need_img:
+            ws_bytes = int(lib.msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, proj.element_size()))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
-    def call():
-        return fn(out_grad.data_ptr(), img.data_ptr(), shapes.data_ptr(), proj.data_ptr(), reference_points.data_ptr(),
-                  g_img.data_ptr() if need_img else None, g_proj.data_ptr(), g_ref_part.data_ptr(),
-                  B, I, H, D, Q, L, P, ref_dim, pad, int(bool(align_corners)),
-                  ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(img.device))
+        def call():
+            return fn(out_grad.data_ptr(), img.data_ptr(), shapes.data_ptr(), proj.data_ptr(), reference_points.data_ptr(),
+                      g_img.data_ptr() if need_img else None, g_proj.data_ptr(), g_ref_part.data_ptr(),
+                      B, I, H, D, Q, L, P, ref_dim, pad, int(bool(align_corners)),
+                      ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(img.device))
 
-    with _OnDevice(img.device):
-        timer = KernelTimer.active
-        rc = timer.launch("msda_bwd_fused", img.device, call) if timer else call()
+        with _OnDevice(img.device):
+            timer = KernelTimer.active
+            rc = timer.launch("msda_bwd_fused", img.device, call) if timer else call()
+    finally:
+        if level_cells > 0:
+            lib.msda_hint_level_cells(0)
     if rc == -5:  # MSDA_ERR_UNSUPPORTED
         return None
     _lib.check(rc, f"msda_bwd_fused_{suf}")
@@ -480,7 +487,8 @@ class _HipFusedModuleCoreFunction(Function):
 
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, img, img_shapes, proj, reference_points, padding_mode, align_corners):
+    def forward(ctx, img, img_shapes, proj, reference_points, padding_mode, align_corners, level_cells=0):
+        ctx.level_cells = int(level_cells)
         out = msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, align_corners)
         ctx.fused = out is not None  # the backward has the same L*P limit: do not ask twice
         if out is None:
@@ -498,17 +506,18 @@ class _HipFusedModuleCoreFunction(Function):
         need_img, _, need_proj, need_ref = ctx.needs_input_grad[:4]
         if ctx.fused and (need_proj or need_ref):
             res = msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, ctx.padding_mode,
-                                     ctx.align_corners, need_img)
+                                     ctx.align_corners, need_img, level_cells=ctx.level_cells)
             if res is not None:
                 g_img, g_proj, g_ref = res
-                return g_img, None, (g_proj if need_proj else None), (g_ref if need_ref else None), None, None
+                return g_img, None, (g_proj if need_proj else None), (g_ref if need_ref else None), None, None, None
         with torch.enable_grad():
             proj_ = proj.detach().requires_grad_(need_proj)
             ref_ = reference_points.detach().requires_grad_(need_ref)
             pts, att = module_sampling_inputs(proj_, img_shapes, ref_)
         need_sample = need_proj or need_ref
         g_img, g_pts, g_att = msda_hip_bwd(out_grad, img, img_shapes, pts.detach(), att.detach(), ctx.padding_mode,
-                                           ctx.align_corners, (need_img, need_sample, need_sample))
+                                           ctx.align_corners, (need_img, need_sample, need_sample),
+                                           level_cells=ctx.level_cells)
         g_proj = g_ref = None
         if need_sample:
             wrt = [t for t, n in ((proj_, need_proj), (ref_, need_ref)) if n]
@@ -517,12 +526,14 @@ class _HipFusedModuleCoreFunction(Function):
                 g_proj = grads.pop(0)
             if need_ref:
                 g_ref = grads.pop(0)
-        return g_img, None, g_proj, g_ref, None, None
+        return g_img, None, g_proj, g_ref, None, None, None
 
 
-def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, align_corners) -> torch.Tensor:
+def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, align_corners, level_shapes=None) -> torch.Tensor:
     """``multiscale_deformable_attention(img, img_shapes, *module_sampling_inputs(proj, ...))`` — on GPU tensors
-    with the prologue fused into the forward kernel; on host tensors exactly that composition."""
+    with the prologue fused into the forward kernel; on host tensors exactly that composition.  ``level_shapes``: the
+    level sizes as host numbers, optional (:func:`level_cells_of`)."""
+    level_cells = level_cells_of(level_shapes)
     if img.device.type == "cuda" and img_shapes.device != img.device:
         # the level table is a handful of integers: follow `img` (the reference's module accepts a host-resident
         # img_shapes next to GPU tensors through its fallback, frontend.py:170-172)
@@ -535,7 +546,7 @@ def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, ali
         # input, frontend.py:111): mixed bf16 projections / fp32 reference points still take the fused kernels
         _padding_code(padding_mode)
         return _HipFusedModuleCoreFunction.apply(img, img_shapes, proj, reference_points, padding_mode,
-                                                 bool(align_corners))
+                                                 bool(align_corners), level_cells)
     if img.device.type == "cuda" and dtypes_supported(img.dtype, proj.dtype) and \
             reference_points.dtype == proj.dtype and not torch.compiler.is_compiling():
         pad = _padding_code(padding_mode)
@@ -552,9 +563,9 @@ def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, ali
                     and tuple(proj.shape[:3]) == (B, reference_points.shape[1], H) \
                     and reference_points.shape[0] == B and tuple(img_shapes.shape) == (proj.shape[3], 2):
                 _shapes_i64(img_shapes)
-                return ext.msda_fused(img, img_shapes, proj, reference_points, pad, bool(align_corners))
+                return ext.msda_fused(img, img_shapes, proj, reference_points, pad, bool(align_corners), level_cells)
         return _HipFusedModuleCoreFunction.apply(img, img_shapes, proj, reference_points, padding_mode,
-                                                 bool(align_corners))
+                                                 bool(align_corners), level_cells)
     if img.device.type == "cuda" and torch.compiler.is_compiling() and dtypes_supported(img.dtype, proj.dtype) and \
             reference_points.dtype == proj.dtype:
         from . import compile_op  # traced: keep the fused kernels as one custom op per direction

@@ -66,7 +66,7 @@ class MultiscaleDeformableAttention(nn.Module):
         return module_sampling_inputs(proj, img_shapes, reference_points)
 
     def forward(self, img: torch.Tensor, img_shapes: torch.Tensor, queries: torch.Tensor,
-                reference_points: torch.Tensor) -> torch.Tensor:
+                reference_points: torch.Tensor, level_shapes=None) -> torch.Tensor:
         """
         Args:
             img: flattened pyramid ``[batch, num_image, emb_dim]``.
@@ -74,6 +74,8 @@ class MultiscaleDeformableAttention(nn.Module):
             queries: ``[batch, num_queries, emb_dim]``.
             reference_points: ``[batch, num_queries, 2]`` (x, y) or ``[batch, num_queries, 4]``
                 (cx, cy, w, h), normalised to [0, 1].
+            level_shapes: optional (not in the reference): the same (height, width) pairs as host numbers; see
+                ``msda_triton_amd.functional.level_cells_of``.
 
         Returns:
             ``[batch, num_queries, emb_dim]``.
@@ -94,8 +96,8 @@ class MultiscaleDeformableAttention(nn.Module):
             value = value.to(self.value_dtype)  # nothing to do when autocast already produced this dtype
             with torch.autocast("cuda", enabled=False):
                 attended = fused_module_core(value, img_shapes, proj.float(), reference_points.float(),
-                                             self.padding_mode, self.align_corners).to(proj.dtype)
+                                             self.padding_mode, self.align_corners, level_shapes).to(proj.dtype)
         else:
             attended = fused_module_core(value, img_shapes, proj, reference_points, self.padding_mode,
-                                         self.align_corners)
+                                         self.align_corners, level_shapes)
         return self.query_output_proj(attended.reshape(B, N, self.hidden_dim))

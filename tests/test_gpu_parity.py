@@ -942,6 +942,45 @@ def test_level_shapes_hint_opens_the_single_launch_kernel_on_image_sized_pyramid
         assert lib.msda_bwd_workspace_bytes(*dims) > 0       # withdrawn again (this thread; the engine's thread set its own)
 
 
+def test_level_shapes_hint_through_the_fused_module_core_and_the_module():
+    """The same promise through fused_module_core (C++ node or Python Function) and MultiscaleDeformableAttention's
+    forward(level_shapes=...): same outputs and gradients as without it (the route differs, the numbers may in the
+    last bits: different summation order)."""
+    from msda_triton_amd.functional import fused_module_core
+    ops = _ops()
+    levels = [(100, 134), (50, 67)]  # 2 I + 2 L = 33 504 cells do not fit the kernel's LDS, the promised 101 * 135 do
+    B, Q, H, D, P = 2, 70, 2, 32, 4
+    g = torch.Generator(device="cpu").manual_seed(42)
+    I = sum(h * w for h, w in levels)
+    value = torch.randn(B, I, H, D, generator=g)
+    proj = torch.randn(B, Q, H, len(levels), P, 3, generator=g)
+    ref = torch.rand(B, Q, 2, generator=g)
+    gout = torch.rand(B, Q, H, D, generator=g)
+    shapes = torch.tensor(levels, device=DEV)
+    res = []
+    for ls in (None, levels):
+        v, pr, rf = (t.clone().to(DEV).requires_grad_(True) for t in (value, proj, ref))
+        out = fused_module_core(v, shapes, pr, rf, "zeros", False, level_shapes=ls)
+        out.backward(gout.to(DEV))
+        res.append((out.detach(), v.grad, pr.grad, rf.grad))
+    for name, a, b in zip(("out", "grad_value", "grad_proj", "grad_ref"), res[0], res[1]):
+        torch.testing.assert_close(a, b, atol=2e-5, rtol=1e-4, msg=lambda m, n=name: f"{n}: {m}")
+    torch.manual_seed(0)
+    mod = ops.MultiscaleDeformableAttention(emb_dim=32, hidden_dim=64, num_levels=len(levels), num_heads=2, num_points=4,
+                                            padding_mode="border", align_corners=True).to(DEV)
+    img = torch.randn(B, I, 32, device=DEV)
+    qs = torch.randn(B, Q, 32, device=DEV)
+    refs = torch.rand(B, Q, 4, device=DEV)
+    outs = []
+    for ls in (None, levels):
+        mod.zero_grad()
+        o = mod(img, shapes, qs, refs, level_shapes=ls)
+        o.square().sum().backward()
+        outs.append((o.detach(), mod.img_input_proj.weight.grad.clone()))
+    torch.testing.assert_close(outs[0][0], outs[1][0], atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(outs[0][1], outs[1][1], atol=2e-3, rtol=2e-3)
+
+
 def test_broken_level_shapes_promise_gives_nan_rows_not_wrong_ones():
     """A level larger than promised cannot be served by the table sized on the promise and cannot be reported from the
     kernel: its grad_value rows come back NaN, the other levels' rows are right."""
