@@ -262,6 +262,35 @@ def bench_config(name, dev, steps=20, warmup=5):
             "peak_mem_MB": round(peak / 1e6, 1), "inputs_MB": round(base / 1e6, 1), "kernels": kernels}
 
 
+def real_pyramid_leg(dev, steps=50, warmup=10):
+    """Not a BASELINE config: the c4 decoder call (B=8, Q=900) over the pyramid of an 800 x 1066 image (c3's levels)
+    instead of 64 x 64 ... 8 x 8 — what a Grounding-DINO / Deformable-DETR decoder layer sees at COCO size — without
+    and with the level sizes given as host numbers (`level_shapes=`, include/msda_hip.h msda_hint_level_cells)."""
+    import torch
+    from msda_triton_amd import synth
+    from msda_triton_amd.functional import multiscale_deformable_attention
+
+    wl = synth.WORKLOADS["dec_coco"]
+    d = synth.make_inputs_torch(wl, dev, seed=0)
+    v, l, a = (d[k].requires_grad_(True) for k in ("value", "loc", "attn"))
+    out = {"workload": f"dec_coco: B={wl.B} Q={wl.Q} H={wl.H} D={wl.D} levels={list(wl.levels)} P={wl.P} {wl.dtype} "
+                       f"{wl.padding_mode} align_corners={wl.align_corners} (not a BASELINE config)"}
+    for key, ls in (("fwd_bwd_ms", None), ("fwd_bwd_ms_with_level_shapes", list(wl.levels))):
+        def step():
+            o = multiscale_deformable_attention(v, d["shapes"], l, a, wl.padding_mode, wl.align_corners, level_shapes=ls)
+            o.backward(torch.rand_like(o))
+            v.grad = l.grad = a.grad = None
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        out[key] = (time.perf_counter() - t0) * 1e3 / steps
+    return out
+
+
 def triton_comparator_leg(wl_name, dev):
     """A Triton kernel WRITTEN FOR THIS REPO (scripts/triton_comparator.py: the reference's parallelisation — a program
     per (query, batch, head), tl.atomic_add grad_value, num_warps autotuned — but not its code, which cannot travel to
@@ -699,6 +728,7 @@ def main():
                 torch.cuda.empty_cache()
             return out
         optional("configs", leg_configs, False)
+        optional("decoder_real_pyramid", lambda: real_pyramid_leg(dev), False)
     if world == 1 and on_gpu and rank == 0 and not args.no_triton and args.workload == "c2_q10k":
         result["triton_comparator"] = triton_comparator_leg(args.workload, dev)
     if rank == 0:
