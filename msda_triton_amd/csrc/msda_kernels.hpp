@@ -133,9 +133,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV));
     const rsrc_t rs = make_rsrc(plane, plane_bytes);
 
-    load_level_table(tab, p.shapes, p.L);
-    __syncthreads();
-
     const int tid = threadIdx.x;
     const int wave = tid / kWave, lane = tid % kWave;
     const int wunit = lane / G, j = lane % G;  // unit inside the wave, lane inside the unit
@@ -151,11 +148,38 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
     const int qc_end = min(p.nqc, (slot + 1) * p.qw);
 
+    // The workgroup's FIRST chunk of samples is requested before the level table is waited for (the addresses do not
+    // need it), so the two round trips overlap.  Same-box A/B at c2 @ 10k (two alternations): fwd 0.0985 -> 0.0954 ms
+    // warm, 0.129 -> 0.123 ms by the cold-cache do_bench recipe; nothing at Q <= 1000.  (An earlier look at this through
+    // rocprofv3 runs on different boxes had called it noise.)  Plain operator, one channel chunk, all L * P samples
+    // parked at once, at most kPre per lane.
+    constexpr int kPre = 2;
+    const bool pre = !FUSED && nchan_chunks == 1 && p.sc >= p.LP && UPW * p.LP <= kPre * kWave;
+    Pack<T, 2> pxy[kPre];
+    T pa[kPre];
+#pragma unroll
+    for (int t = 0; t < kPre; ++t) {
+        pxy[t].v[0] = pxy[t].v[1] = pa[t] = TR::from_acc((A)0);
+        if constexpr (!FUSED) {
+            const int f = lane + t * kWave;
+            const int fu = div_small(f, p.LP, 1.0f / (float)p.LP);
+            const int fq = (slot * p.qw) * NU + wave * UPW + fu;
+            if (pre && f < UPW * p.LP && fq < p.Q) {
+                const int sidx = imul24(fq, HLP) + (f - imul24(fu, p.LP));
+                pxy[t] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                pa[t] = attn[sidx];
+            }
+        }
+    }
+    load_level_table(tab, p.shapes, p.L);
+    __syncthreads();
+
     for (int qc = slot * p.qw; qc < qc_end; ++qc) {
         const int wq0 = qc * NU + wave * UPW;  // first query of this wave
         if (wq0 >= p.Q) break;                 // wave-uniform
         const int q = wq0 + wunit;
         const bool unit_ok = q < p.Q;
+        const bool use_pre = pre && qc == slot * p.qw;
         for (int cc = 0; cc < nchan_chunks; ++cc) {
             const int c0 = (cc * G + j) * VEC;
             const bool lane_ok = unit_ok && (c0 < p.D);
@@ -213,7 +237,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                     wave_lds_sync();
                 }
                 // ---- phase 1: the wave's UPW * sc samples, one per lane and trip ----
-                for (int f = lane; f < UPW * sc; f += kWave) {
+                auto tap_sample = [&](int f, bool have, const Pack<T, 2> &hxy, T ha) {
                     const int fu = div_small(f, sc, inv_sc);
                     const int sl = s0 + (f - imul24(fu, sc));
                     const int fq = wq0 + fu;
@@ -226,6 +250,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                             sx = pk.v[1];
                             sy = pk.v[2];
                             a = exp_t(pk.v[0] - un.v[0]) * un.v[1];
+                        } else if (have) {
+                            sx = TR::to_acc(hxy.v[0]);
+                            sy = TR::to_acc(hxy.v[1]);
+                            a = TR::to_acc(ha);
                         } else {
                             const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
                             sx = TR::to_acc(xy.v[0]);
@@ -244,6 +272,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                         w_off[rslot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
                         w_rec[rslot] = w;
                     }
+                };
+                if (use_pre) {
+#pragma unroll
+                    for (int t = 0; t < kPre; ++t)
+                        if (lane + t * kWave < UPW * sc) tap_sample(lane + t * kWave, true, pxy[t], pa[t]);
+                } else {
+                    for (int f = lane; f < UPW * sc; f += kWave) tap_sample(f, false, pxy[0], pa[0]);
                 }
                 wave_lds_sync();
                 // ---- phase 2: gather + blend ----
@@ -308,9 +343,6 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
     const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV));
     const rsrc_t rs = make_rsrc(plane, plane_bytes);
 
-    load_level_table(tab, p.shapes, p.L);
-    __syncthreads();
-
     const int tid = threadIdx.x;
     const int wave = tid / kWave, lane = tid % kWave;
     const int wunit = lane / G, j = lane % G;
@@ -329,11 +361,34 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
     const int qc_end = min(p.nqc, (slot + 1) * p.qw);
 
+    // the workgroup's first chunk of samples requested before the level table is waited for, as in the forward
+    constexpr int kPre = 2;
+    const bool pre = !FUSED && p.sc >= p.LP && UPW * p.LP <= kPre * kWave;
+    Pack<T, 2> pxy[kPre];
+    T pa[kPre];
+#pragma unroll
+    for (int t = 0; t < kPre; ++t) {
+        pxy[t].v[0] = pxy[t].v[1] = pa[t] = TR::from_acc((A)0);
+        if constexpr (!FUSED) {
+            const int f = lane + t * kWave;
+            const int fu = div_small(f, p.LP, 1.0f / (float)p.LP);
+            const int fq = (slot * p.qw) * NU + wave * UPW + fu;
+            if (pre && f < UPW * p.LP && fq < p.Q) {
+                const int sidx = imul24(fq, HLP) + (f - imul24(fu, p.LP));
+                pxy[t] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                pa[t] = attn[sidx];
+            }
+        }
+    }
+    load_level_table(tab, p.shapes, p.L);
+    __syncthreads();
+
     for (int qc = slot * p.qw; qc < qc_end; ++qc) {
         const int wq0 = qc * NU + wave * UPW;
         if (wq0 >= p.Q) break;
         const int q = wq0 + wunit;
         const bool unit_ok = q < p.Q;
+        const bool use_pre = pre && qc == slot * p.qw;
         for (int s0 = 0; s0 < p.LP; s0 += p.sc) {
             const int sc = min(p.sc, p.LP - s0);
             const float inv_sc = 1.0f / (float)sc;
@@ -383,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                 wave_lds_sync();
             }
             // ---- phase 1 ----
-            for (int f = lane; f < UPW * sc; f += kWave) {
+            auto tap_sample = [&](int f, bool have, const Pack<T, 2> &hxy, T ha) {
                 const int fu = div_small(f, sc, inv_sc);
                 const int sl = s0 + (f - imul24(fu, sc));
                 const int fq = wq0 + fu;
@@ -400,6 +455,10 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                         py = pk.v[2];
                         a = exp_t(pk.v[0] - un.v[0]) * un.v[1];
                         w_a[rs_] = a;
+                    } else if (have) {
+                        px = TR::to_acc(hxy.v[0]);
+                        py = TR::to_acc(hxy.v[1]);
+                        a = TR::to_acc(ha);
                     } else {
                         const Pack<T, 2> xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
                         px = TR::to_acc(xy.v[0]);
@@ -419,6 +478,13 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                     w_off[rslot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
                     w_rec[rslot] = r;
                 }
+            };
+            if (use_pre) {
+#pragma unroll
+                for (int t = 0; t < kPre; ++t)
+                    if (lane + t * kWave < UPW * sc) tap_sample(lane + t * kWave, true, pxy[t], pa[t]);
+            } else {
+                for (int f = lane; f < UPW * sc; f += kWave) tap_sample(f, false, pxy[0], pa[0]);
             }
             wave_lds_sync();
             // FUSED: softmax backward needs dot = sum_s a_s * gA_s over the unit; the reference point's gradient is

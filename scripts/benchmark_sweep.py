@@ -2,7 +2,8 @@
 """Runtime / memory sweep over the number of queries — the measurement the reference publishes
 (/root/reference/scripts/benchmark.py:10-180, README.md:6-22): forward ms, forward+backward ms and peak
 memory for Q in {10, 100, 300, 900, 1000, 10000}; B=4, H=8, C=32, L=4 levels 64..8, P=4, fp32,
-border / align_corners=True; providers: the HIP kernels and the plain-PyTorch formulation on the GPU.
+border / align_corners=True; providers: the HIP kernels, the plain-PyTorch formulation on the GPU and the Triton
+comparator written for this repo (scripts/triton_comparator.py — not the reference's kernel).
 
 Timing follows triton.testing.do_bench's recipe (which the reference uses): ~100 ms warm-up, ~1 s of
 repetitions, one HIP-event pair per repetition, an L2-sized buffer zeroed before each, median and the
@@ -70,11 +71,23 @@ def main():
     ap.add_argument("--queries", type=int, nargs="+", default=[10, 100, 300, 900, 1000, 10000])
     ap.add_argument("--no-native", action="store_true")
     ap.add_argument("--no-plots", action="store_true")
+    ap.add_argument("--no-triton", action="store_true", help="leave out the Triton comparator (scripts/triton_comparator.py)")
     ap.add_argument("--out", default="outputs/benchmark_results")
     args = ap.parse_args()
     providers = {"hip": multiscale_deformable_attention}
     if not args.no_native:
         providers["torch"] = native_multiscale_deformable_attention
+    if not args.no_triton:  # the builder-authored Triton comparator (NOT the reference's kernel), scripts/triton_comparator.py
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location(
+                "msda_triton_comparator", os.path.join(os.path.dirname(os.path.abspath(__file__)), "triton_comparator.py"))
+            tc = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(tc)
+            if tc.HAVE_TRITON:
+                providers["triton"] = tc.triton_comparator_msda
+        except Exception as e:  # noqa: BLE001
+            print("no Triton comparator:", repr(e)[:200])
     os.makedirs(args.out, exist_ok=True)
     rows = []
     for N in args.queries:
@@ -94,11 +107,19 @@ def main():
                 img.grad = pts.grad = att.grad = None
 
             fb = do_bench(fwdbwd)
+            # peak memory of one fwd+bwd, inputs included (benchmark.py:110-174), with nothing else alive: the
+            # previous provider's tensors and autotuner scratch are dropped first
+            del img, shapes, pts, att
+            import gc
+            gc.collect()
             torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            base = torch.cuda.memory_allocated()
+            img, shapes, pts, att = make_inputs(N, True)
             torch.cuda.reset_peak_memory_stats()
             fwdbwd()
             torch.cuda.synchronize()
-            mem = torch.cuda.max_memory_allocated() / 2**20
+            mem = (torch.cuda.max_memory_allocated() - base) / 2**20
             rows.append(dict(num_queries=N, provider=name, fwd_ms=f[0], fwd_ms_p20=f[1], fwd_ms_p80=f[2],
                              fwdbwd_ms=fb[0], fwdbwd_ms_p20=fb[1], fwdbwd_ms_p80=fb[2], peak_mem_MB=mem))
             print(rows[-1], flush=True)
@@ -118,7 +139,8 @@ def plot(rows, out_dir):
     matplotlib.use("Agg")
     import matplotlib.pyplot as plt
 
-    labels = {"hip": "HIP kernels (this package, MI355X)", "torch": "plain PyTorch on the same GPU"}
+    labels = {"hip": "HIP kernels (this package, MI355X)", "torch": "plain PyTorch on the same GPU",
+              "triton": "Triton comparator written here (atomics as the reference calls them)"}
     for key, title, fname in (("fwd_ms", "msda fwd runtime (ms)", "msda_fwd_runtime_ms.png"),
                               ("fwdbwd_ms", "msda fwd+bwd runtime (ms)", "msda_fwd_bwd_runtime_ms.png"),
                               ("peak_mem_MB", "msda memory consumption (MB)", "msda_memory_consumption_MB.png")):
