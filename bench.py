@@ -218,13 +218,18 @@ def bench_config(name, dev, steps=20, warmup=5):
         with torch.no_grad():
             multiscale_deformable_attention(img, shapes, pts, attn, pm, ac)
 
-    def timed(fn, n):
+    def timed_once(fn, n):
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t0) * 1e3 / n
+
+    def timed(fn, n):
+        # median of three means of n steps: one stall of the box (an allocation, another tenant) inside a 5 ms window
+        # otherwise lands in the figure — seen once as 1.79 ms for a 0.25 ms step
+        return sorted(timed_once(fn, n) for _ in range(3))[1]
 
     for _ in range(warmup):
         step()
@@ -253,11 +258,12 @@ def bench_config(name, dev, steps=20, warmup=5):
         launchers()
     ms_launchers = timed(launchers, steps)
     with KernelTimer() as kt:
-        timed(step, steps)
+        timed_once(step, steps)
     kernels = kernel_table(wl, kt.summary(), load_traffic(name))
     return {"workload": f"{wl.name}: B={wl.B} Q={wl.Q} H={wl.H} D={wl.D} L={wl.L} levels={list(wl.levels)} P={wl.P} "
                         f"{wl.dtype} {pm} align_corners={ac}",
-            "steps": steps, "fwd_ms": ms_fwd, "fwd_bwd_ms": ms_step, "launcher_api_fwd_bwd_ms": ms_launchers,
+            "steps": steps, "timing": "median of three warm means of `steps` steps",
+            "fwd_ms": ms_fwd, "fwd_bwd_ms": ms_step, "launcher_api_fwd_bwd_ms": ms_launchers,
             "alg_fwd_bwd_GBs": round((wl.alg_fwd_bytes + wl.alg_bwd_bytes) / (ms_step * 1e-3) / 1e9, 1),
             "peak_mem_MB": round(peak / 1e6, 1), "inputs_MB": round(base / 1e6, 1), "kernels": kernels}
 
