@@ -540,12 +540,18 @@ def main():
             torch.cuda.synchronize()
 
     def timed(fn, n):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        barrier()
-        dt = time.perf_counter() - t0
+        import gc
+        gc.collect()
+        gc.disable()  # no collector pause inside the K steps (the loop allocates only tensors, freed by refcount)
+        try:
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            barrier()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
         if use_dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
