@@ -269,13 +269,17 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
         fn = getattr(lib, f"msda_bwd_{suf}")
         ws, ws_bytes = None, 0
         level_cells = int(level_cells)
-        if level_cells > 0:  # this thread's promise for the size query and the launch below; withdrawn afterwards
-            lib.msda_hint_level_cells(level_cells)
         if want_value:  # scratch for the inverted index; the caching allocator makes this cheap
             key = (B, I, H, D, Q, L, P, sampling_points.element_size(), _lib.OPTION_EPOCH, level_cells)
             ws_bytes = _WS_BYTES.get(key)
             if ws_bytes is None:
-                ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes(*key[:8]))
+                if level_cells > 0:  # the size depends on this thread's promise too
+                    lib.msda_hint_level_cells(level_cells)
+                try:
+                    ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes(*key[:8]))
+                finally:
+                    if level_cells > 0:
+                        lib.msda_hint_level_cells(0)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
         def call(value_part: bool, sample_part: bool):
@@ -288,6 +292,8 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
                       ws.data_ptr() if (ws is not None and value_part) else None, ws_bytes,
                       _stream_ptr(img.device))
 
+        if level_cells > 0:  # this thread's promise for the launch; withdrawn whatever happens
+            lib.msda_hint_level_cells(level_cells)
         try:
             with _OnDevice(img.device):
                 timer = KernelTimer.active
