@@ -22,6 +22,8 @@ static std::atomic<int> g_level_cells{0};
 static std::atomic<int> g_overlap{-1};
 static std::atomic<int> g_gather_win{0};
 static std::atomic<int> g_deterministic{0};
+static std::atomic<int> g_place_path{0};
+static std::atomic<int> g_place_block{0};
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
 // Per THREAD, because the fork (record on the user's stream, wait on the side stream) and the join are two calls
@@ -91,6 +93,8 @@ void set_thread_level_cells(int64_t n) { t_level_cells = n > 0 ? n : 0; }
 int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
 int option_gather_win() { return g_gather_win.load(std::memory_order_relaxed); }
 int option_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
+int option_place_path() { return g_place_path.load(std::memory_order_relaxed); }
+int option_place_block() { return g_place_block.load(std::memory_order_relaxed); }
 
 void set_error(const char *fmt, ...)
 {
@@ -170,6 +174,14 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_deterministic.store(value ? 1 : 0, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "place_path") == 0) {
+        msda::g_place_path.store(value == 1 || value == 2 ? value : 0, std::memory_order_relaxed);
+        return 0;
+    }
+    if (key && strcmp(key, "place_block") == 0 && (value == 0 || value == 256 || value == 512 || value == 1024)) {
+        msda::g_place_block.store(value, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "cell_slices") == 0 && value >= 0 && value <= 64) {
         msda::g_cell_slices.store(value, std::memory_order_relaxed);
         return 0;
@@ -195,6 +207,8 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "overlap") == 0) return msda::option_overlap();
     if (key && strcmp(key, "gather_win") == 0) return msda::option_gather_win();
     if (key && strcmp(key, "deterministic") == 0) return msda::option_deterministic();
+    if (key && strcmp(key, "place_path") == 0) return msda::option_place_path();
+    if (key && strcmp(key, "place_block") == 0) return msda::option_place_block();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

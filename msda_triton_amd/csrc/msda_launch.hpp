@@ -7,6 +7,7 @@
 #include <atomic>
 
 #include "msda_value_sorted.hpp"
+#include "msda_value_place.hpp"
 #include "msda_value_small.hpp"
 
 namespace msda {
@@ -19,6 +20,8 @@ int option_small_ns();      // workgroups per (plane, level) of the single-launc
 int option_level_cells();   // caller's promise: no level has more than this many bilinear cells (0: unknown)
 int option_q_round();       // queries per round of the sorted grad_value path (0: automatic)
 int option_debug();         // dev-only ablation mask
+int option_place_path();    // 0: level-major place pass with LDS-staged runs (msda_value_place.hpp); 1: the plane-major place pass
+int option_place_block();   // threads per workgroup of the level-major place pass (0: automatic)
 int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream; 0: never; -1: automatic
 // fork-join helpers around a lazily created per-device side stream (msda_api.hip)
 hipStream_t side_stream_fork(hipStream_t user);   // side stream that waits for everything queued on `user`
@@ -301,16 +304,53 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
         return MSDA_ERR_TOO_LARGE;
     }
     constexpr int VECF = 16 / sizeof(T);
+    const int g3_cell = p.grid3d, cell_cap_pm = p.cell_cap;
+    // level-major place pass with LDS-staged runs (msda_value_place.hpp) unless the deterministic option asks for the
+    // one-wave kernel; 512 threads: two workgroups per CU at its register count
+    const int place_tb = option_place_block() == 1024 ? 1024 : option_place_block() == 256 ? 256 : kPlaceBlock;
+    // ... when a plane has at least as many samples as its cell tables have entries: every workgroup loads its level's
+    // whole table, so on pyramids much larger than the sample count (a decoder over a real image: 14 k samples against
+    // 36 k cells per plane) the tables outweigh the samples and the plane-major pass is faster (14 us against 21)
+    const bool place_lm = d.P >= 1 && d.P <= place_tb && !option_deterministic() &&
+                          (option_place_path() == 0 ? (int64_t)w.q_round * d.L * d.P >= (int64_t)w.nc_cap
+                                                    : option_place_path() == 2);
+    const int place_cells = place_cell_cap(w.nc_cap, (size_t)kMaxDynLds);
+    dim3 gplace;
+    int g3_place = 0;
+    if (place_lm) {
+        if (!plane_grid(p, npairs, (int64_t)d.L * p.nsplit, gplace)) {
+            set_error("grid too large");
+            return MSDA_ERR_TOO_LARGE;
+        }
+        g3_place = p.grid3d;
+        static std::atomic<uint64_t> big_lds_lm[3] = {};
+        allow_big_lds(msda_cell_place_lm_kernel<T, 256>, big_lds_lm[0]);
+        allow_big_lds(msda_cell_place_lm_kernel<T, 512>, big_lds_lm[1]);
+        allow_big_lds(msda_cell_place_lm_kernel<T, 1024>, big_lds_lm[2]);
+    }
     for (int r = 0; r < w.rounds; ++r) {  // one round unless Q is so large that a plane's grad_out rows leave L2
         p.q_begin = r * w.q_round;
         p.q_end = p.q_begin + w.q_round < p.Q ? p.q_begin + w.q_round : p.Q;
         p.finish_mode = w.rounds == 1 ? 0 : r == 0 ? 1 : r == w.rounds - 1 ? 3 : 2;
+        p.grid3d = g3_cell;
+        p.cell_cap = cell_cap_pm;
         hipLaunchKernelGGL((msda_cell_pass_kernel<T, false>), gcell, dim3(kCellBlock), cell_lds, stream, p);
         hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)scan_blocks), dim3(kScanCells), 0, stream, p);
-        if (option_deterministic())
+        if (option_deterministic()) {
             hipLaunchKernelGGL((msda_cell_place_det_kernel<T>), gcell, dim3(kWave), cell_lds, stream, p);
-        else
+        } else if (place_lm) {
+            p.grid3d = g3_place;
+            p.cell_cap = place_cells;
+            const size_t lds = (size_t)place_cells * 4;
+            if (place_tb == 1024)
+                hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, 1024>), gplace, dim3(1024), lds, stream, p);
+            else if (place_tb == 256)
+                hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, 256>), gplace, dim3(256), lds, stream, p);
+            else
+                hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, 512>), gplace, dim3(512), lds, stream, p);
+        } else {
             hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
+        }
         int rc = (int)hipGetLastError();
         if (rc) return rc;
         rc = vec_ok ? dispatch_value_gather_group<T, VECF, TV>(p, stream) : dispatch_value_gather_group<T, 1, TV>(p, stream);
@@ -588,15 +628,13 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     bool forked = false;
     // The fork/join is not free: two event record/wait pairs cost ~14 us of host time and ~19 us of GPU-side
     // latency per backward on this runtime (tools/anyorder_probe.hip; hipExtAnyOrderLaunch, the in-stream
-    // alternative, is ignored on gfx9), more under the autograd engine.  Measured fwd+bwd with / without (us,
-    // tools/overlap_matrix.sh, round 3 kernels): c2 @ 1k 83 / 65, c4 with B=4 82 / 72, c4 (B=8) 115 / 105, c2 @ 2k
-    // 132 / 127, @ 3k 165 / 163, @ 5k equal, c4 with B=16 196 / 194, B=32 equal, B=64 938 / 925; c2 @ 10k -3.5 %,
-    // c5 -0.3 %; with 64-byte rows (c3) +2 %.  So by default: never next to the single-launch grad_value kernel
-    // (until round 3 it left most CUs idle behind one slow workgroup and the fork paid from ~800k samples), next to
-    // the sorted pipeline (place pass bound by L2 write requests, sample kernel by the vector-memory path) from 4M
-    // samples when rows are at least 128 bytes.
+    // alternative, is ignored on gfx9), more under the autograd engine, and the kernels of the two halves lean on the
+    // same L2 request path.  Round 3 (plane-major place pass, 59 us of scattered stores) the fork paid from 4M samples
+    // with 128-byte rows: c2 @ 10k -3.5 %.  With the level-major place pass (round 4) it no longer does: same-box
+    // A/B at c2 @ 10k, fwd+bwd 0.3999-0.4024 ms forked against 0.3912-0.3972 serial (tools/ab_opt.sh - overlap=0).  So
+    // the automatic setting never forks; msda_set_option("overlap", 1) still forces it.
     const int ov = option_overlap();
-    const bool ov_auto = !small_path_chosen<T>(d) && ns >= 4000000 && D * (int64_t)sizeof(T) >= 128;
+    const bool ov_auto = false;
     if (want_sample && want_value && (ov == 1 || (ov < 0 && ov_auto))) {
         hipStream_t side = side_stream_fork(stream);
         if (side != nullptr) {

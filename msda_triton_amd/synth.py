@@ -56,6 +56,11 @@ class Workload:
     dtype: str = "float32"
     padding_mode: str = "border"
     align_corners: bool = True
+    # how sampling points are drawn: "uniform" = U[0, 1) (the reference benchmark, scripts/benchmark.py:34), "encoder"
+    # = what a Deformable-DETR encoder layer produces (reference module, frontend.py:271-276: reference point + small
+    # offset): query q sits on a pixel of the pyramid, its reference point is that pixel's centre, and every sample
+    # is the reference point plus an N(0, 2 px) offset in the sampled level's pixels
+    loc_mode: str = "uniform"
     L: int = field(init=False)
     I: int = field(init=False)  # noqa: E741
 
@@ -94,9 +99,15 @@ WORKLOADS = {
     "c2_q1k": Workload("c2_q1k", 4, 1000, 8, 32, _PYR64, 4, "float32", "border", True),
     "c2_q5k": Workload("c2_q5k", 4, 5000, 8, 32, _PYR64, 4, "float32", "border", True),
     "c2_q10k": Workload("c2_q10k", 4, 10000, 8, 32, _PYR64, 4, "float32", "border", True),
+    # ... configs[1] also in the other mode SURVEY.md 8d lists for c2 (the reference benches border / True only)
+    "c2_q10k_zeros": Workload("c2_q10k_zeros", 4, 10000, 8, 32, _PYR64, 4, "float32", "zeros", False),
     # configs[2]: Deformable-DETR encoder shape
     "c3_ddetr_enc": Workload("c3_ddetr_enc", 2, 17821, 8, 32,
                              ((100, 134), (50, 67), (25, 34), (13, 17)), 4, "bfloat16", "zeros", False),
+    # ... the same shape with encoder-like locality of the sampling points ("pixel-centre reference +
+    # N(0, 2 px) offsets"): neighbouring queries hit the same few cells
+    "c3_ddetr_enc_local": Workload("c3_ddetr_enc_local", 2, 17821, 8, 32,
+                                   ((100, 134), (50, 67), (25, 34), (13, 17)), 4, "bfloat16", "zeros", False, "encoder"),
     # configs[3]: Grounding-DINO decoder shape
     "c4_gdino_dec": Workload("c4_gdino_dec", 8, 900, 8, 32, _PYR64, 4, "float32", "zeros", False),
     # configs[4]: stress
@@ -112,8 +123,27 @@ WORKLOADS = {
 }
 
 
+def encoder_reference_points(wl: Workload, q_begin: int = 0, q_end: int | None = None) -> np.ndarray:
+    """[nq, 2] (x, y) in [0, 1]: query q is pixel floor(q * I / Q) of the level-packed pyramid (q itself when Q == I, the
+    encoder's case) and its reference point is that pixel's centre, ((x + 0.5) / w, (y + 0.5) / h)."""
+    q_end = wl.Q if q_end is None else q_end
+    q = np.arange(q_begin, q_end, dtype=np.int64)
+    pix = q if wl.Q == wl.I else (q * wl.I) // max(wl.Q, 1)
+    ref = np.zeros((q.size, 2))
+    start = 0
+    for h, w in wl.levels:
+        m = (pix >= start) & (pix < start + h * w)
+        rel = pix[m] - start
+        if w > 0:
+            ref[m, 0] = ((rel % w) + 0.5) / w
+            ref[m, 1] = ((rel // w) + 0.5) / h
+        start += h * w
+    return ref
+
+
 def make_inputs_numpy(wl: Workload, seed: int = 0, q_begin: int = 0, q_end: int | None = None,
-                      attn_mode: str = "softmax", loc_lo: float = 0.0, loc_hi: float = 1.0):
+                      attn_mode: str = "softmax", loc_lo: float = 0.0, loc_hi: float = 1.0,
+                      loc_mode: str | None = None, offset_px: float = 2.0):
     """float64 numpy inputs for queries [q_begin, q_end) of every batch element.
 
     Element values depend only on their *global* index, so a query shard equals the
@@ -128,10 +158,20 @@ def make_inputs_numpy(wl: Workload, seed: int = 0, q_begin: int = 0, q_end: int 
     loc = np.empty((B, nq, H, L, P, 2))
     att = np.empty((B, nq, H, L, P))
     gout = np.empty((B, nq, H, D))
+    loc_mode = wl.loc_mode if loc_mode is None else loc_mode
+    if loc_mode not in ("uniform", "encoder"):
+        raise ValueError(f"unknown loc_mode {loc_mode!r}")
+    if loc_mode == "encoder":
+        ref = encoder_reference_points(wl, q_begin, q_end)                             # [nq, 2] (x, y)
+        wh = np.asarray([(max(w, 1), max(h, 1)) for h, w in wl.levels], dtype=np.float64)  # [L, 2] (w, h)
     for b in range(B):
         g0 = b * Q + q_begin
-        loc[b] = (loc_lo + (loc_hi - loc_lo) * uniform(seed, 2, nq * per_q_loc, g0 * per_q_loc)
-                  ).reshape(nq, H, L, P, 2)
+        if loc_mode == "encoder":
+            off = normal(seed, 5, nq * per_q_loc, g0 * per_q_loc).reshape(nq, H, L, P, 2) * offset_px
+            loc[b] = ref[:, None, None, None, :] + off / wh[None, None, :, None, :]
+        else:
+            loc[b] = (loc_lo + (loc_hi - loc_lo) * uniform(seed, 2, nq * per_q_loc, g0 * per_q_loc)
+                      ).reshape(nq, H, L, P, 2)
         if attn_mode == "softmax":
             a = normal(seed, 3, nq * per_q_att, g0 * per_q_att).reshape(nq, H, L, P)
             a = np.exp(a - a.max(-1, keepdims=True))
@@ -152,7 +192,15 @@ def make_row_inputs_numpy(wl: Workload, seed: int = 0, r_begin: int = 0, r_end: 
     n = r_end - r_begin
     per_q_loc, per_q_att, per_q_out = H * L * P * 2, H * L * P, H * D
     value = normal(seed, 1, B * I * H * D).reshape(B, I, H, D)
-    loc = uniform(seed, 2, n * per_q_loc, r_begin * per_q_loc).reshape(n, H, L, P, 2)
+    if wl.loc_mode == "encoder":  # row r = b * Q + q: the batch elements' reference points repeat
+        rows = np.arange(r_begin, r_end, dtype=np.int64)
+        ref_all = encoder_reference_points(wl)
+        ref = ref_all[rows % max(Q, 1)]
+        wh = np.asarray([(max(w, 1), max(h, 1)) for h, w in wl.levels], dtype=np.float64)
+        off = normal(seed, 5, n * per_q_loc, r_begin * per_q_loc).reshape(n, H, L, P, 2) * 2.0
+        loc = ref[:, None, None, None, :] + off / wh[None, None, :, None, :]
+    else:
+        loc = uniform(seed, 2, n * per_q_loc, r_begin * per_q_loc).reshape(n, H, L, P, 2)
     a = normal(seed, 3, n * per_q_att, r_begin * per_q_att).reshape(n, H, L, P)
     a = np.exp(a - a.max(-1, keepdims=True))
     att = a / a.sum(-1, keepdims=True)

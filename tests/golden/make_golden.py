@@ -127,12 +127,16 @@ def write_small_cases():
 # bf16 for levels > 2048 px); the bf16 GPU tests compare against these digests with bf16 tolerances.
 DIGEST_CASES = (("c1_readme", (0.0, 1.0)), ("c2_q1k", (0.0, 1.0)), ("c1_readme", (-0.25, 1.25)),
                 ("c2_q5k", (0.0, 1.0)), ("c2_q10k", (0.0, 1.0)), ("c4_gdino_dec", (0.0, 1.0)),
-                ("c4_gdino_dec", (-0.25, 1.25)), ("c3_ddetr_enc", (0.0, 1.0)))
+                ("c4_gdino_dec", (-0.25, 1.25)), ("c3_ddetr_enc", (0.0, 1.0)),
+                # encoder-like locality: pixel-centre reference points + N(0, 2 px) offsets (synth loc_mode)
+                ("c3_ddetr_enc_local", (0.0, 1.0)))
 
 
-def write_digests():
+def write_digests(only=None):
     # full-size digests: inputs are regenerated from synth on the checking side
     for wl_name, pts_range in DIGEST_CASES:
+        if only and wl_name not in only:
+            continue
         wl = synth.WORKLOADS[wl_name]
         d = synth.make_inputs_torch(wl, "cpu", seed=0, dtype=torch.float32,
                                     loc_lo=pts_range[0], loc_hi=pts_range[1])
@@ -215,6 +219,9 @@ def main():
         write_small_cases()
     if "digests" in what:
         write_digests()
+    only = {w.split(":", 1)[1] for w in what if w.startswith("digest:")}  # e.g. digest:c3_ddetr_enc_local
+    if only:
+        write_digests(only)
     if "module" in what:
         write_module_cases()
 
