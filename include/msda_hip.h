@@ -74,7 +74,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 8
+#define MSDA_ABI_VERSION 9
 
 #if defined(__GNUC__)
 #define MSDA_API __attribute__((visibility("default")))
@@ -126,6 +126,49 @@ MSDA_DECLARE(f32_vbf16)
 MSDA_DECLARE(f32_vf16)
 #undef MSDA_DECLARE
 
+/*
+ * The backward entry points with the caller's knowledge of the level sizes AS AN ARGUMENT (ABI 9).  `shapes` lives on the
+ * device, so the library sizes the single-launch grad_value kernel's LDS cell table for the worst level `I` pixels can
+ * form, (2 I + 2 L) cells — which rules that kernel out for the pyramids of real images (a 100 x 134 ... 13 x 17
+ * pyramid: 35.6 k cells by the bound, 13.6 k in its largest level) and sends decoder-sized calls on them to the sorted
+ * pipeline, 1.4x slower there.  A caller that knows the level sizes on the host (Hugging Face models carry
+ * `spatial_shapes_list`) passes max_level_cells = the bilinear cells of the largest level, max_l (h_l + 1) * (w_l + 1);
+ * 0 = unknown (then these are msda_bwd_<dtype> / msda_bwd_fused_<dtype>).  The workspace query takes the same number.
+ * A level larger than stated cannot be reported from the kernel: its grad_value rows come back NaN.
+ */
+#define MSDA_DECLARE_EX(SUF)                                                                                  \
+    MSDA_API int msda_bwd_ex_##SUF(const void *grad_out, const void *value, const int64_t *shapes,            \
+                       const void *loc, const void *attn, void *grad_value, void *grad_loc,                   \
+                       void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,                \
+                       int64_t L, int64_t P, int padding_mode, int align_corners, int64_t max_level_cells,    \
+                       void *workspace, int64_t workspace_bytes, void *stream);                               \
+    MSDA_API int msda_bwd_fused_ex_##SUF(const void *grad_out, const void *value, const int64_t *shapes,      \
+                       const void *proj, const void *ref, void *grad_value, void *grad_proj,                  \
+                       void *grad_ref_partial, int64_t B, int64_t I, int64_t H, int64_t D,                    \
+                       int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,                        \
+                       int align_corners, int64_t max_level_cells, void *workspace,                           \
+                       int64_t workspace_bytes, void *stream);
+MSDA_DECLARE_EX(f32)
+MSDA_DECLARE_EX(f16)
+MSDA_DECLARE_EX(bf16)
+MSDA_DECLARE_EX(f64)
+MSDA_DECLARE_EX(f32_vbf16)
+MSDA_DECLARE_EX(f32_vf16)
+#undef MSDA_DECLARE_EX
+MSDA_API int64_t msda_bwd_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
+                                             int64_t P, int elem_size, int64_t max_level_cells);
+MSDA_API int64_t msda_bwd_fused_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
+                                                   int64_t P, int elem_size, int64_t max_level_cells);
+
+/*
+ * 1 when msda_bwd_<dtype> can produce grad_value for these sizes, 0 when it would return MSDA_ERR_UNSUPPORTED (a plane
+ * of 2^22 pixels or more, or a head dimension beyond the 32-bit slot offsets of the sorted pipeline, on a problem that
+ * is also too large for the single-launch kernel).  Host arithmetic only: a caller asks at FORWARD time when the value
+ * pyramid requires a gradient, instead of learning it from the backward in the middle of a training step.
+ */
+MSDA_API int msda_bwd_supported(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P,
+                                int elem_size);
+
 /* Bytes of device workspace msda_bwd_<dtype> wants for these sizes; elem_size = sizeof(dtype). */
 MSDA_API int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
                                           int64_t P, int elem_size);
@@ -139,15 +182,11 @@ MSDA_API int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H,
 MSDA_API int64_t msda_fused_lp_limit(int64_t D, int elem_size);
 
 /*
- * The pyramid's level sizes live on the device (`shapes`), so the library sizes the single-launch grad_value kernel's
- * LDS cell table for the worst level `I` pixels can form, (2 I + 2 L) cells — which rules that kernel out for the
- * pyramids of real images (a 100 x 134 ... 13 x 17 pyramid: 35.6 k cells by the bound, 13.6 k in its largest level) and
- * sends decoder-sized calls on them to the sorted pipeline, 1.4x slower there.  A caller that knows the level sizes on
- * the host (Hugging Face models carry `spatial_shapes_list`) can promise a bound: no level of the calls that follow ON
- * THIS THREAD has more than `max_level_cells` bilinear cells, (h + 1) * (w + 1).  0 withdraws the promise (default).
- * msda_bwd_workspace_bytes and msda_bwd_<dtype> must see the same promise (autograd runs the backward on its own
- * thread: set it there).  A broken promise cannot be reported from the kernel: the affected level's grad_value rows
- * are returned as NaN.  msda_set_option("level_cells", n) is the same promise process-wide (a thread's own wins).
+ * Superseded by the max_level_cells argument of msda_bwd_ex_<dtype> / msda_bwd_workspace_bytes_ex (above); kept for one
+ * ABI version.  The same bound as a per-THREAD side channel: "no level of the calls that follow on this thread has more
+ * than `max_level_cells` bilinear cells"; 0 withdraws it.  msda_bwd_workspace_bytes and msda_bwd_<dtype> must see the
+ * same promise (autograd runs the backward on its own thread: set it there).  msda_set_option("level_cells", n) is the
+ * same promise process-wide (a thread's own wins; an argument of an _ex call wins over both).
  */
 MSDA_API void msda_hint_level_cells(int64_t max_level_cells);
 

@@ -15,16 +15,17 @@ LIB_NAME = "libmsda_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PADDING_MODES = {"border": 0, "zeros": 1}
 # one storage type for every tensor, then the mixed ones: value / grad_value in 16 bits, everything else fp32
 DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64", "f32_vbf16", "f32_vf16")
 
 # every symbol include/msda_hip.h declares
 EXPORTED_SYMBOLS = tuple(
-    [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused", "bwd_fused") for s in DTYPE_SUFFIXES]
+    [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused", "bwd_fused", "bwd_ex", "bwd_fused_ex") for s in DTYPE_SUFFIXES]
     + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option", "msda_bwd_workspace_bytes",
-       "msda_bwd_fused_workspace_bytes", "msda_fused_lp_limit", "msda_hint_level_cells"]
+       "msda_bwd_fused_workspace_bytes", "msda_bwd_workspace_bytes_ex", "msda_bwd_fused_workspace_bytes_ex",
+       "msda_bwd_supported", "msda_fused_lp_limit", "msda_hint_level_cells"]
 )
 
 _lib = None
@@ -78,10 +79,23 @@ def load():
             gf = getattr(lib, f"msda_bwd_fused_{suf}")
             gf.restype = ci
             gf.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, vp, i64, vp]
+            # ... with the level-size bound as an argument (max_level_cells, 0: unknown)
+            gx = getattr(lib, f"msda_bwd_ex_{suf}")
+            gx.restype = ci
+            gx.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, i64, vp, i64, vp]
+            gfx = getattr(lib, f"msda_bwd_fused_ex_{suf}")
+            gfx.restype = ci
+            gfx.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, i64, vp, i64, vp]
         lib.msda_bwd_workspace_bytes.restype = i64
         lib.msda_bwd_workspace_bytes.argtypes = [i64] * 7 + [ci]
         lib.msda_bwd_fused_workspace_bytes.restype = i64
         lib.msda_bwd_fused_workspace_bytes.argtypes = [i64] * 7 + [ci]
+        lib.msda_bwd_workspace_bytes_ex.restype = i64
+        lib.msda_bwd_workspace_bytes_ex.argtypes = [i64] * 7 + [ci, i64]
+        lib.msda_bwd_fused_workspace_bytes_ex.restype = i64
+        lib.msda_bwd_fused_workspace_bytes_ex.argtypes = [i64] * 7 + [ci, i64]
+        lib.msda_bwd_supported.restype = ci
+        lib.msda_bwd_supported.argtypes = [i64] * 7 + [ci]
         lib.msda_fused_lp_limit.restype = i64
         lib.msda_fused_lp_limit.argtypes = [i64, ci]
         lib.msda_hint_level_cells.restype = None

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <thread>
 
 #include "../../include/msda_hip.h"
 
@@ -30,10 +31,21 @@ static std::atomic<int> g_place_block{0};
 // each: with a stream / event pair shared by all callers, two threads issuing backwards on one device (autograd's
 // worker threads, different user streams) could interleave record(A) record(B) wait(.) and make the sample kernel wait
 // for the wrong work.  Inside one thread everything is in program order, whatever streams the caller alternates.
+static const std::thread::id g_loader_thread = std::this_thread::get_id();  // the thread that loaded the library
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     bool tried = false;
+    // a host thread that ends gives its stream and events back (thread pools, per-call worker threads); at process
+    // exit the runtime may already be gone: errors are swallowed
+    ~SideStream()
+    {
+        if (std::this_thread::get_id() == g_loader_thread) return;  // process exit: leave it to the runtime's teardown
+        if (join != nullptr) (void)hipEventDestroy(join);
+        if (fork != nullptr) (void)hipEventDestroy(fork);
+        if (stream != nullptr) (void)hipStreamDestroy(stream);
+        (void)hipGetLastError();
+    }
 };
 static thread_local SideStream t_side[64];
 
@@ -90,6 +102,7 @@ int option_level_cells()
     return g_level_cells.load(std::memory_order_relaxed);
 }
 void set_thread_level_cells(int64_t n) { t_level_cells = n > 0 ? n : 0; }
+int64_t get_thread_level_cells() { return t_level_cells; }
 int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
 int option_gather_win() { return g_gather_win.load(std::memory_order_relaxed); }
 int option_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
@@ -128,6 +141,44 @@ extern "C" int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t 
     // the sorted pipeline's own workspace (msda_launch.hpp: fused_mat_bytes)
     const int64_t mat = (B * Q * H * L * P * 3 * (int64_t)elem_size + 255) / 256 * 256;
     return mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
+}
+
+// the level-size bound as an argument: it becomes the thread's promise for the duration of the call
+namespace msda {
+struct LevelCellsScope {
+    int64_t saved;
+    bool on;
+    explicit LevelCellsScope(int64_t n) : saved(get_thread_level_cells()), on(n > 0)
+    {
+        if (on) set_thread_level_cells(n);
+    }
+    ~LevelCellsScope()
+    {
+        if (on) set_thread_level_cells(saved);
+    }
+};
+}  // namespace msda
+
+extern "C" int64_t msda_bwd_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
+                                               int64_t P, int elem_size, int64_t max_level_cells)
+{
+    const msda::LevelCellsScope scope(max_level_cells);
+    return msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, elem_size);
+}
+
+extern "C" int64_t msda_bwd_fused_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
+                                                     int64_t P, int elem_size, int64_t max_level_cells)
+{
+    const msda::LevelCellsScope scope(max_level_cells);
+    return msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, elem_size);
+}
+
+extern "C" int msda_bwd_supported_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
+
+extern "C" int msda_bwd_supported(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int elem_size)
+{
+    if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0 || elem_size <= 0) return 0;
+    return msda_bwd_supported_impl(B, I, H, D, Q, L, P, elem_size);
 }
 
 extern "C" int64_t msda_fused_lp_limit_impl(int64_t, int);

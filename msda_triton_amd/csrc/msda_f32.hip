@@ -20,6 +20,20 @@ extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_byte
     return (int64_t)(vec > sca ? vec : sca);
 }
 
+// can grad_value be produced for these sizes at all (include/msda_hip.h: msda_bwd_supported)
+extern "C" __attribute__((visibility("hidden"))) int msda_bwd_supported_impl(int64_t B, int64_t I, int64_t H, int64_t D,
+                                                                           int64_t Q, int64_t L, int64_t P, int elem_size)
+{
+    const msda::Dims d{B, I, H, D, Q, L, P};
+    if (L > MSDA_MAX_LEVELS) return 0;
+    if (B * Q * H * D == 0 || L * P == 0 || I == 0) return 1;  // all-zero gradients
+    switch (elem_size) {
+    case 8: return msda::sorted_fits<double>(d) || msda::small_fits<double>(d);
+    case 2: return msda::sorted_fits<_Float16>(d) || msda::small_fits<_Float16>(d);
+    default: return msda::sorted_fits<float>(d) || msda::small_fits<float>(d);
+    }
+}
+
 // largest L*P the fused-prologue kernels (msda_fwd_fused / msda_bwd_fused) take for this head dimension and
 // element size: all records of a unit must sit in LDS at once (plan_gather); the 16-byte vector path and the
 // backward's larger records give the smaller bound

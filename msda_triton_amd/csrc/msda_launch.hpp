@@ -27,6 +27,21 @@ int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurre
 hipStream_t side_stream_fork(hipStream_t user);   // side stream that waits for everything queued on `user`
 int side_stream_join(hipStream_t user);            // `user` waits for everything queued on the side stream
 void set_error(const char *fmt, ...);
+void set_thread_level_cells(int64_t n);   // this thread's promise about the level sizes (msda_hint_level_cells)
+int64_t get_thread_level_cells();
+// max_level_cells argument of the _ex entry points: the thread's promise for the duration of one call
+struct LevelCellsArg {
+    int64_t saved;
+    bool on;
+    explicit LevelCellsArg(int64_t n) : saved(get_thread_level_cells()), on(n > 0)
+    {
+        if (on) set_thread_level_cells(n);
+    }
+    ~LevelCellsArg()
+    {
+        if (on) set_thread_level_cells(saved);
+    }
+};
 
 constexpr int kRecordLdsBudget = 48 * 1024;                // per workgroup, parked sample records
 constexpr int kMaxDynLds = 160 * 1024 - 2048;  // leaves room for small static __shared__ objects
@@ -518,7 +533,7 @@ template <typename T, typename TV = T> inline int run_value_small(Params &p, con
     return vec_ok ? dispatch_value_small_group<T, VECF, TV>(p, lds, stream) : dispatch_value_small_group<T, 1, TV>(p, lds, stream);
 }
 
-// the sorted pipeline's record format: 4 level bits, 24-bit biased pixel index, 32-bit slot offsets
+// the sorted pipeline's record format: 5 level bits, 23-bit biased pixel index, 32-bit slot offsets
 template <typename T> inline bool sorted_fits(const Dims &d)
 {
     using A = typename Traits<T>::acc;
@@ -543,7 +558,7 @@ template <typename T> inline bool small_path_chosen(const Dims &d)
 
 // grad_value: the single-launch kernel for small problems (no workspace), else the sorted-gather pipeline in the
 // caller's workspace.  There is no third path: a large problem without (enough) workspace is an argument error, and
-// shapes beyond the sorted pipeline's record format (more than 16 levels, I >= 2^23, D beyond 32-bit slot offsets) are
+// shapes beyond the sorted pipeline's record format (I >= 2^22 pixels per plane, D beyond 32-bit slot offsets) are
 // unsupported for grad_value when they are also too large for the single-launch kernel.
 template <typename T, typename TV = T>
 inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspace_bytes, hipStream_t stream)
@@ -562,7 +577,7 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
     } else if (sorted) {
         rc = run_value_sorted<T, TV>(p, d, workspace, stream);
     } else if (!fits) {
-        set_error("grad_value: this shape is beyond the sorted pipeline's record format (L <= %d, I < 2^23, "
+        set_error("grad_value: this shape is beyond the sorted pipeline's record format (L <= %d, I < 2^22, "
                   "16*D*sizeof(acc) < 2^24, I*4*D*sizeof(acc) < 2^31) and too large for the single-launch kernel",
                   kSortedMaxLevels);
         return MSDA_ERR_UNSUPPORTED;
@@ -776,6 +791,29 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
     {                                                                                                            \
         return msda::run_bwd<T, TV>(grad_out, value, shapes, loc, attn, grad_value, grad_loc, grad_attn, B, I, H,   \
                                 D, Q, L, P, padding_mode, align_corners, workspace, workspace_bytes, stream);    \
+    }                                                                                                            \
+    extern "C" int msda_bwd_ex_##SUF(const void *grad_out, const void *value, const int64_t *shapes,            \
+                                     const void *loc, const void *attn, void *grad_value, void *grad_loc,       \
+                                     void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,    \
+                                     int64_t L, int64_t P, int padding_mode, int align_corners,                 \
+                                     int64_t max_level_cells, void *workspace, int64_t workspace_bytes,         \
+                                     void *stream)                                                               \
+    {                                                                                                            \
+        const msda::LevelCellsArg scope(max_level_cells);                                                        \
+        return msda::run_bwd<T, TV>(grad_out, value, shapes, loc, attn, grad_value, grad_loc, grad_attn, B, I, H,   \
+                                D, Q, L, P, padding_mode, align_corners, workspace, workspace_bytes, stream);    \
+    }                                                                                                            \
+    extern "C" int msda_bwd_fused_ex_##SUF(const void *grad_out, const void *value, const int64_t *shapes,      \
+                                           const void *proj, const void *ref, void *grad_value,                 \
+                                           void *grad_proj, void *grad_ref_partial, int64_t B, int64_t I,       \
+                                           int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int ref_dim,  \
+                                           int padding_mode, int align_corners, int64_t max_level_cells,        \
+                                           void *workspace, int64_t workspace_bytes, void *stream)              \
+    {                                                                                                            \
+        const msda::LevelCellsArg scope(max_level_cells);                                                        \
+        return msda::run_bwd_fused<T, TV>(grad_out, value, shapes, proj, ref, grad_value, grad_proj,                \
+                                      grad_ref_partial, B, I, H, D, Q, L, P, ref_dim, padding_mode,              \
+                                      align_corners, workspace, workspace_bytes, stream);                        \
     }                                                                                                            \
     extern "C" int msda_bwd_fused_##SUF(const void *grad_out, const void *value, const int64_t *shapes,         \
                                         const void *proj, const void *ref, void *grad_value, void *grad_proj,   \

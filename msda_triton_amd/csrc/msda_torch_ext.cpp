@@ -18,14 +18,16 @@ namespace {
 
 using FwdFn = int (*)(const void *, const int64_t *, const void *, const void *, void *, int64_t, int64_t, int64_t,
                       int64_t, int64_t, int64_t, int64_t, int, int, void *);
+// (the _ex forms: the level-size bound travels as an argument, include/msda_hip.h ABI 9)
 using BwdFn = int (*)(const void *, const void *, const int64_t *, const void *, const void *, void *, void *, void *,
-                      int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, void *, int64_t, void *);
+                      int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int64_t, void *, int64_t,
+                      void *);
 
 using FwdFusedFn = int (*)(const void *, const int64_t *, const void *, const void *, void *, int64_t, int64_t, int64_t,
                            int64_t, int64_t, int64_t, int64_t, int, int, int, void *);
 using BwdFusedFn = int (*)(const void *, const void *, const int64_t *, const void *, const void *, void *, void *, void *,
-                           int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, void *, int64_t,
-                           void *);
+                           int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, int64_t, void *,
+                           int64_t, void *);
 
 struct Fns {
     FwdFn fwd;
@@ -42,14 +44,14 @@ Fns fns_for(at::ScalarType t, at::ScalarType c)
         TORCH_CHECK_VALUE(c == at::kFloat && (t == at::kBFloat16 || t == at::kHalf),
                           "unsupported dtype combination: value ", t, " with ", c);
         if (t == at::kBFloat16)
-            return {msda_fwd_f32_vbf16, msda_bwd_f32_vbf16, msda_fwd_fused_f32_vbf16, msda_bwd_fused_f32_vbf16};
-        return {msda_fwd_f32_vf16, msda_bwd_f32_vf16, msda_fwd_fused_f32_vf16, msda_bwd_fused_f32_vf16};
+            return {msda_fwd_f32_vbf16, msda_bwd_ex_f32_vbf16, msda_fwd_fused_f32_vbf16, msda_bwd_fused_ex_f32_vbf16};
+        return {msda_fwd_f32_vf16, msda_bwd_ex_f32_vf16, msda_fwd_fused_f32_vf16, msda_bwd_fused_ex_f32_vf16};
     }
     switch (t) {
-    case at::kFloat: return {msda_fwd_f32, msda_bwd_f32, msda_fwd_fused_f32, msda_bwd_fused_f32};
-    case at::kHalf: return {msda_fwd_f16, msda_bwd_f16, msda_fwd_fused_f16, msda_bwd_fused_f16};
-    case at::kBFloat16: return {msda_fwd_bf16, msda_bwd_bf16, msda_fwd_fused_bf16, msda_bwd_fused_bf16};
-    case at::kDouble: return {msda_fwd_f64, msda_bwd_f64, msda_fwd_fused_f64, msda_bwd_fused_f64};
+    case at::kFloat: return {msda_fwd_f32, msda_bwd_ex_f32, msda_fwd_fused_f32, msda_bwd_fused_ex_f32};
+    case at::kHalf: return {msda_fwd_f16, msda_bwd_ex_f16, msda_fwd_fused_f16, msda_bwd_fused_ex_f16};
+    case at::kBFloat16: return {msda_fwd_bf16, msda_bwd_ex_bf16, msda_fwd_fused_bf16, msda_bwd_fused_ex_bf16};
+    case at::kDouble: return {msda_fwd_f64, msda_bwd_ex_f64, msda_fwd_fused_f64, msda_bwd_fused_ex_f64};
     default: TORCH_CHECK_VALUE(false, "unsupported dtype ", t);
     }
 }
@@ -78,20 +80,6 @@ torch::autograd::variable_list once_differentiable(const torch::autograd::variab
         "trying to differentiate twice a function that was marked with @once_differentiable", (int64_t)outs.size());
     return (*err)(std::move(outs));
 }
-
-struct LevelCellsHint {
-    const int64_t n;
-    explicit LevelCellsHint(int64_t cells) : n(cells)
-    {
-        if (n > 0) msda_hint_level_cells(n);
-    }
-    ~LevelCellsHint()
-    {
-        if (n > 0) msda_hint_level_cells(0);
-    }
-    LevelCellsHint(const LevelCellsHint &) = delete;
-    LevelCellsHint &operator=(const LevelCellsHint &) = delete;
-};
 
 void *current_stream(const at::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
@@ -125,9 +113,7 @@ public:
         const at::Tensor &img = saved[0], &shapes = saved[1], &pts = saved[2], &att = saved[3];
         const int padding_mode = (int)ctx->saved_data["padding_mode"].toInt();
         const bool align_corners = ctx->saved_data["align_corners"].toBool();
-        // the caller's promise about the level sizes (msda_hint_level_cells): for the workspace query and the launch
-        // on THIS thread (the autograd engine's), withdrawn when the scope ends
-        const LevelCellsHint hint(ctx->saved_data["level_cells"].toInt());
+        const int64_t level_cells = ctx->saved_data["level_cells"].toInt();  // bound on the largest level's cells (0: unknown)
         at::Tensor gout = grads[0].contiguous();
         if (gout.scalar_type() != pts.scalar_type()) gout = gout.to(pts.scalar_type());
         const bool want_value = ctx->needs_input_grad(0);
@@ -138,7 +124,7 @@ public:
         int64_t ws_bytes = 0;
         if (want_value) {
             g_img = at::empty_like(img);
-            ws_bytes = msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, (int)pts.element_size());
+            ws_bytes = msda_bwd_workspace_bytes_ex(B, I, H, D, Q, L, P, (int)pts.element_size(), level_cells);
             ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));  // scratch: no initialisation needed
         }
         if (want_sample) {
@@ -151,7 +137,7 @@ public:
                          .bwd(gout.data_ptr(), img.data_ptr(), shapes.data_ptr<int64_t>(), pts.data_ptr(), att.data_ptr(),
                               want_value ? g_img.data_ptr() : nullptr, want_sample ? g_pts.data_ptr() : nullptr,
                               want_sample ? g_att.data_ptr() : nullptr, B, I, H, D, Q, L, P, padding_mode,
-                              align_corners ? 1 : 0, want_value ? ws.data_ptr() : nullptr, ws_bytes, current_stream(img)),
+                              align_corners ? 1 : 0, level_cells, want_value ? ws.data_ptr() : nullptr, ws_bytes, current_stream(img)),
                      "msda_bwd");
         }
         return once_differentiable(grads, {g_img, at::Tensor(), ctx->needs_input_grad(2) ? g_pts : at::Tensor(),
@@ -193,7 +179,7 @@ public:
         const at::Tensor &img = saved[0], &shapes = saved[1], &proj = saved[2], &ref = saved[3];
         const int padding_mode = (int)ctx->saved_data["padding_mode"].toInt();
         const bool align_corners = ctx->saved_data["align_corners"].toBool();
-        const LevelCellsHint hint(ctx->saved_data["level_cells"].toInt());
+        const int64_t level_cells = ctx->saved_data["level_cells"].toInt();
         at::Tensor gout = grads[0].contiguous();
         if (gout.scalar_type() != proj.scalar_type()) gout = gout.to(proj.scalar_type());
         const bool want_value = ctx->needs_input_grad(0);
@@ -205,7 +191,7 @@ public:
         int64_t ws_bytes = 0;
         if (want_value) {
             g_img = at::empty_like(img);
-            ws_bytes = msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, (int)proj.element_size());
+            ws_bytes = msda_bwd_fused_workspace_bytes_ex(B, I, H, D, Q, L, P, (int)proj.element_size(), level_cells);
             ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));
         }
         {
@@ -214,7 +200,7 @@ public:
                          .bwd_fused(gout.data_ptr(), img.data_ptr(), shapes.data_ptr<int64_t>(), proj.data_ptr(),
                                     ref.data_ptr(), want_value ? g_img.data_ptr() : nullptr, g_proj.data_ptr(),
                                     g_ref_part.data_ptr(), B, I, H, D, Q, L, P, (int)ref_dim, padding_mode,
-                                    align_corners ? 1 : 0, want_value ? ws.data_ptr() : nullptr, ws_bytes,
+                                    align_corners ? 1 : 0, level_cells, want_value ? ws.data_ptr() : nullptr, ws_bytes,
                                     current_stream(img)),
                      "msda_bwd_fused");
         }

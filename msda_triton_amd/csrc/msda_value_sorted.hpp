@@ -44,12 +44,14 @@ constexpr int kCellBlock = 1024;      // threads of K1 / K3
 constexpr int kScanCells = 256;       // cells per K2 workgroup (= its thread count)
 constexpr int kCellLdsInts = 36864;   // cells a K1 / K3 workgroup keeps in LDS at a time (144 KiB)
 // record cell word: where the cell's rows go, decoded once by the place pass (the gather needs no division):
-//   bits 0-23  index of the cell's corner-00 pixel (x0, y0) inside the plane + kPixBias (virtual — possibly
-//              negative before the bias — when x0 or y0 is -1);  24-27 level;  28-31 which corners are pixels of the image
+//   bits 0-22  index of the cell's corner-00 pixel (x0, y0) inside the plane + kPixBias (virtual — possibly
+//              negative before the bias — when x0 or y0 is -1);  23-27 level;  28-31 which corners are pixels of the image
 // Two records belong to the same cell iff their words are equal (cells that alias one virtual index differ in the
 // validity bits).
-constexpr uint32_t kPixBias = 1u << 23;
-constexpr int kSortedMaxLevels = 16;  // 4 level bits (more levels: only problems the single-launch kernel takes)
+constexpr uint32_t kPixBias = 1u << 22;
+constexpr uint32_t kPixMask = 0x7FFFFFu;  // 23 bits: biased index < 2^22 + I, I < 2^22 (host check)
+constexpr int kLevelShift = 23;
+constexpr int kSortedMaxLevels = 32;  // 5 level bits = MSDA_MAX_LEVELS (round 3: 4 bits; L = 17..32 had no grad_value route beyond the single-launch kernel)
 
 // ------------------------------------------------------------------------------------------
 // sorted sample records.  float accumulate type: 16 bytes, the fractional offsets carried with 20 fractional bits
@@ -134,7 +136,7 @@ __device__ __forceinline__ bool sample_cell(A x, A y, int h, int w, int cstart, 
                            ((uint32_t)(xv1 && yv1) << 3);
     // start + iy * w + ix, biased: (iy + 1) * w is non-negative, so the 24-bit multiply applies
     const uint32_t pixq = (uint32_t)((int)kPixBias + start + (int)mul24((uint32_t)(iy + 1), (uint32_t)w) - w + ix);
-    cellw = (pixq & 0xFFFFFFu) | ((uint32_t)level << 24) | (valid << 28);
+    cellw = (pixq & kPixMask) | ((uint32_t)level << kLevelShift) | (valid << 28);
     return true;
 }
 
@@ -623,8 +625,8 @@ __global__ __launch_bounds__(GB) void msda_value_gather_kernel(const Params p)
         // one segment's rows -> the pixels' slots.  skip_right: the right-hand corners were carried over.
         auto flush = [&](bool skip_right) {
             if (!lane_ok) return;
-            const uint32_t base = mul24(cur_cellw & 0xFFFFFFu, rowstep) - bias_off + (uint32_t)c0 * (uint32_t)sizeof(A);
-            const uint32_t wstep = s_wstep[(cur_cellw >> 24) & 15u];
+            const uint32_t base = mul24(cur_cellw & kPixMask, rowstep) - bias_off + (uint32_t)c0 * (uint32_t)sizeof(A);
+            const uint32_t wstep = s_wstep[(cur_cellw >> kLevelShift) & 31u];
             const uint32_t dstep = (uint32_t)p.D * (uint32_t)sizeof(A);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {

@@ -29,6 +29,9 @@ from __future__ import annotations
 
 from typing import Literal, Optional, Tuple
 
+import warnings
+import weakref
+
 import torch
 import torch.distributed as dist
 from torch.autograd.function import Function
@@ -173,6 +176,8 @@ def row_segments(num_queries: int, r0: int, r1: int):
 
 
 _OWNER_GROUPS: dict = {}
+_WARNED_OWNERS_DOWNGRADE = False
+_OWNER_GROUPS_OF = None  # weakref to the default process group the cached sub-groups were made under
 
 
 def _owner_groups(B: int, Q: int, group):
@@ -182,15 +187,18 @@ def _owner_groups(B: int, Q: int, group):
     same order.  So the sub-groups are only made when ``group`` is the default group (every rank of the job runs the
     operator); for a caller-supplied sub-group the function returns None and the caller falls back to an all-reduce on
     ``group`` (ranks outside it never call the operator, so they could not take part in the group creation).
-    The cache is keyed on the default group's identity, so groups made before a ``destroy_process_group`` /
-    ``init_process_group`` cycle are never handed out again."""
+    Groups made before a ``destroy_process_group`` / ``init_process_group`` cycle are never handed out again."""
     default = dist.group.WORLD
     if group is not None and group is not default:
         return None
     world = dist.get_world_size(group)
-    key = (id(default), B, Q, world)
-    for stale in [k for k in _OWNER_GROUPS if k[0] != id(default)]:
-        del _OWNER_GROUPS[stale]
+    # The cache lives and dies with the default group OBJECT (a weak reference, not its id(): after a
+    # destroy_process_group / init_process_group cycle the new default group can be allocated at the freed one's address)
+    global _OWNER_GROUPS_OF
+    if _OWNER_GROUPS_OF is None or _OWNER_GROUPS_OF() is not default:
+        _OWNER_GROUPS.clear()
+        _OWNER_GROUPS_OF = weakref.ref(default)
+    key = (B, Q, world)
     if key in _OWNER_GROUPS:
         return _OWNER_GROUPS[key]
     rows = B * Q
@@ -425,6 +433,11 @@ def row_sharded_multiscale_deformable_attention(
     owners = _owner_groups(B, Q, group) if (grad_value_sync == "owners" and img.requires_grad) else None
     if grad_value_sync == "owners" and img.requires_grad and owners is None:
         grad_value_sync = "all_reduce"  # a caller-supplied sub-group: see _owner_groups
+        global _WARNED_OWNERS_DOWNGRADE
+        if not _WARNED_OWNERS_DOWNGRADE:
+            _WARNED_OWNERS_DOWNGRADE = True
+            warnings.warn("grad_value_sync='owners' needs sub-groups of the DEFAULT process group; on a caller-supplied "
+                          "group grad_value is all-reduced over that group instead", stacklevel=2)
     if overlap_chunks is None:  # exchange piece by piece only when a piece is worth a message (>= ~2k rows); the
         # count must be the same on every rank, so it follows the nominal shard size, not this rank's
         overlap_chunks = max(1, min(4, -(-rows // world) // 2048)) if world > 1 else 1

@@ -82,6 +82,26 @@ def _shapes_i64(img_shapes: torch.Tensor) -> torch.Tensor:
     return img_shapes.to(torch.int64).contiguous()  # stays on the device: no host sync
 
 
+_BWD_SUPPORTED: dict = {}  # (B, I, H, D, Q, L, P, element size) -> msda_bwd_supported
+
+
+def check_backward_supported(img, sampling_points) -> None:
+    """Raise at FORWARD time when the value pyramid needs a gradient the library cannot produce for these sizes (a plane
+    of 2^22 pixels or more, or a head dimension beyond the sorted pipeline's 32-bit slot offsets, on a problem too
+    large for the single-launch kernel) — not from the backward in the middle of a training step."""
+    B, I, H, D = img.shape
+    _, Q, _, L, P = sampling_points.shape[:5]
+    key = (B, I, H, D, Q, L, P, sampling_points.element_size())
+    ok = _BWD_SUPPORTED.get(key)
+    if ok is None:
+        ok = _BWD_SUPPORTED[key] = bool(_lib.load().msda_bwd_supported(*key))
+    if not ok:
+        raise ValueError(
+            f"`img` requires a gradient, but grad_value is not available for this shape (I={I} pixels per plane, D={D}, "
+            f"Q={Q}): the sorted pipeline addresses planes below 2^22 pixels with 4*I*D*sizeof(acc) < 2^31 bytes of "
+            "partial rows.  Detach `img` or split the pyramid.")
+
+
 def _check_devices(*tensors: torch.Tensor) -> torch.device:
     """All tensors must live on ONE gpu (reference: frontend.py:93-95).  Raised before any ``data_ptr()`` is handed
     to the library: a host or foreign-device pointer would otherwise fault inside the kernel."""
@@ -206,9 +226,9 @@ def msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mo
     return out
 
 
-def level_cells_of(level_shapes) -> int:
+def level_cells_of(level_shapes, num_levels: Optional[int] = None, num_pixels: Optional[int] = None) -> int:
     """``level_shapes``: the pyramid's (height, width) pairs AS HOST NUMBERS (e.g. Hugging Face's
-    ``spatial_shapes_list``), or None.  Returns the bound ``msda_hint_level_cells`` takes — the bilinear cells of the
+    ``spatial_shapes_list``), or None.  Returns the bound ``msda_bwd_ex_<dtype>`` takes as ``max_level_cells`` — the bilinear cells of the
     largest level, (h + 1) * (w + 1) — or 0 for "unknown".  With it the backward can use its single-launch grad_value
     kernel on decoder-sized calls over real-image pyramids (include/msda_hip.h); it must describe the same pyramid as
     the ``img_shapes`` tensor (a level larger than promised gets NaN gradients)."""
@@ -219,7 +239,14 @@ def level_cells_of(level_shapes) -> int:
             raise ValueError("`level_shapes` should be host numbers (a device tensor would need a synchronisation); "
                              "pass e.g. `spatial_shapes_list`")
         level_shapes = level_shapes.tolist()
-    return max(((int(h) + 1) * (int(w) + 1) for h, w in level_shapes), default=0)
+    level_shapes = [(int(h), int(w)) for h, w in level_shapes]
+    # what can be checked without reading `img_shapes` back from the device: the level count and the pixel total of
+    # the call it is supposed to describe (a list describing another pyramid would give NaN grad_value rows)
+    if num_levels is not None and len(level_shapes) != num_levels:
+        raise ValueError(f"`level_shapes` has {len(level_shapes)} levels, `img_shapes` {num_levels}")
+    if num_pixels is not None and sum(h * w for h, w in level_shapes) != num_pixels:
+        raise ValueError(f"`level_shapes` describes {sum(h * w for h, w in level_shapes)} pixels, `img` has {num_pixels}")
+    return max(((h + 1) * (w + 1) for h, w in level_shapes), default=0)
 
 
 def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners,
@@ -266,20 +293,14 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
     g_att = buf(2, (B, Q, H, L, P), want_sample, cdt)
     if want_value or want_sample:
         lib = _lib.load()
-        fn = getattr(lib, f"msda_bwd_{suf}")
+        fn = getattr(lib, f"msda_bwd_ex_{suf}")  # (the level-size bound travels as an argument: include/msda_hip.h, ABI 9)
         ws, ws_bytes = None, 0
         level_cells = int(level_cells)
         if want_value:  # scratch for the inverted index; the caching allocator makes this cheap
             key = (B, I, H, D, Q, L, P, sampling_points.element_size(), _lib.OPTION_EPOCH, level_cells)
             ws_bytes = _WS_BYTES.get(key)
             if ws_bytes is None:
-                if level_cells > 0:  # the size depends on this thread's promise too
-                    lib.msda_hint_level_cells(level_cells)
-                try:
-                    ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes(*key[:8]))
-                finally:
-                    if level_cells > 0:
-                        lib.msda_hint_level_cells(0)
+                ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes_ex(*key[:8], level_cells))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
         def call(value_part: bool, sample_part: bool):
@@ -288,27 +309,21 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
                       g_img.data_ptr() if value_part else None,
                       g_pts.data_ptr() if sample_part else None,
                       g_att.data_ptr() if sample_part else None,
-                      B, I, H, D, Q, L, P, pad, int(bool(align_corners)),
+                      B, I, H, D, Q, L, P, pad, int(bool(align_corners)), level_cells,
                       ws.data_ptr() if (ws is not None and value_part) else None, ws_bytes,
                       _stream_ptr(img.device))
 
-        if level_cells > 0:  # this thread's promise for the launch; withdrawn whatever happens
-            lib.msda_hint_level_cells(level_cells)
-        try:
-            with _OnDevice(img.device):
-                timer = KernelTimer.active
-                if timer is None:
-                    rc = call(want_value, want_sample)
-                else:  # one C-ABI call per kernel so each gets its own event pair
-                    rc = 0
-                    if want_sample:
-                        rc = timer.launch("msda_bwd_sample", img.device, lambda: call(False, True))
-                    if rc == 0 and want_value:
-                        rc = timer.launch("msda_bwd_value", img.device, lambda: call(True, False))
-        finally:
-            if level_cells > 0:
-                lib.msda_hint_level_cells(0)
-        _lib.check(rc, f"msda_bwd_{suf}")
+        with _OnDevice(img.device):
+            timer = KernelTimer.active
+            if timer is None:
+                rc = call(want_value, want_sample)
+            else:  # one C-ABI call per kernel so each gets its own event pair
+                rc = 0
+                if want_sample:
+                    rc = timer.launch("msda_bwd_sample", img.device, lambda: call(False, True))
+                if rc == 0 and want_value:
+                    rc = timer.launch("msda_bwd_value", img.device, lambda: call(True, False))
+        _lib.check(rc, f"msda_bwd_ex_{suf}")
     return g_img, (g_pts if needs[1] else None), (g_att if needs[2] else None)
 
 
@@ -320,6 +335,8 @@ class _HipMultiscaleDeformableAttentionFunction(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # under autocast the op runs in fp32 (frontend.py:111)
     def forward(ctx, img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners, level_cells=0):
+        if ctx.needs_input_grad[0]:
+            check_backward_supported(img, sampling_points)
         ctx.save_for_backward(img, img_shapes, sampling_points, attention_weights)
         ctx.padding_mode = padding_mode
         ctx.align_corners = align_corners
@@ -370,11 +387,13 @@ def hip_multiscale_deformable_attention(
     if ext is not None and KernelTimer.active is None and not _autocast_on():
         _dims(img, sampling_points, attention_weights, img_shapes)
         _shapes_i64(img_shapes)
+        if img.requires_grad and torch.is_grad_enabled():
+            check_backward_supported(img, sampling_points)
         return ext.msda(img, img_shapes, sampling_points, attention_weights, _padding_code(padding_mode),
-                        bool(align_corners), level_cells_of(level_shapes))
+                        bool(align_corners), level_cells_of(level_shapes, img_shapes.shape[0], img.shape[1]))
     return _HipMultiscaleDeformableAttentionFunction.apply(
         img, img_shapes, sampling_points, attention_weights, padding_mode, bool(align_corners),
-        level_cells_of(level_shapes))
+        level_cells_of(level_shapes, img_shapes.shape[0], img.shape[1]))
 
 
 # ------------------------------------------------------------------------------------------
@@ -458,31 +477,25 @@ def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, paddin
     g_proj = torch.empty((B, Q, H, L, P, 3), **kw)
     g_ref_part = torch.empty((B, Q, H, ref_dim), **kw)
     lib = _lib.load()
-    fn = getattr(lib, f"msda_bwd_fused_{suf}")
+    fn = getattr(lib, f"msda_bwd_fused_ex_{suf}")
     ws, ws_bytes = None, 0
-    level_cells = int(level_cells)
-    if level_cells > 0:  # this thread's promise (level_cells_of) for the size query and the launch; withdrawn below
-        lib.msda_hint_level_cells(level_cells)
-    try:
-        if need_img:
-            ws_bytes = int(lib.msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, proj.element_size()))
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
+    level_cells = int(level_cells)  # the level-size bound (level_cells_of), an argument of the size query and the launch
+    if need_img:
+        ws_bytes = int(lib.msda_bwd_fused_workspace_bytes_ex(B, I, H, D, Q, L, P, proj.element_size(), level_cells))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
-        def call():
-            return fn(out_grad.data_ptr(), img.data_ptr(), shapes.data_ptr(), proj.data_ptr(), reference_points.data_ptr(),
-                      g_img.data_ptr() if need_img else None, g_proj.data_ptr(), g_ref_part.data_ptr(),
-                      B, I, H, D, Q, L, P, ref_dim, pad, int(bool(align_corners)),
-                      ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(img.device))
+    def call():
+        return fn(out_grad.data_ptr(), img.data_ptr(), shapes.data_ptr(), proj.data_ptr(), reference_points.data_ptr(),
+                  g_img.data_ptr() if need_img else None, g_proj.data_ptr(), g_ref_part.data_ptr(),
+                  B, I, H, D, Q, L, P, ref_dim, pad, int(bool(align_corners)), level_cells,
+                  ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(img.device))
 
-        with _OnDevice(img.device):
-            timer = KernelTimer.active
-            rc = timer.launch("msda_bwd_fused", img.device, call) if timer else call()
-    finally:
-        if level_cells > 0:
-            lib.msda_hint_level_cells(0)
+    with _OnDevice(img.device):
+        timer = KernelTimer.active
+        rc = timer.launch("msda_bwd_fused", img.device, call) if timer else call()
     if rc == -5:  # MSDA_ERR_UNSUPPORTED
         return None
-    _lib.check(rc, f"msda_bwd_fused_{suf}")
+    _lib.check(rc, f"msda_bwd_fused_ex_{suf}")
     return g_img, g_proj, g_ref_part.sum(dim=2)
 
 
@@ -539,7 +552,7 @@ def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, ali
     """``multiscale_deformable_attention(img, img_shapes, *module_sampling_inputs(proj, ...))`` — on GPU tensors
     with the prologue fused into the forward kernel; on host tensors exactly that composition.  ``level_shapes``: the
     level sizes as host numbers, optional (:func:`level_cells_of`)."""
-    level_cells = level_cells_of(level_shapes)
+    level_cells = level_cells_of(level_shapes, img_shapes.shape[0], img.shape[1])
     if img.device.type == "cuda" and img_shapes.device != img.device:
         # the level table is a handful of integers: follow `img` (the reference's module accepts a host-resident
         # img_shapes next to GPU tensors through its fallback, frontend.py:170-172)

@@ -1152,3 +1152,15 @@ def test_torch_compile_module_keeps_the_fused_kernels():
     pr = torch.randn(2, 21, 4, 2, 3, 3, device=DEV)
     torch.library.opcheck(torch.ops.msda_amd.fused_forward.default, (v, s, pr, ref, False, True),
                           test_utils=("test_schema", "test_faketensor"))
+
+
+def test_seventeen_levels_beyond_the_single_launch_kernel(oracle):
+    """L = 17 with Q*P > 4096 (too many samples for the single-launch kernel, more levels than the round-3
+    record format's 4 level bits) had no grad_value route.  The cell word now carries 5 level bits."""
+    rng = np.random.default_rng(17)
+    levels = [(6, 5), (4, 7), (3, 3), (8, 2), (2, 9), (5, 5), (1, 6), (7, 1), (4, 4), (3, 6), (2, 2), (6, 3), (1, 1), (5, 2),
+              (2, 7), (3, 4), (9, 9)]
+    c = rand_case(rng, 1, 1100, 2, 8, levels, 4)
+    assert 1100 * 4 > 4096 and len(levels) == 17
+    for pm, ac in MODES:
+        check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float32], BWD_TOL[torch.float32])

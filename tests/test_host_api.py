@@ -305,3 +305,24 @@ def test_level_cells_of_host_shapes():
     assert level_cells_of([(100, 134), (50, 67)]) == 101 * 135
     assert level_cells_of(torch.tensor([[8, 8], [64, 3]])) == 65 * 4
     assert level_cells_of(((1, 1),)) == 4
+
+
+def test_backward_support_query_and_forward_time_rejection():
+    """shapes beyond the sorted pipeline's record format used to surface as MSDA_ERR_UNSUPPORTED from the
+    BACKWARD, mid-training.  The library now answers at forward time (host arithmetic, no GPU): L = 17..32 is served
+    (5 level bits), a plane whose partial rows would not fit 32-bit offsets is refused with a clear ValueError."""
+    import torch
+    from msda_triton_amd import _lib
+    from msda_triton_amd.functional import check_backward_supported
+    lib = _lib.load()
+    assert lib.msda_bwd_supported(4, 5440, 8, 32, 10000, 4, 4, 4) == 1          # c2 @ 10k
+    assert lib.msda_bwd_supported(1, 2000, 2, 8, 5000, 17, 4, 4) == 1           # 17 levels, Q*P > 4096: sorted pipeline
+    assert lib.msda_bwd_supported(1, 2000, 2, 8, 5000, 32, 4, 4) == 1
+    assert lib.msda_bwd_supported(1, 2000, 2, 8, 5000, 33, 4, 4) == 0           # > MSDA_MAX_LEVELS
+    assert lib.msda_bwd_supported(1, 600000, 1, 256, 5000, 1, 4, 4) == 0        # I*4*D*4 bytes >= 2^31
+    assert lib.msda_bwd_supported(1, 1 << 22, 1, 8, 5000, 1, 4, 4) == 0         # 2^22 pixels in one plane
+    img = torch.empty(1, 600000, 1, 256, device="meta")
+    pts = torch.empty(1, 5000, 1, 1, 4, 2, device="meta")
+    with pytest.raises(ValueError, match="grad_value is not available"):
+        check_backward_supported(img, pts)
+    check_backward_supported(torch.empty(4, 5440, 8, 32, device="meta"), torch.empty(4, 10000, 8, 4, 4, 2, device="meta"))
