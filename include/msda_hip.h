@@ -155,10 +155,44 @@ MSDA_DECLARE_EX(f64)
 MSDA_DECLARE_EX(f32_vbf16)
 MSDA_DECLARE_EX(f32_vf16)
 #undef MSDA_DECLARE_EX
+/* elem_size: of everything but `value`; value_elem_size: of `value` / `grad_value` (0: the same — 2 next to elem_size 4
+ * for the mixed-storage entry points) */
 MSDA_API int64_t msda_bwd_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                             int64_t P, int elem_size, int64_t max_level_cells);
+                                             int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells);
 MSDA_API int64_t msda_bwd_fused_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                                   int64_t P, int elem_size, int64_t max_level_cells);
+                                                   int64_t P, int elem_size, int value_elem_size,
+                                                   int64_t max_level_cells);
+
+/*
+ * Forward entry points with an OPTIONAL workspace (ABI 9).  When a row of `value` has exactly 64 bytes (D = 32 in
+ * bf16 / fp16, D = 16 in fp32) two rows share one 128-byte cache line, and the four corner rows of a bilinear footprint
+ * are four half-used lines.  Given msda_fwd_workspace_bytes(...) of workspace (256-byte aligned) the library first
+ * builds an x-pair table there — entry p = the rows of pixels p and p + 1 of one head, one line — and gathers from
+ * it: both x-corners of a footprint row come from one line (the gather alone: 15.5 -> 8.1 ps per sample,
+ * profiles/r04_row_pair_bench.txt).  An internal layout: the tensors' conventions do not change, results agree with
+ * the plain entry points to rounding.  workspace == NULL (or too small, or another row size: the query returns 0) is
+ * exactly msda_fwd_<dtype> / msda_fwd_fused_<dtype>.  The backward takes its table from the workspace it already has
+ * (msda_bwd_workspace_bytes includes the room).  The layout is OFF unless msda_set_option("pairs", 1): measured at c3
+ * it does not pay yet (see the option's note below); with it off the query returns 0 and these are the plain calls.
+ */
+#define MSDA_DECLARE_FWD_EX(SUF)                                                                              \
+    MSDA_API int msda_fwd_ex_##SUF(const void *value, const int64_t *shapes, const void *loc,                 \
+                       const void *attn, void *out, int64_t B, int64_t I, int64_t H, int64_t D,               \
+                       int64_t Q, int64_t L, int64_t P, int padding_mode, int align_corners,                  \
+                       void *workspace, int64_t workspace_bytes, void *stream);                               \
+    MSDA_API int msda_fwd_fused_ex_##SUF(const void *value, const int64_t *shapes, const void *proj,          \
+                       const void *ref, void *out, int64_t B, int64_t I, int64_t H, int64_t D,                \
+                       int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,                        \
+                       int align_corners, void *workspace, int64_t workspace_bytes, void *stream);
+MSDA_DECLARE_FWD_EX(f32)
+MSDA_DECLARE_FWD_EX(f16)
+MSDA_DECLARE_FWD_EX(bf16)
+MSDA_DECLARE_FWD_EX(f64)
+MSDA_DECLARE_FWD_EX(f32_vbf16)
+MSDA_DECLARE_FWD_EX(f32_vf16)
+#undef MSDA_DECLARE_FWD_EX
+/* value_elem_size = sizeof of the value pyramid's storage type */
+MSDA_API int64_t msda_fwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int value_elem_size);
 
 /*
  * 1 when msda_bwd_<dtype> can produce grad_value for these sizes, 0 when it would return MSDA_ERR_UNSUPPORTED (a plane
@@ -215,6 +249,13 @@ MSDA_API const char *msda_last_error(void);
  *                1: bitwise reproducible grad_value: the place pass runs one wave per query slice and ranks the samples
  *                   of a cell by index (no atomics at all); small problems take the sorted pipeline too (workspace
  *                   needed); slower
+ *   "pairs"      0 (default): never;  1: pyramids with 64-byte rows are gathered through an x-pair table where the
+ *                   caller gave the workspace for it (msda_fwd_ex_<dtype>, msda_bwd_<dtype>).  Off by default: the
+ *                   gather itself gets 1.85x faster (profiles/r04_row_pair_bench.txt) but the kernels around it only
+ *                   1.05-1.2x, which the 11 us table build per call eats (c3: fwd 86 -> 72 + 11 us, sample gradients
+ *                   90 -> 86 + 11 us)
+ *   "place_path" 0 (default): the level-major place pass where a plane has at least as many samples as cell-table
+ *                   entries;  1: the plane-major pass always;  2: the level-major pass always
  *   "level_cells" 0 (default): unknown;  n: process-wide form of msda_hint_level_cells(n)
  *   "cell_slices", "small_ns", "gather_win", "wg_target", "debug": experiment knobs, see
  *                msda_triton_amd/csrc/msda_launch.hpp and msda_value_sorted.hpp

@@ -22,10 +22,11 @@ DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64", "f32_vbf16", "f32_vf16")
 
 # every symbol include/msda_hip.h declares
 EXPORTED_SYMBOLS = tuple(
-    [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused", "bwd_fused", "bwd_ex", "bwd_fused_ex") for s in DTYPE_SUFFIXES]
+    [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused", "bwd_fused", "fwd_ex", "fwd_fused_ex", "bwd_ex", "bwd_fused_ex")
+     for s in DTYPE_SUFFIXES]
     + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option", "msda_bwd_workspace_bytes",
        "msda_bwd_fused_workspace_bytes", "msda_bwd_workspace_bytes_ex", "msda_bwd_fused_workspace_bytes_ex",
-       "msda_bwd_supported", "msda_fused_lp_limit", "msda_hint_level_cells"]
+       "msda_fwd_workspace_bytes", "msda_bwd_supported", "msda_fused_lp_limit", "msda_hint_level_cells"]
 )
 
 _lib = None
@@ -79,6 +80,13 @@ def load():
             gf = getattr(lib, f"msda_bwd_fused_{suf}")
             gf.restype = ci
             gf.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, vp, i64, vp]
+            # ... with an optional workspace (x-pair table of a pyramid with 64-byte rows)
+            fx = getattr(lib, f"msda_fwd_ex_{suf}")
+            fx.restype = ci
+            fx.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, vp, i64, vp]
+            ffx = getattr(lib, f"msda_fwd_fused_ex_{suf}")
+            ffx.restype = ci
+            ffx.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, ci, vp, i64, vp]
             # ... with the level-size bound as an argument (max_level_cells, 0: unknown)
             gx = getattr(lib, f"msda_bwd_ex_{suf}")
             gx.restype = ci
@@ -91,9 +99,11 @@ def load():
         lib.msda_bwd_fused_workspace_bytes.restype = i64
         lib.msda_bwd_fused_workspace_bytes.argtypes = [i64] * 7 + [ci]
         lib.msda_bwd_workspace_bytes_ex.restype = i64
-        lib.msda_bwd_workspace_bytes_ex.argtypes = [i64] * 7 + [ci, i64]
+        lib.msda_bwd_workspace_bytes_ex.argtypes = [i64] * 7 + [ci, ci, i64]
         lib.msda_bwd_fused_workspace_bytes_ex.restype = i64
-        lib.msda_bwd_fused_workspace_bytes_ex.argtypes = [i64] * 7 + [ci, i64]
+        lib.msda_bwd_fused_workspace_bytes_ex.argtypes = [i64] * 7 + [ci, ci, i64]
+        lib.msda_fwd_workspace_bytes.restype = i64
+        lib.msda_fwd_workspace_bytes.argtypes = [i64] * 4 + [ci]
         lib.msda_bwd_supported.restype = ci
         lib.msda_bwd_supported.argtypes = [i64] * 7 + [ci]
         lib.msda_fused_lp_limit.restype = i64

@@ -25,6 +25,7 @@ static std::atomic<int> g_gather_win{0};
 static std::atomic<int> g_deterministic{0};
 static std::atomic<int> g_place_path{0};
 static std::atomic<int> g_place_block{0};
+static std::atomic<int> g_pairs{0};
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
 // Per THREAD, because the fork (record on the user's stream, wait on the side stream) and the join are two calls
@@ -108,6 +109,7 @@ int option_gather_win() { return g_gather_win.load(std::memory_order_relaxed); }
 int option_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
 int option_place_path() { return g_place_path.load(std::memory_order_relaxed); }
 int option_place_block() { return g_place_block.load(std::memory_order_relaxed); }
+int option_pairs() { return g_pairs.load(std::memory_order_relaxed); }
 
 void set_error(const char *fmt, ...)
 {
@@ -126,11 +128,24 @@ extern "C" void msda_hint_level_cells(int64_t max_level_cells) { msda::set_threa
 // the layout lives in a device header (msda_value_sorted.hpp); msda_f32.hip exposes its size formula
 extern "C" int64_t msda_bwd_workspace_bytes_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
 
+// room for the x-pair table (rows of exactly 64 bytes of the value storage type; msda_launch.hpp pair_table_bytes)
+static int64_t pair_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int value_elem_size)
+{
+    if (msda::option_pairs() == 0 || value_elem_size <= 0 || D * value_elem_size != 64 || B > 65535) return 0;
+    return (B * H * I * 128 + 255) / 256 * 256;
+}
+
+extern "C" int64_t msda_fwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int value_elem_size)
+{
+    if (B < 0 || I < 0 || H < 0 || D < 0) return 0;
+    return pair_bytes(B, I, H, D, value_elem_size);
+}
+
 extern "C" int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
                                             int64_t P, int elem_size)
 {
     if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0) return 0;
-    return msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
+    return pair_bytes(B, I, H, D, elem_size) + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
 }
 
 extern "C" int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
@@ -140,7 +155,7 @@ extern "C" int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t 
     // the derived sampling points + attention weights (3 elements per sample, rounded up to 256 bytes), then
     // the sorted pipeline's own workspace (msda_launch.hpp: fused_mat_bytes)
     const int64_t mat = (B * Q * H * L * P * 3 * (int64_t)elem_size + 255) / 256 * 256;
-    return mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
+    return pair_bytes(B, I, H, D, elem_size) + mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
 }
 
 // the level-size bound as an argument: it becomes the thread's promise for the duration of the call
@@ -160,17 +175,22 @@ struct LevelCellsScope {
 }  // namespace msda
 
 extern "C" int64_t msda_bwd_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                               int64_t P, int elem_size, int64_t max_level_cells)
+                                               int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells)
 {
+    if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0) return 0;
     const msda::LevelCellsScope scope(max_level_cells);
-    return msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, elem_size);
+    return pair_bytes(B, I, H, D, value_elem_size > 0 ? value_elem_size : elem_size) +
+           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
 }
 
 extern "C" int64_t msda_bwd_fused_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                                     int64_t P, int elem_size, int64_t max_level_cells)
+                                                     int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells)
 {
+    if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0 || elem_size <= 0) return 0;
     const msda::LevelCellsScope scope(max_level_cells);
-    return msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, elem_size);
+    const int64_t mat = (B * Q * H * L * P * 3 * (int64_t)elem_size + 255) / 256 * 256;
+    return pair_bytes(B, I, H, D, value_elem_size > 0 ? value_elem_size : elem_size) + mat +
+           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
 }
 
 extern "C" int msda_bwd_supported_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
@@ -233,6 +253,10 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_place_block.store(value, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "pairs") == 0) {
+        msda::g_pairs.store(value ? 1 : 0, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "cell_slices") == 0 && value >= 0 && value <= 64) {
         msda::g_cell_slices.store(value, std::memory_order_relaxed);
         return 0;
@@ -260,6 +284,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "deterministic") == 0) return msda::option_deterministic();
     if (key && strcmp(key, "place_path") == 0) return msda::option_place_path();
     if (key && strcmp(key, "place_block") == 0) return msda::option_place_block();
+    if (key && strcmp(key, "pairs") == 0) return msda::option_pairs();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

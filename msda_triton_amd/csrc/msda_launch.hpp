@@ -155,7 +155,8 @@ inline void plan_gather(int NU, int LP, size_t acc_bytes, int &sc, size_t &lds, 
 }
 
 // MODE 0: forward, 1: grad_loc/grad_attn, 2: fused forward, 3: fused backward (sample half)
-template <typename T, int VEC, int G, int MODE, typename TV = T> inline int launch_gather(Params &p, hipStream_t stream)
+// PAIR: value rows from the x-pair table (p.pairs); G then counts both halves of a unit's lanes
+template <typename T, int VEC, int G, int MODE, typename TV = T, bool PAIR = false> inline int launch_gather(Params &p, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
     constexpr int NU = kBlock / G;
@@ -178,19 +179,19 @@ template <typename T, int VEC, int G, int MODE, typename TV = T> inline int laun
     }
     static std::atomic<uint64_t> big_lds_done{0};  // one per template instantiation
     if constexpr (MODE == 3) {
-        auto kernel = msda_bwd_sample_kernel<T, VEC, G, true, TV>;
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, true, TV, PAIR>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else if constexpr (MODE == 1) {
-        auto kernel = msda_bwd_sample_kernel<T, VEC, G, false, TV>;
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, false, TV, PAIR>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else if constexpr (MODE == 2) {
-        auto kernel = msda_fwd_kernel<T, VEC, G, true, TV>;
+        auto kernel = msda_fwd_kernel<T, VEC, G, true, TV, PAIR>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else {
-        auto kernel = msda_fwd_kernel<T, VEC, G, false, TV>;
+        auto kernel = msda_fwd_kernel<T, VEC, G, false, TV, PAIR>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     }
@@ -214,6 +215,47 @@ template <typename T, int MODE, typename TV = T> inline int dispatch_gather(Para
     constexpr int VECF = 16 / sizeof(T);  // channels per lane (mixed storage: the 16-bit value rows load as 8-byte pieces)
     if (vec_ok && (p.D % VECF) == 0) return dispatch_group<T, VECF, MODE, TV>(p, stream);
     return dispatch_group<T, 1, MODE, TV>(p, stream);
+}
+
+// ---- x-pair table of the value pyramid (msda_kernels.hpp, PAIR): for rows of exactly 64 bytes ----
+int option_pairs();  // 0: never; else where the shape qualifies and the caller gave workspace (msda_api.hip)
+
+// does the pair layout apply to this value storage type and head dimension?
+template <typename TV> inline bool pair_shape_ok(int64_t D) { return D * (int64_t)sizeof(TV) == 64; }
+inline size_t pair_table_bytes(int64_t B, int64_t I, int64_t H) { return align_up((size_t)(B * H * I) * 128, 256); }
+
+// lanes of a PAIR unit: two halves of (64 bytes / bytes per lane)
+template <typename T, typename TV> constexpr int pair_group()
+{
+    constexpr int VECF = 16 / (int)sizeof(T);            // channels per lane
+    return 2 * (64 / (VECF * (int)sizeof(TV)));           // T = TV 16 bit: 8;  fp32 next to a 16-bit pyramid: 16;  fp32 / fp64 rows of 64 bytes: 8
+}
+
+template <typename TV> inline int build_pairs(const void *value, void *pairs, const Dims &d, hipStream_t stream)
+{
+    const int row16 = (int)(d.D * (int64_t)sizeof(TV) / 16);
+    const long long n = (long long)d.I * d.H * row16;
+    if (d.B > 65535 || n >= ((long long)1 << 31) * kBlock) return MSDA_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(msda_pairs_build_kernel<0>, dim3((unsigned)((n + kBlock - 1) / kBlock), (unsigned)d.B), dim3(kBlock), 0, stream,
+                       static_cast<const uint4 *>(value), static_cast<uint4 *>(pairs), (int)d.I, (int)d.H, row16);
+    return (int)hipGetLastError();
+}
+
+// the gather kernels on the pair table: MODE as in launch_gather
+template <typename T, int MODE, typename TV> inline int dispatch_gather_pairs(Params &p, hipStream_t stream)
+{
+    constexpr int VECF = 16 / sizeof(T);
+    return launch_gather<T, VECF, pair_group<T, TV>(), MODE, TV, true>(p, stream);
+}
+
+// can this call take the pair kernels?  (16-byte vector path, rows of 64 bytes, enough aligned workspace for the table)
+template <typename T, typename TV>
+inline bool pairs_ok(const Params &p, const Dims &d, bool vec_ok, const void *workspace, int64_t workspace_bytes)
+{
+    constexpr int VECF = 16 / sizeof(T);
+    return option_pairs() != 0 && vec_ok && pair_shape_ok<TV>(d.D) && (d.D % VECF) == 0 && d.B <= 65535 &&
+           workspace != nullptr && aligned_to(workspace, 256) && (uint64_t)workspace_bytes >= pair_table_bytes(d.B, d.I, d.H) &&
+           (size_t)d.I * 128 < ((size_t)1 << 31);
 }
 
 // ---- sorted (gather-formulated) grad_value: K1..K5 of msda_value_sorted.hpp ----
@@ -396,10 +438,11 @@ inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_co
     p.div_h = make_fast_div((uint32_t)d.H);
 }
 
+// workspace (optional, msda_fwd_workspace_bytes): room for the x-pair table of a pyramid with 64-byte rows
 template <typename T, typename TV = T>
 int run_fwd(const void *value, const int64_t *shapes, const void *loc, const void *attn, void *out, int64_t B,
             int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int padding_mode, int align_corners,
-            void *stream_)
+            void *stream_, void *workspace = nullptr, int64_t workspace_bytes = 0)
 {
     const Dims d{B, I, H, D, Q, L, P};
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -427,7 +470,13 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
     p.out = out;
     fill_params(p, d, padding_mode, align_corners);
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
-    rc = dispatch_gather<T, 0, TV>(p, vec_ok, stream);
+    if (pairs_ok<T, TV>(p, d, vec_ok, workspace, workspace_bytes)) {
+        rc = build_pairs<TV>(value, workspace, d, stream);
+        p.pairs = workspace;
+        if (rc == 0) rc = dispatch_gather_pairs<T, 0, TV>(p, stream);
+    } else {
+        rc = dispatch_gather<T, 0, TV>(p, vec_ok, stream);
+    }
     if (rc > 0) set_error("forward launch failed: %s", hipGetErrorString((hipError_t)rc));  // negative: message already set
     return rc;
 }
@@ -437,7 +486,7 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
 template <typename T, typename TV = T>
 int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, const void *ref, void *out, int64_t B,
                   int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,
-                  int align_corners, void *stream_)
+                  int align_corners, void *stream_, void *workspace = nullptr, int64_t workspace_bytes = 0)
 {
     const Dims d{B, I, H, D, Q, L, P};
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -473,7 +522,16 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
     p.ref = ref;
     p.ref_dim = ref_dim;
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
-    rc = dispatch_gather<T, 2, TV>(p, vec_ok, stream);
+    size_t lds_unused;
+    int sc_all;
+    plan_gather(kBlock / pair_group<T, TV>(), (int)(L * P), sizeof(typename Traits<T>::acc), sc_all, lds_unused);
+    if (pairs_ok<T, TV>(p, d, vec_ok, workspace, workspace_bytes) && sc_all == (int)(L * P)) {
+        rc = build_pairs<TV>(value, workspace, d, stream);
+        p.pairs = workspace;
+        if (rc == 0) rc = dispatch_gather_pairs<T, 2, TV>(p, stream);
+    } else {
+        rc = dispatch_gather<T, 2, TV>(p, vec_ok, stream);
+    }
     if (rc > 0) set_error("fused forward launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }
@@ -560,6 +618,17 @@ template <typename T> inline bool small_path_chosen(const Dims &d)
 // caller's workspace.  There is no third path: a large problem without (enough) workspace is an argument error, and
 // shapes beyond the sorted pipeline's record format (I >= 2^22 pixels per plane, D beyond 32-bit slot offsets) are
 // unsupported for grad_value when they are also too large for the single-launch kernel.
+// would run_value find a route with this workspace?  (the single-launch kernel, or the sorted pipeline with enough room)
+template <typename T> inline bool value_ws_ok(const Params &p, const Dims &d, const void *workspace, int64_t workspace_bytes)
+{
+    using A = typename Traits<T>::acc;
+    const bool fits = sorted_fits<T>(d);
+    const size_t need = fits ? sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), sizeof(T), value_vec_ok<T>(p)).total : 0;
+    const bool sorted = fits && workspace != nullptr && aligned_to(workspace, 256) && workspace_bytes >= 0 &&
+                        (uint64_t)workspace_bytes >= need;
+    return sorted || small_path_chosen<T>(d) || (option_value_path() != 2 && !option_deterministic() && small_fits<T>(d));
+}
+
 template <typename T, typename TV = T>
 inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspace_bytes, hipStream_t stream)
 {
@@ -637,6 +706,20 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     p.grad_loc = grad_loc;
     p.grad_attn = grad_attn;
     fill_params(p, d, padding_mode, align_corners);
+    // The workspace's front may carry the x-pair table for the sample-gradient kernel (64-byte value rows): only when
+    // what follows it still covers what grad_value needs.
+    const bool vec_sample = aligned_to(value, 16) && aligned_to(grad_out, 16);
+    bool use_pairs = false;
+    if (want_sample && pairs_ok<T, TV>(p, d, vec_sample, workspace, workspace_bytes)) {
+        const int64_t pb = (int64_t)pair_table_bytes(B, I, H);
+        const bool value_fits = !want_value || value_ws_ok<T>(p, d, static_cast<unsigned char *>(workspace) + pb, workspace_bytes - pb);
+        if (value_fits) {
+            use_pairs = true;
+            p.pairs = workspace;
+            workspace = static_cast<unsigned char *>(workspace) + pb;
+            workspace_bytes -= pb;
+        }
+    }
     // The two halves of the backward are independent: when both are wanted, grad_loc/grad_attn run on a
     // forked side stream next to the grad_value pipeline (fork/join with events: still graph-capturable).
     hipStream_t sample_stream = stream;
@@ -658,8 +741,12 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
         }
     }
     if (want_sample) {
-        const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
-        rc = dispatch_gather<T, 1, TV>(p, vec_ok, sample_stream);
+        if (use_pairs) {
+            rc = build_pairs<TV>(value, const_cast<void *>(p.pairs), d, sample_stream);
+            if (rc == 0) rc = dispatch_gather_pairs<T, 1, TV>(p, sample_stream);
+        } else {
+            rc = dispatch_gather<T, 1, TV>(p, vec_sample, sample_stream);
+        }
         if (rc) {
             if (rc > 0) set_error("backward (grad_loc/grad_attn) launch failed: %s", hipGetErrorString((hipError_t)rc));
             if (forked) (void)side_stream_join(stream);
@@ -728,6 +815,31 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
     }
     const bool want_value = grad_value != nullptr;
     const size_t mat = fused_mat_bytes(B, H, Q, L, P, sizeof(T));
+    // the x-pair table for the sample half sits in front when the rest of the workspace still serves grad_value
+    bool use_pairs = false;
+    const void *pairs_at = nullptr;
+    {
+        Params probe{};
+        probe.grad_out = grad_out;
+        probe.grad_value = grad_value;
+        fill_params(probe, d, padding_mode, align_corners);
+        size_t lds_unused;
+        int sc_all;
+        plan_gather(kBlock / pair_group<T, TV>(), (int)(L * P), sizeof(typename Traits<T>::acc), sc_all, lds_unused, true);
+        const bool vec_s = aligned_to(value, 16) && aligned_to(grad_out, 16);
+        if (pairs_ok<T, TV>(probe, d, vec_s, workspace, workspace_bytes) && sc_all == (int)(L * P)) {
+            const int64_t pb = (int64_t)pair_table_bytes(B, I, H);
+            unsigned char *rest = static_cast<unsigned char *>(workspace) + pb;
+            const bool ok = !want_value || ((uint64_t)(workspace_bytes - pb) >= mat &&
+                                            value_ws_ok<T>(probe, d, rest + mat, workspace_bytes - pb - (int64_t)mat));
+            if (ok) {
+                use_pairs = true;
+                pairs_at = workspace;
+                workspace = rest;
+                workspace_bytes -= pb;
+            }
+        }
+    }
     if (want_value && (workspace == nullptr || !aligned_to(workspace, 256) || (uint64_t)workspace_bytes < mat)) {
         set_error("the fused backward needs a 256-byte aligned workspace of at least %zu bytes for grad_value", mat);
         return MSDA_ERR_BAD_ARG;
@@ -744,13 +856,19 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
     fill_params(p, d, padding_mode, align_corners);
     p.ref = ref;
     p.ref_dim = ref_dim;
+    p.pairs = pairs_at;
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     if (want_value) {
         p.mat_loc = ws;
         p.mat_attn = ws + ns * 2 * sizeof(T);
     }
     const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
-    rc = dispatch_gather<T, 3, TV>(p, vec_ok, stream);
+    if (use_pairs) {
+        rc = build_pairs<TV>(value, const_cast<void *>(p.pairs), d, stream);
+        if (rc == 0) rc = dispatch_gather_pairs<T, 3, TV>(p, stream);
+    } else {
+        rc = dispatch_gather<T, 3, TV>(p, vec_ok, stream);
+    }
     if (rc) {
         if (rc > 0) set_error("fused backward launch failed: %s", hipGetErrorString((hipError_t)rc));
         return rc;
@@ -782,6 +900,23 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
     {                                                                                                            \
         return msda::run_fwd_fused<T, TV>(value, shapes, proj, ref, out, B, I, H, D, Q, L, P, ref_dim, padding_mode, \
                                       align_corners, stream);                                                    \
+    }                                                                                                            \
+    extern "C" int msda_fwd_ex_##SUF(const void *value, const int64_t *shapes, const void *loc, const void *attn, \
+                                     void *out, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, \
+                                     int64_t P, int padding_mode, int align_corners, void *workspace,            \
+                                     int64_t workspace_bytes, void *stream)                                      \
+    {                                                                                                            \
+        return msda::run_fwd<T, TV>(value, shapes, loc, attn, out, B, I, H, D, Q, L, P, padding_mode,               \
+                                align_corners, stream, workspace, workspace_bytes);                              \
+    }                                                                                                            \
+    extern "C" int msda_fwd_fused_ex_##SUF(const void *value, const int64_t *shapes, const void *proj,          \
+                                           const void *ref, void *out, int64_t B, int64_t I, int64_t H,          \
+                                           int64_t D, int64_t Q, int64_t L, int64_t P, int ref_dim,              \
+                                           int padding_mode, int align_corners, void *workspace,                 \
+                                           int64_t workspace_bytes, void *stream)                                \
+    {                                                                                                            \
+        return msda::run_fwd_fused<T, TV>(value, shapes, proj, ref, out, B, I, H, D, Q, L, P, ref_dim, padding_mode, \
+                                      align_corners, stream, workspace, workspace_bytes);                        \
     }                                                                                                            \
     extern "C" int msda_bwd_##SUF(const void *grad_out, const void *value, const int64_t *shapes,               \
                                   const void *loc, const void *attn, void *grad_value, void *grad_loc,          \

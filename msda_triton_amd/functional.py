@@ -213,17 +213,32 @@ def msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mo
         raise ValueError(f"`out` should be a contiguous {(B, Q, H, D)} {cdt} tensor on {img.device}, but got "
                          f"{tuple(out.shape)} {out.dtype} on {out.device} (contiguous: {out.is_contiguous()}).")
     lib = _lib.load()
-    fn = getattr(lib, f"msda_fwd_{suf}")
+    fn = getattr(lib, f"msda_fwd_ex_{suf}")
+    ws, ws_bytes = _fwd_workspace(lib, img)
 
     def call():
         return fn(img.data_ptr(), shapes.data_ptr(), sampling_points.data_ptr(), attention_weights.data_ptr(),
-                  out.data_ptr(), B, I, H, D, Q, L, P, pad, int(bool(align_corners)), _stream_ptr(img.device))
+                  out.data_ptr(), B, I, H, D, Q, L, P, pad, int(bool(align_corners)),
+                  ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(img.device))
 
     with _OnDevice(img.device):
         timer = KernelTimer.active
         rc = timer.launch("msda_fwd", img.device, call) if timer else call()
-    _lib.check(rc, f"msda_fwd_{suf}")
+    _lib.check(rc, f"msda_fwd_ex_{suf}")
     return out
+
+
+_FWD_WS_BYTES: dict = {}  # (B, I, H, D, value element size, option epoch) -> msda_fwd_workspace_bytes
+
+
+def _fwd_workspace(lib, img):
+    """Optional scratch for the forward: room for the x-pair table the library builds for a pyramid whose rows have
+    exactly 64 bytes (include/msda_hip.h, msda_fwd_ex_<dtype>); (None, 0) for every other shape."""
+    key = (*img.shape, img.element_size(), _lib.OPTION_EPOCH)
+    n = _FWD_WS_BYTES.get(key)
+    if n is None:
+        n = _FWD_WS_BYTES[key] = int(lib.msda_fwd_workspace_bytes(*key[:5]))
+    return (torch.empty(n, dtype=torch.uint8, device=img.device), n) if n > 0 else (None, 0)
 
 
 def level_cells_of(level_shapes, num_levels: Optional[int] = None, num_pixels: Optional[int] = None) -> int:
@@ -296,11 +311,13 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
         fn = getattr(lib, f"msda_bwd_ex_{suf}")  # (the level-size bound travels as an argument: include/msda_hip.h, ABI 9)
         ws, ws_bytes = None, 0
         level_cells = int(level_cells)
-        if want_value:  # scratch for the inverted index; the caching allocator makes this cheap
-            key = (B, I, H, D, Q, L, P, sampling_points.element_size(), _lib.OPTION_EPOCH, level_cells)
+        if not want_value:  # only the x-pair table, if the shape takes one
+            ws, ws_bytes = _fwd_workspace(lib, img)
+        else:  # scratch: the inverted index (grad_value), in front of it the x-pair table
+            key = (B, I, H, D, Q, L, P, sampling_points.element_size(), img.element_size(), _lib.OPTION_EPOCH, level_cells)
             ws_bytes = _WS_BYTES.get(key)
             if ws_bytes is None:
-                ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes_ex(*key[:8], level_cells))
+                ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes_ex(*key[:9], level_cells))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
         def call(value_part: bool, sample_part: bool):
@@ -310,7 +327,7 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
                       g_pts.data_ptr() if sample_part else None,
                       g_att.data_ptr() if sample_part else None,
                       B, I, H, D, Q, L, P, pad, int(bool(align_corners)), level_cells,
-                      ws.data_ptr() if (ws is not None and value_part) else None, ws_bytes,
+                      ws.data_ptr() if ws is not None else None, ws_bytes,
                       _stream_ptr(img.device))
 
         with _OnDevice(img.device):
@@ -440,18 +457,21 @@ def msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, al
     img, proj, reference_points = img.contiguous(), proj.contiguous(), reference_points.contiguous()
     shapes = _shapes_i64(img_shapes)
     out = torch.empty((B, Q, H, D), dtype=cdt, device=img.device)
-    fn = getattr(_lib.load(), f"msda_fwd_fused_{suf}")
+    lib = _lib.load()
+    fn = getattr(lib, f"msda_fwd_fused_ex_{suf}")
+    ws, ws_bytes = _fwd_workspace(lib, img)
 
     def call():
         return fn(img.data_ptr(), shapes.data_ptr(), proj.data_ptr(), reference_points.data_ptr(), out.data_ptr(),
-                  B, I, H, D, Q, L, P, ref_dim, pad, int(bool(align_corners)), _stream_ptr(img.device))
+                  B, I, H, D, Q, L, P, ref_dim, pad, int(bool(align_corners)),
+                  ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(img.device))
 
     with _OnDevice(img.device):
         timer = KernelTimer.active
         rc = timer.launch("msda_fwd_fused", img.device, call) if timer else call()
     if rc == -5:  # MSDA_ERR_UNSUPPORTED
         return None
-    _lib.check(rc, f"msda_fwd_fused_{suf}")
+    _lib.check(rc, f"msda_fwd_fused_ex_{suf}")
     return out
 
 
@@ -480,8 +500,9 @@ def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, paddin
     fn = getattr(lib, f"msda_bwd_fused_ex_{suf}")
     ws, ws_bytes = None, 0
     level_cells = int(level_cells)  # the level-size bound (level_cells_of), an argument of the size query and the launch
-    if need_img:
-        ws_bytes = int(lib.msda_bwd_fused_workspace_bytes_ex(B, I, H, D, Q, L, P, proj.element_size(), level_cells))
+    if need_img or img.element_size() * D == 64:
+        ws_bytes = int(lib.msda_bwd_fused_workspace_bytes_ex(B, I, H, D, Q, L, P, proj.element_size(), img.element_size(),
+                                                             level_cells))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
     def call():

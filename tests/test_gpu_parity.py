@@ -1164,3 +1164,56 @@ def test_seventeen_levels_beyond_the_single_launch_kernel(oracle):
     assert 1100 * 4 > 4096 and len(levels) == 17
     for pm, ac in MODES:
         check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float32], BWD_TOL[torch.float32])
+
+
+@pytest.mark.parametrize("td,vd,D", [(torch.bfloat16, torch.bfloat16, 32), (torch.float16, torch.float16, 32),
+                                     (torch.float32, torch.bfloat16, 32), (torch.float32, torch.float32, 16),
+                                     (torch.float64, torch.float64, 8)],
+                         ids=["bf16", "fp16", "fp32_vbf16", "fp32_d16", "fp64_d8"])
+@pytest.mark.parametrize("pm,ac", [("zeros", False), ("border", True), ("border", False)], ids=["zeros_0", "border_1", "border_0"])
+def test_x_pair_table_kernels_match_the_oracle(oracle, td, vd, D, pm, ac):
+    """msda_set_option("pairs", 1): pyramids with 64-byte rows are gathered through the x-pair table (forward and
+    sample gradients, include/msda_hip.h).  Same oracle comparison as the plain kernels, points beyond the image so
+    that clamped / masked x1 corners (the entries that are NOT the x0 corner's neighbour) are exercised; the plain
+    kernels on the same inputs agree to rounding."""
+    from msda_triton_amd import _lib
+    levels = [(9, 7), (4, 5), (1, 3), (6, 1)]
+    c = rand_case(np.random.default_rng(41), 2, 45, 3, D, levels, 3, lo=-0.3, hi=1.3,
+                  dtype=np.float64 if td == torch.float64 else np.float32)
+    rounded = {k: (v if k == "shapes" else torch.from_numpy(v).to(vd if k == "value" else td).to(torch.from_numpy(v).dtype).numpy())
+               for k, v in c.items()}
+    ops = _ops()
+
+    def run():
+        v = torch.from_numpy(rounded["value"]).to(DEV, vd).requires_grad_(True)
+        l = torch.from_numpy(rounded["loc"]).to(DEV, td).requires_grad_(True)
+        a = torch.from_numpy(rounded["attn"]).to(DEV, td).requires_grad_(True)
+        out = ops.multiscale_deformable_attention(v, torch.from_numpy(rounded["shapes"]).to(DEV), l, a, pm, ac)
+        out.backward(torch.from_numpy(rounded["grad_out"]).to(DEV, td))
+        return [t.detach().double().cpu().numpy() for t in (out, v.grad, l.grad, a.grad)]
+
+    plain = run()
+    try:
+        _lib.set_option("pairs", 1)
+        assert _lib.load().msda_fwd_workspace_bytes(2, sum(h * w for h, w in levels), 3, D, torch.empty(0, dtype=vd).element_size()) > 0
+        paired = run()
+    finally:
+        _lib.set_option("pairs", 0)
+    r_out = oracle.forward(rounded["value"], rounded["shapes"], rounded["loc"], rounded["attn"], pm, ac)
+    r_gv, r_gl, r_ga = oracle.backward(rounded["grad_out"], rounded["value"], rounded["shapes"], rounded["loc"],
+                                       rounded["attn"], pm, ac)
+    atol, rtol = {torch.float64: (1e-9, 1e-9), torch.float32: (1e-4, 1e-3), torch.float16: (2e-2, 2e-2),
+                  torch.bfloat16: (4e-2, 2e-2)}[td]
+    np.testing.assert_allclose(paired[0], r_out, atol=atol, rtol=rtol, err_msg="out")
+    np.testing.assert_allclose(paired[3], r_ga, atol=atol * 4, rtol=rtol * 10, err_msg="grad_attn")
+    np.testing.assert_allclose(paired[1], r_gv, atol=atol * 4 if vd == td else 4e-2, rtol=rtol * 10, err_msg="grad_value")
+    keep = ~kink_mask(rounded["loc"], rounded["shapes"], ac, tol=2e-2 if td in (torch.float16, torch.bfloat16) else 1e-4)
+    scale = max(1.0, float(np.abs(r_gl).max()))
+    np.testing.assert_allclose(np.where(keep, paired[2], 0), np.where(keep, r_gl, 0), atol=atol * 10 * scale, rtol=rtol * 10,
+                               err_msg="grad_loc")
+    # and against the plain kernels: the same arithmetic in another order
+    eps = {torch.float64: 1e-12, torch.float32: 1e-5, torch.float16: 2e-2, torch.bfloat16: 6e-2}[td]
+    np.testing.assert_allclose(paired[0], plain[0], atol=eps * max(1.0, float(np.abs(plain[0]).max())), rtol=0)
+    np.testing.assert_allclose(paired[3], plain[3], atol=eps * max(1.0, float(np.abs(plain[3]).max())), rtol=0)
+    np.testing.assert_allclose(np.where(keep, paired[2], 0), np.where(keep, plain[2], 0),
+                               atol=eps * max(1.0, float(np.abs(plain[2]).max())), rtol=0)
