@@ -45,6 +45,16 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 README_RTX2060_MS = {"fwd": 3.78, "fwd_bwd": 22.78}  # reference README.md:18-19 (Triton, RTX 2060)
+L1_PEAK_GBS = 64 * 256 * 2.4  # vector L1: 64 B/clk/CU x 256 CUs x 2.4 GHz = 39 322 GB/s (guides/MI355X_MICROARCH.md)
+
+
+def single_kernel_alg_bytes(wl):
+    """Compulsory bytes per launch of the individual kernels that have a clean definition (the forward and the
+    sample-gradient kernel are their launch groups; the grad_value pipeline's kernels share one budget, ALG of the
+    group, and are listed with their times only)."""
+    alg = kernel_alg_bytes(wl)
+    return {"msda_fwd_kernel": alg["msda_fwd"], "msda_bwd_sample_kernel": alg["msda_bwd_sample"]}
+
 
 
 def kernel_alg_bytes(wl):
@@ -608,6 +618,15 @@ def main():
             timed(step, args.steps)
         kern = kt.summary()
         torch.cuda.synchronize()
+        # ... and once more with the library's own event pair around every single kernel (msda_profile_read)
+        single = {}
+        try:
+            _lib.set_option("profile", 1)
+            _lib.profile_read()
+            timed(step, args.steps)
+            single = _lib.profile_read()
+        finally:
+            _lib.set_option("profile", 0)
         torch.cuda.reset_peak_memory_stats(dev)
         step()
         torch.cuda.synchronize()
@@ -656,17 +675,35 @@ def main():
             "kernels": kernels,
             "peak_mem_MB": round(peak_mem / 1e6, 1) if peak_mem is not None else None,
         }
+        if on_gpu and single:
+            salg = single_kernel_alg_bytes(wl)
+            result["single_kernels"] = {
+                name: {"launches": n, "avg_us": round(us, 2),
+                       **({"alg_bytes": salg[name], "achieved_GBs": round(salg[name] / (us * 1e-6) / 1e9, 1),
+                           "frac_of_hbm_peak": round(salg[name] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)} if name in salg else {})}
+                for name, (n, us) in sorted(single.items(), key=lambda kv: -kv[1][1])}
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
+            sk = result.get("single_kernels", {})
+            dom_single = max(sk, key=lambda k: sk[k]["avg_us"]) if sk else None
+            fwd_us = sk.get("msda_fwd_kernel", {}).get("avg_us") or kernels.get("msda_fwd", {}).get("avg_us")
             result["roofline"] = {
-                "kernel": dom + (" (grad_value: cell_pass x2, cell_scan, value_gather, value_finish — or the "
+                "kernel": dom + (" (grad_value: count, scan, place, value_gather, value_finish — or the "
                                  "single-launch kernel on small problems; timed as one C-ABI call)"
                                  if dom == "msda_bwd_value" else ""),
                 "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": kernels[dom]["traffic"],
                 "traffic_source": "profiles/hbm_traffic.json: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of this "
                                   "bench, gfx950 corrections applied; not re-measured in this run",
-                "timing": "HIP events around every launch, same K steps repeated right after the timed region"}
+                "timing": "HIP events around every launch, same K steps repeated right after the timed region",
+                # the line's `kernel` is a launch GROUP (one C-ABI call); the slowest SINGLE kernel, with its own figure:
+                "dominant_single_kernel": ({"kernel": dom_single, **sk[dom_single]} if dom_single else None),
+                # the forward's gather as the hardware sees it: logical row bytes per second, and as a fraction of
+                # the vector L1 rate (64 B/clk/CU x 256 CUs x 2.4 GHz) — "bound by requests, not HBM bytes"
+                "effective_gather_TBs": round(wl.gather_fwd_bytes / (fwd_us * 1e-6) / 1e12, 2) if fwd_us else None,
+                "gather_frac_of_l1_rate": round(wl.gather_fwd_bytes / (fwd_us * 1e-6) / 1e9 / L1_PEAK_GBS, 3) if fwd_us else None,
+                "traffic_caveat": "the 2x FETCH_SIZE correction is calibrated for 16-byte-per-lane streaming reads only: "
+                                  "for the scatter / gather kernels `traffic` is an upper-ish bound (profiles/hbm_traffic.json)"}
         if on_gpu:
             result["options"] = {k: _lib.get_option(k) for k in ("xcd_map", "value_path", "overlap")}
     else:

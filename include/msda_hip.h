@@ -256,11 +256,17 @@ MSDA_API const char *msda_last_error(void);
  *                   90 -> 86 + 11 us)
  *   "place_path" 0 (default): the level-major place pass where a plane has at least as many samples as cell-table
  *                   entries;  1: the plane-major pass always;  2: the level-major pass always
+ *   "profile"    0 (default);  1: event pairs around every kernel launch, read with msda_profile_read (measurement only)
  *   "level_cells" 0 (default): unknown;  n: process-wide form of msda_hint_level_cells(n)
  *   "cell_slices", "small_ns", "gather_win", "wg_target", "debug": experiment knobs, see
  *                msda_triton_amd/csrc/msda_launch.hpp and msda_value_sorted.hpp
  */
 MSDA_API int msda_set_option(const char *key, int value);
+/* Measurement only.  With msda_set_option("profile", 1) every kernel the library launches is bracketed by a HIP event
+ * pair on its stream; msda_profile_read waits for the events recorded (by any thread) since the last read and
+ * writes one line per kernel — "name launches total_microseconds\n" — into buf (NUL-terminated, at most cap bytes);
+ * returns the characters written.  The read consumes the records.  bench.py's per-kernel figures come from here. */
+MSDA_API int msda_profile_read(char *buf, int cap);
 MSDA_API int msda_get_option(const char *key);
 
 #ifdef __cplusplus

@@ -26,7 +26,8 @@ EXPORTED_SYMBOLS = tuple(
      for s in DTYPE_SUFFIXES]
     + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option", "msda_bwd_workspace_bytes",
        "msda_bwd_fused_workspace_bytes", "msda_bwd_workspace_bytes_ex", "msda_bwd_fused_workspace_bytes_ex",
-       "msda_fwd_workspace_bytes", "msda_bwd_supported", "msda_fused_lp_limit", "msda_hint_level_cells"]
+       "msda_fwd_workspace_bytes", "msda_bwd_supported", "msda_fused_lp_limit", "msda_hint_level_cells",
+       "msda_profile_read"]
 )
 
 _lib = None
@@ -106,6 +107,8 @@ def load():
         lib.msda_fwd_workspace_bytes.argtypes = [i64] * 4 + [ci]
         lib.msda_bwd_supported.restype = ci
         lib.msda_bwd_supported.argtypes = [i64] * 7 + [ci]
+        lib.msda_profile_read.restype = ci
+        lib.msda_profile_read.argtypes = [ctypes.c_char_p, ci]
         lib.msda_fused_lp_limit.restype = i64
         lib.msda_fused_lp_limit.argtypes = [i64, ci]
         lib.msda_hint_level_cells.restype = None
@@ -142,3 +145,16 @@ def set_option(key: str, value: int) -> None:
 
 def get_option(key: str) -> int:
     return int(load().msda_get_option(key.encode()))
+
+
+def profile_read() -> dict:
+    """{kernel name: (launches, mean microseconds)} of the kernels launched (by any thread) since the last read while
+    option "profile" was 1 (measurement only; synchronises on the recorded events)."""
+    lib = load()
+    buf = ctypes.create_string_buffer(1 << 16)  # (one call: the read consumes the records)
+    lib.msda_profile_read(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, launches, total = line.rsplit(" ", 2)
+        out[name] = (int(launches), float(total) / max(int(launches), 1))
+    return out

@@ -7,6 +7,10 @@
 
 #include <atomic>
 #include <thread>
+#include <vector>
+#include <map>
+#include <mutex>
+#include <string>
 
 #include "../../include/msda_hip.h"
 
@@ -26,6 +30,7 @@ static std::atomic<int> g_deterministic{0};
 static std::atomic<int> g_place_path{0};
 static std::atomic<int> g_place_block{0};
 static std::atomic<int> g_pairs{0};
+static std::atomic<int> g_profile{0};
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
 // Per THREAD, because the fork (record on the user's stream, wait on the side stream) and the join are two calls
@@ -110,6 +115,36 @@ int option_deterministic() { return g_deterministic.load(std::memory_order_relax
 int option_place_path() { return g_place_path.load(std::memory_order_relaxed); }
 int option_place_block() { return g_place_block.load(std::memory_order_relaxed); }
 int option_pairs() { return g_pairs.load(std::memory_order_relaxed); }
+int option_profile() { return g_profile.load(std::memory_order_relaxed); }
+
+// ---- measurement only: device time of every kernel the library launches on this thread (option "profile") ----
+struct ProfileRec {
+    const char *name;
+    hipEvent_t a, b;
+};
+static std::vector<ProfileRec> t_profile;  // (process-wide: autograd launches the backward from its own thread)
+static std::mutex t_profile_mutex;
+
+void *profile_begin(const char *name, hipStream_t stream)
+{
+    if (!option_profile() || t_profile.size() >= 65536) return nullptr;
+    ProfileRec r{name, nullptr, nullptr};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess || hipEventRecord(r.a, stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    const std::lock_guard<std::mutex> lock(t_profile_mutex);
+    t_profile.push_back(r);
+    return reinterpret_cast<void *>(t_profile.size());  // 1-based index
+}
+
+void profile_end(void *token, hipStream_t stream)
+{
+    if (token == nullptr) return;
+    const size_t i = reinterpret_cast<size_t>(token) - 1;
+    const std::lock_guard<std::mutex> lock(t_profile_mutex);
+    if (i < t_profile.size()) (void)hipEventRecord(t_profile[i].b, stream);
+}
 
 void set_error(const char *fmt, ...)
 {
@@ -207,6 +242,37 @@ extern "C" int64_t msda_fused_lp_limit(int64_t D, int elem_size) { return msda_f
 
 extern "C" const char *msda_last_error(void) { return msda::g_err; }
 
+// "name launches total_us\n" per kernel launched on this thread since the last read while option "profile" was 1;
+// (any thread: the records are process-wide) waits for the recorded events, then forgets them.  Returns the number of characters written (without the NUL).
+extern "C" int msda_profile_read(char *buf, int cap)
+{
+    std::map<std::string, std::pair<int, double>> acc;
+    const std::lock_guard<std::mutex> lock(msda::t_profile_mutex);
+    for (const msda::ProfileRec &r : msda::t_profile) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto &e = acc[r.name];
+            e.first += 1;
+            e.second += (double)ms * 1e3;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    (void)hipGetLastError();
+    msda::t_profile.clear();
+    std::string out;
+    for (const auto &kv : acc) {
+        char line[160];
+        snprintf(line, sizeof(line), "%s %d %.3f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        out += line;
+    }
+    if (buf == nullptr || cap <= 0) return (int)out.size();
+    const int n = (int)out.size() < cap - 1 ? (int)out.size() : cap - 1;
+    memcpy(buf, out.data(), (size_t)n);
+    buf[n] = 0;
+    return n;
+}
+
 extern "C" int msda_set_option(const char *key, int value)
 {
     if (key && strcmp(key, "xcd_map") == 0) {
@@ -257,6 +323,10 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_pairs.store(value ? 1 : 0, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "profile") == 0) {
+        msda::g_profile.store(value ? 1 : 0, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "cell_slices") == 0 && value >= 0 && value <= 64) {
         msda::g_cell_slices.store(value, std::memory_order_relaxed);
         return 0;
@@ -285,6 +355,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "place_path") == 0) return msda::option_place_path();
     if (key && strcmp(key, "place_block") == 0) return msda::option_place_block();
     if (key && strcmp(key, "pairs") == 0) return msda::option_pairs();
+    if (key && strcmp(key, "profile") == 0) return msda::option_profile();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

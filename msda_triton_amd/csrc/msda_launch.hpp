@@ -27,6 +27,15 @@ int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurre
 hipStream_t side_stream_fork(hipStream_t user);   // side stream that waits for everything queued on `user`
 int side_stream_join(hipStream_t user);            // `user` waits for everything queued on the side stream
 void set_error(const char *fmt, ...);
+// measurement only (option "profile"): an event pair around a kernel launch, read back by msda_profile_read
+void *profile_begin(const char *name, hipStream_t stream);
+void profile_end(void *token, hipStream_t stream);
+struct ProfileScope {
+    void *token;
+    hipStream_t stream;
+    ProfileScope(const char *name, hipStream_t s) : token(profile_begin(name, s)), stream(s) {}
+    ~ProfileScope() { profile_end(token, stream); }
+};
 void set_thread_level_cells(int64_t n);   // this thread's promise about the level sizes (msda_hint_level_cells)
 int64_t get_thread_level_cells();
 // max_level_cells argument of the _ex entry points: the thread's promise for the duration of one call
@@ -178,6 +187,7 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, bool PAIR = fal
         return MSDA_ERR_UNSUPPORTED;
     }
     static std::atomic<uint64_t> big_lds_done{0};  // one per template instantiation
+    const ProfileScope prof(MODE == 0 || MODE == 2 ? "msda_fwd_kernel" : "msda_bwd_sample_kernel", stream);
     if constexpr (MODE == 3) {
         auto kernel = msda_bwd_sample_kernel<T, VEC, G, true, TV, PAIR>;
         allow_big_lds(kernel, big_lds_done);
@@ -236,6 +246,7 @@ template <typename TV> inline int build_pairs(const void *value, void *pairs, co
     const int row16 = (int)(d.D * (int64_t)sizeof(TV) / 16);
     const long long n = (long long)d.I * d.H * row16;
     if (d.B > 65535 || n >= ((long long)1 << 31) * kBlock) return MSDA_ERR_TOO_LARGE;
+    const ProfileScope prof("msda_pairs_build_kernel", stream);
     hipLaunchKernelGGL(msda_pairs_build_kernel<0>, dim3((unsigned)((n + kBlock - 1) / kBlock), (unsigned)d.B), dim3(kBlock), 0, stream,
                        static_cast<const uint4 *>(value), static_cast<uint4 *>(pairs), (int)d.I, (int)d.H, row16);
     return (int)hipGetLastError();
@@ -268,13 +279,17 @@ template <typename T, int VEC, int G, int GB, typename TV = T> inline int launch
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
-    hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G, GB>), g4, dim3(GB), 0, stream, p);
+    {
+        const ProfileScope prof("msda_value_gather_kernel", stream);
+        hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G, GB>), g4, dim3(GB), 0, stream, p);
+    }
     // (4-lane groups: 64 of them per workgroup, so 64 pixels keep them all busy)
     const int fp = kBlock / G > 32 ? 64 : finish_pixels(npairs, p.I);
     if (!plane_grid(p, npairs, (p.I + fp - 1) / fp, g5)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
+    const ProfileScope prof("msda_value_finish_kernel", stream);
     if (fp == 64)
         hipLaunchKernelGGL((msda_value_finish_kernel<T, VEC, G, GB, TV, 64>), g5, dim3(kBlock), 0, stream, p);
     else
@@ -391,8 +406,18 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
         p.finish_mode = w.rounds == 1 ? 0 : r == 0 ? 1 : r == w.rounds - 1 ? 3 : 2;
         p.grid3d = g3_cell;
         p.cell_cap = cell_cap_pm;
-        hipLaunchKernelGGL((msda_cell_pass_kernel<T, false>), gcell, dim3(kCellBlock), cell_lds, stream, p);
-        hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)scan_blocks), dim3(kScanCells), 0, stream, p);
+        {
+            const ProfileScope prof("msda_cell_pass_kernel<count>", stream);
+            hipLaunchKernelGGL((msda_cell_pass_kernel<T, false>), gcell, dim3(kCellBlock), cell_lds, stream, p);
+        }
+        {
+            const ProfileScope prof("msda_cell_scan_kernel", stream);
+            hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)scan_blocks), dim3(kScanCells), 0, stream, p);
+        }
+        {
+        const ProfileScope prof_place(option_deterministic() ? "msda_cell_place_det_kernel" : place_lm ? "msda_cell_place_lm_kernel"
+                                                                                              : "msda_cell_pass_kernel<place>",
+                                      stream);
         if (option_deterministic()) {
             hipLaunchKernelGGL((msda_cell_place_det_kernel<T>), gcell, dim3(kWave), cell_lds, stream, p);
         } else if (place_lm) {
@@ -407,6 +432,7 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
                 hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, 512>), gplace, dim3(512), lds, stream, p);
         } else {
             hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
+        }
         }
         int rc = (int)hipGetLastError();
         if (rc) return rc;
@@ -560,6 +586,7 @@ template <typename T, int VEC, int G, typename TV = T> inline int launch_value_s
     }
     static std::atomic<uint64_t> big_lds_done{0};
     allow_big_lds(msda_value_small_kernel<T, VEC, G, TV>, big_lds_done);
+    const ProfileScope prof("msda_value_small_kernel", stream);
     hipLaunchKernelGGL((msda_value_small_kernel<T, VEC, G, TV>), grid, dim3(kSmallBlock), lds, stream, p);
     return (int)hipGetLastError();
 }

@@ -81,7 +81,11 @@ allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
 allt["_comment"] = ("HBM bytes per call of each launcher-level group, from rocprofv3 PMC passes (separate --pmc FETCH_SIZE / "
                     "--pmc WRITE_SIZE runs of bench.py, tools/collect_profiles.sh): bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
                     "summed over the group's kernels, per guides/MI355X_MICROARCH.md (gfx950 FETCH_SIZE reports half of wide "
-                    "coalesced reads; WRITE_SIZE is exact). Raw per-kernel means: <tag>_<workload>_pmc_hbm.csv.")
+                    "coalesced reads; WRITE_SIZE is exact). Raw per-kernel means: <tag>_<workload>_pmc_hbm.csv.  CAVEAT: the "
+                    "guide calibrates the 2x FETCH_SIZE correction for 16-byte-per-lane streaming reads only; it is applied "
+                    "to every kernel here, so for the scatter / gather-heavy kernels (place pass, value_gather, the row "
+                    "gathers of msda_fwd / msda_bwd_sample) the figures are upper-ish bounds, and Infinity-Cache hits are "
+                    "counted as traffic.  Ratios between rounds of the same kernel are unaffected.")
 allt[workload] = traffic
 json.dump(allt, open(tpath, "w"), indent=1)
 print(json.dumps(summary, indent=1))
