@@ -157,8 +157,14 @@ MSDA_DECLARE_EX(f32_vf16)
 #undef MSDA_DECLARE_EX
 /* elem_size: of everything but `value`; value_elem_size: of `value` / `grad_value` (0: the same — 2 next to elem_size 4
  * for the mixed-storage entry points) */
+/* flags: MSDA_WS_RECORDS_IN_GRADS — the call will ALSO ask for grad_loc / grad_attn (both non-NULL, 16-byte aligned):
+ * the sorted sample records are dead once grad_value is done and those two buffers are written last, so the records of
+ * as many (batch, head) planes as fit are kept in them and the workspace shrinks (c2 @ 10k: 180 -> 119 MB).  A call
+ * with such a workspace but without grad_loc / grad_attn is rejected (MSDA_ERR_BAD_ARG); a larger workspace is fine. */
+#define MSDA_WS_RECORDS_IN_GRADS 1
 MSDA_API int64_t msda_bwd_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                             int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells);
+                                             int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells,
+                                             int flags);
 MSDA_API int64_t msda_bwd_fused_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
                                                    int64_t P, int elem_size, int value_elem_size,
                                                    int64_t max_level_cells);
@@ -256,6 +262,8 @@ MSDA_API const char *msda_last_error(void);
  *                   90 -> 86 + 11 us)
  *   "place_path" 0 (default): the level-major place pass where a plane has at least as many samples as cell-table
  *                   entries;  1: the plane-major pass always;  2: the level-major pass always
+ *   "records_in_grads" 1 (default): msda_bwd_<dtype> with all three gradients keeps sorted records in the grad_loc /
+ *                   grad_attn buffers until the sample-gradient kernel overwrites them;  0: never
  *   "profile"    0 (default);  1: event pairs around every kernel launch, read with msda_profile_read (measurement only)
  *   "level_cells" 0 (default): unknown;  n: process-wide form of msda_hint_level_cells(n)
  *   "cell_slices", "small_ns", "gather_win", "wg_target", "debug": experiment knobs, see

@@ -17,6 +17,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 9
 PADDING_MODES = {"border": 0, "zeros": 1}
+WS_RECORDS_IN_GRADS = 1  # msda_bwd_workspace_bytes_ex flag (include/msda_hip.h)
 # one storage type for every tensor, then the mixed ones: value / grad_value in 16 bits, everything else fp32
 DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64", "f32_vbf16", "f32_vf16")
 
@@ -100,7 +101,7 @@ def load():
         lib.msda_bwd_fused_workspace_bytes.restype = i64
         lib.msda_bwd_fused_workspace_bytes.argtypes = [i64] * 7 + [ci]
         lib.msda_bwd_workspace_bytes_ex.restype = i64
-        lib.msda_bwd_workspace_bytes_ex.argtypes = [i64] * 7 + [ci, ci, i64]
+        lib.msda_bwd_workspace_bytes_ex.argtypes = [i64] * 7 + [ci, ci, i64, ci]
         lib.msda_bwd_fused_workspace_bytes_ex.restype = i64
         lib.msda_bwd_fused_workspace_bytes_ex.argtypes = [i64] * 7 + [ci, ci, i64]
         lib.msda_fwd_workspace_bytes.restype = i64

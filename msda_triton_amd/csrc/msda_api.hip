@@ -31,6 +31,7 @@ static std::atomic<int> g_place_path{0};
 static std::atomic<int> g_place_block{0};
 static std::atomic<int> g_pairs{0};
 static std::atomic<int> g_profile{0};
+static std::atomic<int> g_records_in_grads{1};
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
 // Per THREAD, because the fork (record on the user's stream, wait on the side stream) and the join are two calls
@@ -116,6 +117,7 @@ int option_place_path() { return g_place_path.load(std::memory_order_relaxed); }
 int option_place_block() { return g_place_block.load(std::memory_order_relaxed); }
 int option_pairs() { return g_pairs.load(std::memory_order_relaxed); }
 int option_profile() { return g_profile.load(std::memory_order_relaxed); }
+int option_records_in_grads() { return g_records_in_grads.load(std::memory_order_relaxed); }
 
 // ---- measurement only: device time of every kernel the library launches on this thread (option "profile") ----
 struct ProfileRec {
@@ -161,7 +163,7 @@ extern "C" int msda_abi_version(void) { return MSDA_ABI_VERSION; }
 extern "C" void msda_hint_level_cells(int64_t max_level_cells) { msda::set_thread_level_cells(max_level_cells); }
 
 // the layout lives in a device header (msda_value_sorted.hpp); msda_f32.hip exposes its size formula
-extern "C" int64_t msda_bwd_workspace_bytes_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
+extern "C" int64_t msda_bwd_workspace_bytes_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int);
 
 // room for the x-pair table (rows of exactly 64 bytes of the value storage type; msda_launch.hpp pair_table_bytes)
 static int64_t pair_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int value_elem_size)
@@ -180,7 +182,7 @@ extern "C" int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int
                                             int64_t P, int elem_size)
 {
     if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0) return 0;
-    return pair_bytes(B, I, H, D, elem_size) + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
+    return pair_bytes(B, I, H, D, elem_size) + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0);
 }
 
 extern "C" int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
@@ -190,7 +192,7 @@ extern "C" int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t 
     // the derived sampling points + attention weights (3 elements per sample, rounded up to 256 bytes), then
     // the sorted pipeline's own workspace (msda_launch.hpp: fused_mat_bytes)
     const int64_t mat = (B * Q * H * L * P * 3 * (int64_t)elem_size + 255) / 256 * 256;
-    return pair_bytes(B, I, H, D, elem_size) + mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
+    return pair_bytes(B, I, H, D, elem_size) + mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0);
 }
 
 // the level-size bound as an argument: it becomes the thread's promise for the duration of the call
@@ -210,12 +212,13 @@ struct LevelCellsScope {
 }  // namespace msda
 
 extern "C" int64_t msda_bwd_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                               int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells)
+                                               int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells,
+                                               int flags)
 {
     if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0) return 0;
     const msda::LevelCellsScope scope(max_level_cells);
     return pair_bytes(B, I, H, D, value_elem_size > 0 ? value_elem_size : elem_size) +
-           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
+           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, (flags & MSDA_WS_RECORDS_IN_GRADS) ? 1 : 0);
 }
 
 extern "C" int64_t msda_bwd_fused_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
@@ -225,7 +228,7 @@ extern "C" int64_t msda_bwd_fused_workspace_bytes_ex(int64_t B, int64_t I, int64
     const msda::LevelCellsScope scope(max_level_cells);
     const int64_t mat = (B * Q * H * L * P * 3 * (int64_t)elem_size + 255) / 256 * 256;
     return pair_bytes(B, I, H, D, value_elem_size > 0 ? value_elem_size : elem_size) + mat +
-           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size);
+           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0);
 }
 
 extern "C" int msda_bwd_supported_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
@@ -323,6 +326,10 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_pairs.store(value ? 1 : 0, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "records_in_grads") == 0) {
+        msda::g_records_in_grads.store(value ? 1 : 0, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "profile") == 0) {
         msda::g_profile.store(value ? 1 : 0, std::memory_order_relaxed);
         return 0;
@@ -356,6 +363,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "place_block") == 0) return msda::option_place_block();
     if (key && strcmp(key, "pairs") == 0) return msda::option_pairs();
     if (key && strcmp(key, "profile") == 0) return msda::option_profile();
+    if (key && strcmp(key, "records_in_grads") == 0) return msda::option_records_in_grads();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

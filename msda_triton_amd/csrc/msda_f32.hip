@@ -5,7 +5,7 @@ MSDA_DEFINE_ENTRY_POINTS(f32, float)
 
 // size of the backward workspace (shared by every dtype: the accumulate type decides the record sizes)
 extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_bytes_impl(
-    int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int elem_size)
+    int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int elem_size, int records_in_grads)
 {
     // problems the single-launch kernel takes need no workspace at all
     const msda::Dims d{B, I, H, D, Q, L, P};
@@ -15,8 +15,9 @@ extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_byte
     // the larger of the 16-byte-vector and the scalar layout: which one a call takes depends on the alignment of its
     // grad_out / grad_value pointers (a slice of a shard's buffers can be misaligned), and a workspace that is too
     // small would be rejected (MSDA_ERR_BAD_ARG)
-    const size_t vec = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, true).total;
-    const size_t sca = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, false).total;
+    const bool rg = records_in_grads != 0 && msda::option_records_in_grads() != 0;
+    const size_t vec = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, true, rg).total;
+    const size_t sca = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, false, rg).total;
     return (int64_t)(vec > sca ? vec : sca);
 }
 

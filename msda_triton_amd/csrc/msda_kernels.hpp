@@ -51,7 +51,12 @@ struct Params {
     int *ws_off;        // [pairs][nc_cap+1]  first record of every cell's list (and the plane's total behind the last)
     int *ws_total;      // [pairs]            records of the plane
     int *ws_meta;       // [0] = cells of a plane (written by the count pass for the scan kernel)
-    void *ws_entries;   // [pairs][Q*L*P]     Entry<acc>: sample records sorted by cell
+    void *ws_entries;   // [pairs - ent_n0 - ent_n1][Q*L*P]  Entry<acc>: sample records sorted by cell (plane_entries())
+    // ... the records of the first ent_n0 planes live in the caller's grad_loc buffer, those of the next ent_n1 in
+    // grad_attn (both are written only after the gather has consumed the records): 0 / 0 unless the caller asked for
+    // the sample gradients in the same call and sized the workspace accordingly (MSDA_WS_RECORDS_IN_GRADS)
+    void *ent_alt0, *ent_alt1;
+    int ent_n0, ent_n1;
     void *ws_scratch;   // [pairs][I][4][D]   acc-typed partial rows: slot k of a pixel = what the cell having it as corner k left
     void *ws_cont;      // [pairs][cont_cap][4][D] acc-typed continuation rows: one set per gather workgroup
     int nc_cap, nblk_cap, win_cap, cont_cap;

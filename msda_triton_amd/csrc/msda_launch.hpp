@@ -22,6 +22,7 @@ int option_q_round();       // queries per round of the sorted grad_value path (
 int option_debug();         // dev-only ablation mask
 int option_place_path();    // 0: level-major place pass with LDS-staged runs (msda_value_place.hpp); 1: the plane-major place pass
 int option_place_block();   // threads per workgroup of the level-major place pass (0: automatic)
+int option_records_in_grads();  // 1 (default): the sorted records may live in the caller's grad_loc / grad_attn buffers
 int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream; 0: never; -1: automatic
 // fork-join helpers around a lazily created per-device side stream (msda_api.hip)
 hipStream_t side_stream_fork(hipStream_t user);   // side stream that waits for everything queued on `user`
@@ -326,7 +327,7 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
 {
     using A = typename Traits<T>::acc;
     const bool vec_ok = value_vec_ok<T>(p);
-    const SortedWsLayout w = sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), sizeof(T), vec_ok);
+    const SortedWsLayout w = sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), sizeof(T), vec_ok, p.ent_alt0 != nullptr);
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     p.ws_part = reinterpret_cast<int *>(ws + w.off_part);
     p.ws_blocktot = reinterpret_cast<int *>(ws + w.off_blocktot);
@@ -345,6 +346,8 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
     p.cont_cap = w.cont_cap;
     p.nsplit = w.nsplit;
     p.ent_cap = (int)((int64_t)w.q_round * d.L * d.P);
+    p.ent_n0 = w.ent_n0;  // (0 / 0 unless run_bwd offered the caller's grad_loc / grad_attn buffers: p.ent_alt0 / ent_alt1)
+    p.ent_n1 = w.ent_n1;
     // cells a count / place workgroup keeps in LDS at a time: what the LDS holds next to the level table and the
     // per-block totals
     {
@@ -650,7 +653,7 @@ template <typename T> inline bool value_ws_ok(const Params &p, const Dims &d, co
 {
     using A = typename Traits<T>::acc;
     const bool fits = sorted_fits<T>(d);
-    const size_t need = fits ? sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), sizeof(T), value_vec_ok<T>(p)).total : 0;
+    const size_t need = fits ? sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), sizeof(T), value_vec_ok<T>(p), p.ent_alt0 != nullptr).total : 0;
     const bool sorted = fits && workspace != nullptr && aligned_to(workspace, 256) && workspace_bytes >= 0 &&
                         (uint64_t)workspace_bytes >= need;
     return sorted || small_path_chosen<T>(d) || (option_value_path() != 2 && !option_deterministic() && small_fits<T>(d));
@@ -662,7 +665,7 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
     using A = typename Traits<T>::acc;
     const int64_t B = d.B, I = d.I, H = d.H, D = d.D, Q = d.Q, L = d.L, P = d.P;
     const bool fits = sorted_fits<T>(d);
-    const size_t need = fits ? sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p)).total : 0;
+    const size_t need = fits ? sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p), p.ent_alt0 != nullptr).total : 0;
     const bool sorted = fits && workspace != nullptr && aligned_to(workspace, 256) && (uint64_t)workspace_bytes >= need;
     const bool small_path = small_path_chosen<T>(d) ||
                             (option_value_path() != 2 && !option_deterministic() && !sorted && small_fits<T>(d));
@@ -733,6 +736,17 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     p.grad_loc = grad_loc;
     p.grad_attn = grad_attn;
     fill_params(p, d, padding_mode, align_corners);
+    // Both halves wanted, one after the other: the sorted records are dead once the gather has run and grad_loc /
+    // grad_attn are written only by the sample-gradient kernel, so that kernel goes LAST and the records of as many
+    // planes as fit live in those two buffers (three quarters of them in fp32: 61 of 82 MB at c2 @ 10k).  The workspace
+    // layout shrinks accordingly (msda_bwd_workspace_bytes_ex with MSDA_WS_RECORDS_IN_GRADS); a caller that passes the
+    // full size loses nothing.
+    const bool records_in_grads = want_sample && want_value && option_records_in_grads() != 0 && option_overlap() != 1 &&
+                                  aligned_to(grad_loc, 16) && aligned_to(grad_attn, 16);
+    if (records_in_grads) {
+        p.ent_alt0 = grad_loc;
+        p.ent_alt1 = grad_attn;
+    }
     // The workspace's front may carry the x-pair table for the sample-gradient kernel (64-byte value rows): only when
     // what follows it still covers what grad_value needs.
     const bool vec_sample = aligned_to(value, 16) && aligned_to(grad_out, 16);
@@ -767,20 +781,26 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
             forked = true;
         }
     }
-    if (want_sample) {
+    auto run_sample = [&]() -> int {
+        int r;
         if (use_pairs) {
-            rc = build_pairs<TV>(value, const_cast<void *>(p.pairs), d, sample_stream);
-            if (rc == 0) rc = dispatch_gather_pairs<T, 1, TV>(p, sample_stream);
+            r = build_pairs<TV>(value, const_cast<void *>(p.pairs), d, sample_stream);
+            if (r == 0) r = dispatch_gather_pairs<T, 1, TV>(p, sample_stream);
         } else {
-            rc = dispatch_gather<T, 1, TV>(p, vec_sample, sample_stream);
+            r = dispatch_gather<T, 1, TV>(p, vec_sample, sample_stream);
         }
+        if (r > 0) set_error("backward (grad_loc/grad_attn) launch failed: %s", hipGetErrorString((hipError_t)r));
+        return r;
+    };
+    if (want_sample && !records_in_grads) {
+        rc = run_sample();
         if (rc) {
-            if (rc > 0) set_error("backward (grad_loc/grad_attn) launch failed: %s", hipGetErrorString((hipError_t)rc));
             if (forked) (void)side_stream_join(stream);
             return rc;
         }
     }
     if (want_value) rc = run_value<T, TV>(p, d, workspace, workspace_bytes, stream);
+    if (rc == 0 && want_sample && records_in_grads) rc = run_sample();  // (its outputs held records until now)
     if (forked) {
         const int jrc = side_stream_join(stream);
         if (rc == 0 && jrc != 0) {

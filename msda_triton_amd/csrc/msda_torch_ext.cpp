@@ -132,18 +132,22 @@ public:
         const int64_t Q = pts.size(1), L = pts.size(3), P = pts.size(4);
         at::Tensor g_img, g_pts, g_att, ws;
         int64_t ws_bytes = 0;
+        if (want_sample) {
+            g_pts = at::empty_like(pts);
+            g_att = at::empty_like(att);
+        }
         if (want_value) {
             g_img = at::empty_like(img);
+            // all three gradients in one call: the sorted records may use the grad_loc / grad_attn buffers (the library's
+            // own conditions: 16-byte aligned buffers, no forced side-stream fork)
+            const bool in_grads = want_sample && reinterpret_cast<uintptr_t>(g_pts.data_ptr()) % 16 == 0 &&
+                                  reinterpret_cast<uintptr_t>(g_att.data_ptr()) % 16 == 0 && msda_get_option("overlap") != 1;
             ws_bytes = msda_bwd_workspace_bytes_ex(B, I, H, D, Q, L, P, (int)pts.element_size(), (int)img.element_size(),
-                                                   level_cells);
+                                                   level_cells, in_grads ? MSDA_WS_RECORDS_IN_GRADS : 0);
             ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));  // scratch: no initialisation needed
         } else {  // only the x-pair table for the sample half, if the shape takes one
             ws = fwd_workspace(img);
             ws_bytes = ws.defined() ? ws.numel() : 0;
-        }
-        if (want_sample) {
-            g_pts = at::empty_like(pts);
-            g_att = at::empty_like(att);
         }
         if (want_value || want_sample) {
             const c10::DeviceGuard guard(img.device());

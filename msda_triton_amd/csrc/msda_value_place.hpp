@@ -68,7 +68,7 @@ template <typename T, int TB> __global__ __launch_bounds__(TB) void msda_cell_pl
     int *s_gb = reinterpret_cast<int *>(msda_smem);
     const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1) + cs;
     const int *part = p.ws_part + ((size_t)pair * K + k) * p.nc_cap + cs;
-    Entry<A> *entries = static_cast<Entry<A> *>(p.ws_entries) + (size_t)pair * p.ent_cap;
+    Entry<A> *entries = plane_entries<A>(p, pair);
     const int cc = p.cell_cap;
 
     for (int c0 = 0; c0 < ncl; c0 += cc) {  // one trip unless the level has more cells than fit in LDS

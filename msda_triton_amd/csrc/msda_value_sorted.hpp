@@ -97,6 +97,15 @@ template <> struct alignas(16) Entry<double> {
     __device__ __forceinline__ double dy() const { return ddy; }
 };
 
+// the record array of plane `pair` (uniform): the caller's gradient buffers first, then the workspace
+template <typename A> __device__ __forceinline__ Entry<A> *plane_entries(const Params &p, int pair)
+{
+    if (pair < p.ent_n0) return static_cast<Entry<A> *>(p.ent_alt0) + (size_t)pair * p.ent_cap;
+    pair -= p.ent_n0;
+    if (pair < p.ent_n1) return static_cast<Entry<A> *>(p.ent_alt1) + (size_t)pair * p.ent_cap;
+    return static_cast<Entry<A> *>(p.ws_entries) + (size_t)(pair - p.ent_n1) * p.ent_cap;
+}
+
 __device__ __forceinline__ int plane_cells(const LevelTab &tab, int L)
 {
     return tab.cstart[L - 1] + (tab.h[L - 1] + 1) * (tab.w[L - 1] + 1);
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
     int *part = p.ws_part + ((size_t)pair * p.nsplit + slice) * p.nc_cap;  // [cell] of this slice
     int *blocktot = p.ws_blocktot + ((size_t)pair * p.nsplit + slice) * p.nblk_cap;
     const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
-    Entry<A> *entries = static_cast<Entry<A> *>(p.ws_entries) + (size_t)pair * p.ent_cap;
+    Entry<A> *entries = plane_entries<A>(p, pair);
     // per-plane bases (64-bit, uniform) + 32-bit per-sample offsets (the host checks Q*H*L*P*2 < 2^31)
     const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
     const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
@@ -343,7 +352,7 @@ template <typename T> __global__ __launch_bounds__(kWave) void msda_cell_place_d
     const int cap = p.cell_cap;
     const int *part = p.ws_part + ((size_t)pair * p.nsplit + slice) * p.nc_cap;
     const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
-    Entry<A> *entries = static_cast<Entry<A> *>(p.ws_entries) + (size_t)pair * p.ent_cap;
+    Entry<A> *entries = plane_entries<A>(p, pair);
     const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
     const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
     const T *attn = static_cast<const T *>(p.attn) + plane_s0;
@@ -577,7 +586,7 @@ __global__ __launch_bounds__(GB) void msda_value_gather_kernel(const Params p)
     __shared__ int s_cont[NU];   // the unit's first segment continues the previous window's cell
     __shared__ int s_pure[NU];   // ... and is the unit's only segment
 
-    const Entry<A> *entries = static_cast<const Entry<A> *>(p.ws_entries) + (size_t)pair * p.ent_cap;
+    const Entry<A> *entries = plane_entries<A>(p, pair);
     const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
     const uint32_t q_stride = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);  // bytes; Q*H*D*sizeof < 2^31 is checked on the host
     // grad_out rows of this plane through a buffer descriptor: scalar base + 32-bit byte offset per lane
@@ -969,6 +978,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
 struct SortedWsLayout {
     int nc_cap, nblk_cap, win, win_cap, cont_cap, nsplit;
     int q_round, rounds;  // queries per round and rounds over the queries (1: everything at once)
+    int ent_n0, ent_n1;   // planes whose records live in the caller's grad_loc / grad_attn buffer
     size_t off_part, off_blocktot, off_off, off_total, off_meta, off_entries, off_scratch, off_cont, off_accum, total;
 };
 
@@ -991,8 +1001,10 @@ inline int gather_group_lanes(int64_t D, size_t elem_bytes, bool vec)
 // `vec`: size for the 16-byte vector path (aligned grad_out / grad_value, D a multiple of 16 bytes of elements);
 // the scalar path has fewer windows per workgroup and needs more continuation rows (msda_bwd_workspace_bytes reports
 // the larger of the two layouts)
+// records_in_grads: the caller's grad_loc / grad_attn buffers (of elem_bytes elements) hold the records of as many
+// planes as fit them (MSDA_WS_RECORDS_IN_GRADS); ent_n0 / ent_n1 say how many
 inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P,
-                                       size_t acc_bytes, size_t elem_bytes, bool vec = true)
+                                       size_t acc_bytes, size_t elem_bytes, bool vec = true, bool records_in_grads = false)
 {
     SortedWsLayout w;
     const size_t pairs = (size_t)(B * H);
@@ -1060,7 +1072,17 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     w.off_off = o;      o = align_up(o + pairs * ((size_t)w.nc_cap + 1) * 4, 256);
     w.off_total = o;    o = align_up(o + pairs * 4, 256);
     w.off_meta = o;     o = align_up(o + 256, 256);
-    w.off_entries = o;  o = align_up(o + pairs * samples * entry_bytes, 256);
+    w.ent_n0 = w.ent_n1 = 0;
+    if (records_in_grads && samples > 0) {
+        const size_t plane_bytes = samples * entry_bytes;
+        const size_t loc_bytes = (size_t)(B * Q * H * L * P) * 2 * elem_bytes, attn_bytes = loc_bytes / 2;
+        size_t n0 = loc_bytes / plane_bytes, n1 = attn_bytes / plane_bytes;
+        if (n0 > pairs) n0 = pairs;
+        if (n1 > pairs - n0) n1 = pairs - n0;
+        w.ent_n0 = (int)n0;
+        w.ent_n1 = (int)n1;
+    }
+    w.off_entries = o;  o = align_up(o + (pairs - w.ent_n0 - w.ent_n1) * samples * entry_bytes, 256);
     w.off_scratch = o;  o = align_up(o + pairs * (size_t)I * 4 * (size_t)D * acc_bytes, 256);
     w.off_cont = o;     o = align_up(o + pairs * (size_t)w.cont_cap * 4 * (size_t)D * acc_bytes, 256);
     w.off_accum = o;    if (w.rounds > 1) o = align_up(o + pairs * (size_t)I * (size_t)D * acc_bytes, 256);

@@ -314,10 +314,17 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
         if not want_value:  # only the x-pair table, if the shape takes one
             ws, ws_bytes = _fwd_workspace(lib, img)
         else:  # scratch: the inverted index (grad_value), in front of it the x-pair table
-            key = (B, I, H, D, Q, L, P, sampling_points.element_size(), img.element_size(), _lib.OPTION_EPOCH, level_cells)
+            # all three gradients in ONE call: the sorted records may use the grad_loc / grad_attn buffers (smaller
+            # workspace); the per-kernel timer issues the halves as two calls and needs the full size
+            # (the library's own conditions: 16-byte aligned gradient buffers, no forced side-stream fork)
+            flags = _lib.WS_RECORDS_IN_GRADS if (want_sample and KernelTimer.active is None
+                                                 and g_pts.data_ptr() % 16 == 0 and g_att.data_ptr() % 16 == 0
+                                                 and _lib.get_option("overlap") != 1) else 0
+            key = (B, I, H, D, Q, L, P, sampling_points.element_size(), img.element_size(), _lib.OPTION_EPOCH, level_cells,
+                   flags)
             ws_bytes = _WS_BYTES.get(key)
             if ws_bytes is None:
-                ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes_ex(*key[:9], level_cells))
+                ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes_ex(*key[:9], level_cells, flags))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
         def call(value_part: bool, sample_part: bool):

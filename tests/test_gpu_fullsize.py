@@ -41,10 +41,14 @@ def assert_close_lowp(got, ref, rel, what, abs_frac=None):
 # ------------------------------------------------------------------------------------------
 # c3: Deformable-DETR encoder shape, bf16, full size, forward + backward vs the fp32 oracle on the rounded inputs
 # ------------------------------------------------------------------------------------------
-def test_c3_encoder_bf16_full_size_forward_and_backward(oracle):
+@pytest.mark.parametrize("wl_name", ["c3_ddetr_enc", "c3_ddetr_enc_local"])
+def test_c3_encoder_bf16_full_size_forward_and_backward(oracle, wl_name):
+    """... with uniformly random sampling points, and with what an encoder layer produces: every query sits
+    on a pixel, its samples are that pixel's centre + N(0, 2 px) offsets — neighbouring queries hit the same few cells
+    (cell lists of very unequal length; ~5 % of the samples fall outside the image)."""
     from msda_triton_amd import synth
     ops = _ops()
-    wl = synth.WORKLOADS["c3_ddetr_enc"]
+    wl = synth.WORKLOADS[wl_name]
     d = synth.make_inputs_torch(wl, "cpu", seed=0, loc_lo=-0.02, loc_hi=1.02)  # bf16 tensors
     v, l, a = (d[k].to(DEV).requires_grad_(True) for k in ("value", "loc", "attn"))
     out = ops.multiscale_deformable_attention(v, d["shapes"].to(DEV), l, a, wl.padding_mode, wl.align_corners)
