@@ -249,19 +249,14 @@ MSDA_API const char *msda_last_error(void);
  *                   measured to pay (next to the sorted pipeline from 4M samples when rows have >= 128 bytes; never
  *                   next to the single-launch kernel): the fork/join itself costs ~14 us of host time and ~19 us of
  *                   latency;  0: never;  1: always
- *   "deterministic" 0 (default): grad_value may differ in the last bit from run to run (the order of the records inside
- *                   a cell's list follows the order in which LDS atomics retire; the reference's global atomics have
- *                   the same property); out, grad_loc and grad_attn are always bitwise reproducible
- *                1: bitwise reproducible grad_value: the place pass runs one wave per query slice and ranks the samples
- *                   of a cell by index (no atomics at all); small problems take the sorted pipeline too (workspace
- *                   needed); slower
- *   "pairs"      0 (default): never;  1: pyramids with 64-byte rows are gathered through an x-pair table where the
- *                   caller gave the workspace for it (msda_fwd_ex_<dtype>, msda_bwd_<dtype>).  Off by default: the
- *                   gather itself gets 1.85x faster (profiles/r04_row_pair_bench.txt) but the kernels around it only
- *                   1.05-1.2x, which the 11 us table build per call eats (c3: fwd 86 -> 72 + 11 us, sample gradients
- *                   90 -> 86 + 11 us)
- *   "place_path" 0 (default): the level-major place pass where a plane has at least as many samples as cell-table
- *                   entries;  1: the plane-major pass always;  2: the level-major pass always
+ *   "deterministic" 0 (default): grad_value is bitwise reproducible wherever the level-major place pass runs — the
+ *                   sorted pipeline on problems with at least as many samples per plane as cell-table entries (c2 @ 5k /
+ *                   10k, c3, c5): its waves take their cursor atomics in turns, at no measurable cost.  The single-launch
+ *                   kernel (small problems) and the plane-major place pass (pyramids larger than the sample count) order a
+ *                   cell's records by LDS atomic retirement: there grad_value may differ in the last bit from run to run
+ *                   (as the reference's global atomics do).  out, grad_loc and grad_attn are always reproducible.
+ *                1: reproducible everywhere: those problems take the sorted pipeline with the level-major place pass too
+ *                   (workspace needed; c4: 0.117 -> 0.164 ms fwd+bwd)
  *   "records_in_grads" 1 (default): msda_bwd_<dtype> with all three gradients keeps sorted records in the grad_loc /
  *                   grad_attn buffers until the sample-gradient kernel overwrites them;  0: never
  *   "profile"    0 (default);  1: event pairs around every kernel launch, read with msda_profile_read (measurement only)

@@ -28,7 +28,6 @@ static std::atomic<int> g_overlap{-1};
 static std::atomic<int> g_gather_win{0};
 static std::atomic<int> g_deterministic{0};
 static std::atomic<int> g_place_path{0};
-static std::atomic<int> g_place_block{0};
 static std::atomic<int> g_pairs{0};
 static std::atomic<int> g_profile{0};
 static std::atomic<int> g_records_in_grads{1};
@@ -114,7 +113,6 @@ int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
 int option_gather_win() { return g_gather_win.load(std::memory_order_relaxed); }
 int option_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
 int option_place_path() { return g_place_path.load(std::memory_order_relaxed); }
-int option_place_block() { return g_place_block.load(std::memory_order_relaxed); }
 int option_pairs() { return g_pairs.load(std::memory_order_relaxed); }
 int option_profile() { return g_profile.load(std::memory_order_relaxed); }
 int option_records_in_grads() { return g_records_in_grads.load(std::memory_order_relaxed); }
@@ -318,10 +316,6 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_place_path.store(value == 1 || value == 2 ? value : 0, std::memory_order_relaxed);
         return 0;
     }
-    if (key && strcmp(key, "place_block") == 0 && (value == 0 || value == 256 || value == 512 || value == 1024)) {
-        msda::g_place_block.store(value, std::memory_order_relaxed);
-        return 0;
-    }
     if (key && strcmp(key, "pairs") == 0) {
         msda::g_pairs.store(value ? 1 : 0, std::memory_order_relaxed);
         return 0;
@@ -360,7 +354,6 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "gather_win") == 0) return msda::option_gather_win();
     if (key && strcmp(key, "deterministic") == 0) return msda::option_deterministic();
     if (key && strcmp(key, "place_path") == 0) return msda::option_place_path();
-    if (key && strcmp(key, "place_block") == 0) return msda::option_place_block();
     if (key && strcmp(key, "pairs") == 0) return msda::option_pairs();
     if (key && strcmp(key, "profile") == 0) return msda::option_profile();
     if (key && strcmp(key, "records_in_grads") == 0) return msda::option_records_in_grads();

@@ -21,7 +21,6 @@ int option_level_cells();   // caller's promise: no level has more than this man
 int option_q_round();       // queries per round of the sorted grad_value path (0: automatic)
 int option_debug();         // dev-only ablation mask
 int option_place_path();    // 0: level-major place pass with LDS-staged runs (msda_value_place.hpp); 1: the plane-major place pass
-int option_place_block();   // threads per workgroup of the level-major place pass (0: automatic)
 int option_records_in_grads();  // 1 (default): the sorted records may live in the caller's grad_loc / grad_attn buffers
 int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream; 0: never; -1: automatic
 // fork-join helpers around a lazily created per-device side stream (msda_api.hip)
@@ -371,8 +370,6 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
     static std::atomic<uint64_t> big_lds_count{0}, big_lds_place{0};
     allow_big_lds(msda_cell_pass_kernel<T, false>, big_lds_count);
     allow_big_lds(msda_cell_pass_kernel<T, true>, big_lds_place);
-    static std::atomic<uint64_t> big_lds_place_det{0};
-    allow_big_lds(msda_cell_place_det_kernel<T>, big_lds_place_det);
     const int64_t scan_blocks = (int64_t)p.nblk_cap * npairs;
     if (scan_blocks >= ((int64_t)1 << 31)) {
         set_error("grid too large");
@@ -382,13 +379,14 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
     const int g3_cell = p.grid3d, cell_cap_pm = p.cell_cap;
     // level-major place pass with LDS-staged runs (msda_value_place.hpp) unless the deterministic option asks for the
     // one-wave kernel; 512 threads: two workgroups per CU at its register count
-    const int place_tb = option_place_block() == 1024 ? 1024 : option_place_block() == 256 ? 256 : kPlaceBlock;
-    // ... when a plane has at least as many samples as its cell tables have entries: every workgroup loads its level's
-    // whole table, so on pyramids much larger than the sample count (a decoder over a real image: 14 k samples against
-    // 36 k cells per plane) the tables outweigh the samples and the plane-major pass is faster (14 us against 21)
-    const bool place_lm = d.P >= 1 && d.P <= place_tb && !option_deterministic() &&
-                          (option_place_path() == 0 ? (int64_t)w.q_round * d.L * d.P >= (int64_t)w.nc_cap
-                                                    : option_place_path() == 2);
+    // The level-major place pass (msda_value_place.hpp; reproducible record order) where a plane has at least as many
+    // samples as its cell tables have entries: every workgroup loads its level's whole table, so on pyramids much larger
+    // than the sample count (a decoder over a real image: 14 k samples against 36 k cells per plane) the tables outweigh
+    // the samples and the plane-major pass is faster (14 us against 21) — unless the caller asked for reproducible
+    // results everywhere (option "deterministic").
+    const bool place_lm = d.P >= 1 && d.P <= kPlaceBlock &&
+                          (option_deterministic() || (option_place_path() == 0 ? (int64_t)w.q_round * d.L * d.P >= (int64_t)w.nc_cap
+                                                                               : option_place_path() == 2));
     const int place_cells = place_cell_cap(w.nc_cap, (size_t)kMaxDynLds);
     dim3 gplace;
     int g3_place = 0;
@@ -398,10 +396,8 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
             return MSDA_ERR_TOO_LARGE;
         }
         g3_place = p.grid3d;
-        static std::atomic<uint64_t> big_lds_lm[3] = {};
-        allow_big_lds(msda_cell_place_lm_kernel<T, 256>, big_lds_lm[0]);
-        allow_big_lds(msda_cell_place_lm_kernel<T, 512>, big_lds_lm[1]);
-        allow_big_lds(msda_cell_place_lm_kernel<T, 1024>, big_lds_lm[2]);
+        static std::atomic<uint64_t> big_lds_lm{0};
+        allow_big_lds(msda_cell_place_lm_kernel<T, kPlaceBlock>, big_lds_lm);
     }
     for (int r = 0; r < w.rounds; ++r) {  // one round unless Q is so large that a plane's grad_out rows leave L2
         p.q_begin = r * w.q_round;
@@ -418,21 +414,11 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
             hipLaunchKernelGGL((msda_cell_scan_kernel<T>), dim3((unsigned)scan_blocks), dim3(kScanCells), 0, stream, p);
         }
         {
-        const ProfileScope prof_place(option_deterministic() ? "msda_cell_place_det_kernel" : place_lm ? "msda_cell_place_lm_kernel"
-                                                                                              : "msda_cell_pass_kernel<place>",
-                                      stream);
-        if (option_deterministic()) {
-            hipLaunchKernelGGL((msda_cell_place_det_kernel<T>), gcell, dim3(kWave), cell_lds, stream, p);
-        } else if (place_lm) {
+        const ProfileScope prof_place(place_lm ? "msda_cell_place_lm_kernel" : "msda_cell_pass_kernel<place>", stream);
+        if (place_lm) {
             p.grid3d = g3_place;
             p.cell_cap = place_cells;
-            const size_t lds = (size_t)place_cells * 4;
-            if (place_tb == 1024)
-                hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, 1024>), gplace, dim3(1024), lds, stream, p);
-            else if (place_tb == 256)
-                hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, 256>), gplace, dim3(256), lds, stream, p);
-            else
-                hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, 512>), gplace, dim3(512), lds, stream, p);
+            hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, kPlaceBlock>), gplace, dim3(kPlaceBlock), (size_t)place_cells * 4, stream, p);
         } else {
             hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
         }

@@ -13,8 +13,7 @@
 //   LDS atomics) of different workgroups overlap; the level geometry comes from scalar loads of the shapes tensor (no
 //   LDS level table, no barrier for it), the table's off[] / part[] loads go out in batches.
 //
-// Same record array, same order, same gather / finish kernels.  The order inside a cell's list still follows LDS
-// atomics (the deterministic option keeps its one-wave kernel).
+// Same record array, same gather / finish kernels.
 #pragma once
 
 #include "msda_value_sorted.hpp"
@@ -23,11 +22,20 @@ namespace msda {
 
 constexpr int kPlaceBlock = 1024;  // threads per workgroup (two per CU at 64 VGPRs; 512 x 3 per CU: 60 us against 44.5 at c2 @ 10k)
 
+// REPRODUCIBLE ORDER: the order inside a cell's list must not depend on when LDS atomics retire (the gather sums in
+// list order).  The workgroup's waves take their cursor atomics in TURNS — wave w of round r goes when the turn counter
+// reads r * waves + w and passes it on — so a cell's records of this slice are in (round, wave, sample-in-thread, lane)
+// order every time.  Only the few hundred cycles of the atomics themselves are serialised (the cells are computed
+// before the turn, the records packed and stored after it): 46.0 us against 44.5 with free-running atomics at c2 @ 10k,
+// fwd+bwd unchanged within noise — against 715 us for the one-wave-per-slice kernel of round 3 this replaces.  Lanes
+// of ONE wave instruction that hit the same cell are ranked by the LDS hardware in a fixed order.  grad_value of the
+// sorted pipeline is therefore bitwise reproducible by default wherever this pass runs.
 template <typename T, int TB> __global__ __launch_bounds__(TB) void msda_cell_place_lm_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     constexpr int NS = sizeof(A) == 8 ? 3 : 6;  // samples a thread has in flight
+    __shared__ int s_turn;
     const int K = p.nsplit;
     int pair, slot;
     if (!decode_block(p.grid3d, p.B * p.H, p.L * K, p.xcd_map, pair, slot)) return;
@@ -89,36 +97,55 @@ template <typename T, int TB> __global__ __launch_bounds__(TB) void msda_cell_pl
                 if (i < n) s_gb[i] = va[u] + vb[u];
             }
         }
+        if (tid == 0) s_turn = 0;
         __syncthreads();
-        if (active) {
-            for (int q0 = qa + tq; q0 < qb; q0 += NS * dq) {
+        {
+            const int wid = tid / kWave, nw = TB / kWave;
+            const int rounds = (qb - qa + NS * dq - 1) / (NS * dq);  // the same for every wave: nobody skips a turn
+            for (int r = 0; r < rounds; ++r) {
+                const int q0 = qa + tq + r * NS * dq;
                 Pack<T, 2> xy[NS];
                 T at[NS];
+                unsigned rel[NS];
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
                     const int q = q0 + j * dq;
                     xy[j].v[0] = xy[j].v[1] = at[j] = TR::from_acc((A)0);
-                    if (q < qb) {
+                    if (active && q < qb) {
                         const int sidx = q * HLP + sl;
                         xy[j] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
                         at[j] = attn[sidx];
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < NS; ++j) {
+                for (int j = 0; j < NS; ++j) {  // the cells, before the turn
                     const int q = q0 + j * dq;
                     int cell;
                     uint32_t cellw;
                     A dx, dy;
-                    if (q < qb && sample_cell<A>(TR::to_acc(xy[j].v[0]), TR::to_acc(xy[j].v[1]), lh, lw, 0, ps, l, p.zeros, p.align,
-                                                 cell, cellw, dx, dy)) {
-                        const unsigned r = (unsigned)(cell - c0);
-                        if (r < (unsigned)n) {
-                            const int pos = atomicAdd(&s_gb[r], 1);
-                            // (plain store: these partial lines must merge in L2)
-                            entries[pos] = Entry<A>::pack((uint32_t)q, cellw, TR::to_acc(at[j]), dx, dy);
-                        }
+                    rel[j] = 0xFFFFFFFFu;
+                    if (active && q < qb && sample_cell<A>(TR::to_acc(xy[j].v[0]), TR::to_acc(xy[j].v[1]), lh, lw, 0, ps, l, p.zeros,
+                                                           p.align, cell, cellw, dx, dy)) {
+                        const unsigned rr = (unsigned)(cell - c0);
+                        if (rr < (unsigned)n) rel[j] = rr;
                     }
+                }
+                const int my = r * nw + wid;
+                while (__hip_atomic_load(&s_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != my) __builtin_amdgcn_s_sleep(1);
+                int pos[NS];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) pos[j] = rel[j] != 0xFFFFFFFFu ? atomicAdd(&s_gb[rel[j]], 1) : -1;
+                // (DS operations of one wave execute in order: the hand-over is behind the atomics)
+                if ((tid & (kWave - 1)) == 0) __hip_atomic_store(&s_turn, my + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {  // the records, after the turn
+                    if (pos[j] < 0) continue;
+                    const int q = q0 + j * dq;
+                    int cell;
+                    uint32_t cellw;
+                    A dx, dy;
+                    sample_cell<A>(TR::to_acc(xy[j].v[0]), TR::to_acc(xy[j].v[1]), lh, lw, 0, ps, l, p.zeros, p.align, cell, cellw, dx, dy);
+                    entries[pos[j]] = Entry<A>::pack((uint32_t)q, cellw, TR::to_acc(at[j]), dx, dy);
                 }
             }
         }

@@ -325,124 +325,6 @@ __global__ __launch_bounds__(kCellBlock) void msda_cell_pass_kernel(const Params
 }
 
 // ------------------------------------------------------------------------------------------
-// K3, deterministic variant (msda_set_option("deterministic", 1)): ONE WAVE per (plane, query slice).  The placing
-// order inside a cell list must not depend on the order in which LDS atomics retire, so there are none: the wave
-// walks its slice's samples in index order, 64 at a time, and ranks the lanes that hit the same cell by lane number
-// (ballot of the lanes with the leader's cell, population count of the lower ones).  The cursors are the wave's own
-// (plain LDS reads / writes, in program order).  A cell's list then holds the slices' records in slice order and,
-// inside a slice, in sample order — whatever the hardware does — and everything behind the sort sums in a fixed order
-// already, so grad_value is bitwise reproducible.  Costs more slices (64 per plane) and a few instructions per
-// distinct cell and batch; the count pass is order-independent and stays as it is.
-// ------------------------------------------------------------------------------------------
-template <typename T> __global__ __launch_bounds__(kWave) void msda_cell_place_det_kernel(const Params p)
-{
-    using A = typename Traits<T>::acc;
-    using TR = Traits<T>;
-    int pair, slice;
-    if (!decode_block(p.grid3d, p.B * p.H, p.nsplit, p.xcd_map, pair, slice)) return;
-    const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
-    const int qper = (p.q_end - p.q_begin + p.nsplit - 1) / p.nsplit;
-    const int qa = min(p.q_end, p.q_begin + slice * qper), qb = min(p.q_end, qa + qper);
-
-    LevelTab *tab = reinterpret_cast<LevelTab *>(msda_smem);
-    int *s_cell = reinterpret_cast<int *>(msda_smem + sizeof(LevelTab));
-    load_level_table(tab, p.shapes, p.L);
-    __syncthreads();
-    const int ncells = min(plane_cells(*tab, p.L), p.nc_cap);
-    const int cap = p.cell_cap;
-    const int *part = p.ws_part + ((size_t)pair * p.nsplit + slice) * p.nc_cap;
-    const int *off = p.ws_off + (size_t)pair * (p.nc_cap + 1);
-    Entry<A> *entries = plane_entries<A>(p, pair);
-    const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
-    const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
-    const T *attn = static_cast<const T *>(p.attn) + plane_s0;
-    const int HLP = p.H * p.LP;
-    const int lane = threadIdx.x;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int total = (qb - qa) * p.LP;  // (Q * H * L * P * 2 < 2^31: host check)
-    const unsigned LPu = (unsigned)p.LP, Pu = (unsigned)p.P;
-
-    for (int c0 = 0; c0 < ncells; c0 += cap) {  // one trip unless the plane has more cells than fit in LDS
-        const int n = min(cap, ncells - c0);
-        // this slice's first slot per cell; a single wave fills the table, so its loads go out sixteen at a time
-        for (int i0 = 0; i0 < n; i0 += 8 * kWave) {
-            int a[8], bq[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = min(i0 + u * kWave + lane, n - 1);
-                a[u] = off[c0 + i];
-                bq[u] = part[c0 + i];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + u * kWave + lane;
-                if (i < n) s_cell[i] = a[u] + bq[u];
-            }
-        }
-        __syncthreads();
-        // one batch = 64 consecutive samples of the slice, in index order; the next batch's (x, y, a) are requested
-        // before this one is ranked
-        auto fetch = [&](int f, Pack<T, 2> &xy, T &at) {
-            xy.v[0] = xy.v[1] = at = TR::from_acc((A)0);
-            if (f < total) {
-                const int dq = (int)((unsigned)f / LPu), sl = f - dq * p.LP;
-                const int sidx = (qa + dq) * HLP + sl;
-                xy = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
-                at = attn[sidx];
-            }
-        };
-        Pack<T, 2> xy_n;
-        T at_n;
-        fetch(lane, xy_n, at_n);
-        for (int f0 = 0; f0 < total; f0 += kWave) {
-            const int f = f0 + lane;
-            const Pack<T, 2> xy = xy_n;
-            const T at_t = at_n;
-            fetch(f + kWave, xy_n, at_n);
-            bool pending = false;
-            int rel = 0, q = 0;
-            uint32_t cellw = 0;
-            A dx = (A)0, dy = (A)0;
-            if (f < total) {
-                const int dq = (int)((unsigned)f / LPu), sl = f - dq * p.LP;
-                q = qa + dq;
-                const int l = (int)((unsigned)sl / Pu);
-                int cell;
-                if (sample_cell<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], tab->cstart[l], tab->start[l],
-                                   l, p.zeros, p.align, cell, cellw, dx, dy)) {
-                    rel = cell - c0;
-                    pending = (unsigned)rel < (unsigned)n;
-                }
-            }
-            // rank of every lane among the lanes of its cell (by lane number) and the size of that set: pure ALU, one
-            // trip per distinct cell of the batch
-            int rank = 0, cnt = 0;
-            bool is_lead = false;
-            unsigned long long todo = __builtin_amdgcn_ballot_w64(pending);
-            while (todo != 0ull) {
-                const int lead = __builtin_ctzll(todo);                     // lowest lane not ranked yet (uniform)
-                const int lead_rel = __builtin_amdgcn_readlane(rel, lead);  // its cell
-                const bool mine = pending && rel == lead_rel;
-                const unsigned long long same = __builtin_amdgcn_ballot_w64(mine);
-                if (mine) {
-                    rank = __builtin_popcountll(same & below);
-                    cnt = __builtin_popcountll(same);
-                    is_lead = lane == lead;
-                }
-                todo &= ~same;
-            }
-            // cursors: every lane reads its cell's, then the set's leader moves it (one writer per cell; DS operations of a
-            // wave execute in order, so the reads are done)
-            int base = 0;
-            if (pending) base = s_cell[rel];
-            if (pending && is_lead) s_cell[rel] = base + cnt;
-            if (pending) entries[base + rank] = Entry<A>::pack((uint32_t)q, cellw, TR::to_acc(at_t), dx, dy);
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // K2: cell lists' first records, one launch.  The base of a block of kScanCells cells is the sum of the per-slice
 // block totals K1 left (a few hundred loads), so no pass over the preceding cells and no look-back is needed.
 // ------------------------------------------------------------------------------------------
@@ -985,7 +867,7 @@ struct SortedWsLayout {
 int option_q_round();  // queries per round of the sorted path (0: automatic), msda_api.hip
 
 int option_cell_slices();  // 0: automatic (msda_api.hip)
-int option_deterministic();  // 1: bitwise reproducible grad_value (one-wave place pass, 64 slices, no single-launch kernel)
+int option_deterministic();  // 1: bitwise reproducible grad_value everywhere (level-major place pass always, no single-launch kernel)
 int option_gather_win();   // records per gather window (0: automatic)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1056,10 +938,6 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     // 4 slices 183.
     const int64_t by_tables = I > 0 ? (int64_t)((9 * samples) / (2 * (size_t)I)) : ns;
     if (ns > by_tables) ns = by_tables;
-    if (option_deterministic()) {  // one wave per slice in the place pass: as many slices as the tables allow
-        ns = 64;
-        if (ns > by_work * 8) ns = by_work * 8 > 0 ? by_work * 8 : 1;  // (at least ~256 samples each)
-    }
     if (option_cell_slices() > 0) ns = option_cell_slices();
     if (ns > 64) ns = 64;
     if (ns > q_round) ns = q_round;

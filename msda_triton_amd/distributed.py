@@ -222,6 +222,17 @@ def _owner_groups(B: int, Q: int, group):
     return out
 
 
+def default_overlap_chunks(rows: int, world: int) -> int:
+    """Pieces a rank's rows are computed and exchanged in (the same number on every rank: it follows the nominal shard
+    size).  Piece k's exchange runs while piece k + 1 computes, so only the LAST piece's exchange is exposed: more
+    pieces hide more of it, as long as a piece stays worth a message (>= 4 096 rows: 4 MB per peer at c2's 1 KB rows).
+    c2 weak scaling (40 000 rows per rank): 8 pieces (round 3: at most 4); c5 strong scaling over 8 ranks (50 000 rows
+    per rank, 51 MB per peer): 8 pieces, 1/8 of the exchange exposed instead of 1/4."""
+    if world <= 1:
+        return 1
+    return max(1, min(8, -(-rows // world) // 4096))
+
+
 def _chunk_bounds(n: int, chunks: int, k: int) -> Tuple[int, int]:
     """Rows [begin, end) of chunk ``k`` when ``n`` rows are cut into ``chunks`` ceil-sized pieces."""
     cs = -(-n // chunks) if chunks > 0 else n
@@ -438,8 +449,7 @@ def row_sharded_multiscale_deformable_attention(
             _WARNED_OWNERS_DOWNGRADE = True
             warnings.warn("grad_value_sync='owners' needs sub-groups of the DEFAULT process group; on a caller-supplied "
                           "group grad_value is all-reduced over that group instead", stacklevel=2)
-    if overlap_chunks is None:  # exchange piece by piece only when a piece is worth a message (>= ~2k rows); the
-        # count must be the same on every rank, so it follows the nominal shard size, not this rank's
-        overlap_chunks = max(1, min(4, -(-rows // world) // 2048)) if world > 1 else 1
+    if overlap_chunks is None:
+        overlap_chunks = default_overlap_chunks(rows, world)
     return _RowShardedMSDA.apply(img, img_shapes, pts_rows, att_rows, padding_mode, bool(align_corners), Q, group,
                                  grad_value_sync, grad_sync, owners, overlap_chunks)

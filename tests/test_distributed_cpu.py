@@ -250,3 +250,71 @@ def test_bench_dry_run_failing_optional_leg_keeps_the_line():
     r = lines[0]
     assert r["ms_per_step"] > 0 and "injected failure" in r["strong_scaling_c5"]["error"]
     assert r["failed_legs"] == ["strong_scaling_c5"]
+
+
+# ---------------------------------------------------------------------------------------------
+# the piece schedule: piece k's exchange is issued BEFORE piece k + 1 is computed, all waits come last
+# ---------------------------------------------------------------------------------------------
+def _schedule_worker(rank, world, port, chunks, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        import msda_triton_amd.distributed as D
+        from msda_triton_amd import synth
+        log = []
+        real_op, real_batch = D.multiscale_deformable_attention, dist.batch_isend_irecv
+
+        def traced_op(*a, **k):
+            log.append("compute")
+            return real_op(*a, **k)
+
+        class _Req:
+            def __init__(self, r):
+                self.r = r
+
+            def wait(self):
+                log.append("wait")
+                return self.r.wait()
+
+        def traced_batch(ops):
+            log.append("exchange")
+            return [_Req(r) for r in real_batch(ops)]
+
+        D.multiscale_deformable_attention = traced_op
+        dist.batch_isend_irecv = traced_batch
+        try:
+            wl = synth.Workload("t", 1, 40, 2, 8, ((6, 5), (3, 3)), 2, "float64", "zeros", False)  # one batch element: one piece per chunk
+            d = synth.make_inputs_torch(wl, "cpu", seed=5)
+            out = D.row_sharded_multiscale_deformable_attention(d["value"], d["shapes"], d["loc"], d["attn"], "zeros", False,
+                                                                overlap_chunks=chunks)
+        finally:
+            D.multiscale_deformable_attention = real_op
+            dist.batch_isend_irecv = real_batch
+        ref = real_op(d["value"], d["shapes"], d["loc"], d["attn"], "zeros", False)
+        ret[rank] = (log, bool(torch.allclose(out, ref, atol=1e-12)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_piece_exchange_is_issued_before_the_next_piece_computes():
+    """the schedule itself, not only the result.  With c pieces the forward must run
+    compute, exchange, compute, exchange, ... and wait for the exchanges only after the last piece was issued — so that on
+    RCCL piece k travels while piece k + 1's kernels run."""
+    world, chunks = 2, 3
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_schedule_worker, args=(world, _free_port(), chunks, ret), nprocs=world, join=True)
+    for rank in range(world):
+        log, ok = ret[rank]
+        assert ok
+        assert log[:2 * chunks] == ["compute", "exchange"] * chunks, log
+        assert log[2 * chunks:] and set(log[2 * chunks:]) == {"wait"}, log
+
+
+def test_default_overlap_chunks():
+    from msda_triton_amd.distributed import default_overlap_chunks
+    assert default_overlap_chunks(40000, 1) == 1
+    assert default_overlap_chunks(4 * 10000 * 8, 8) == 8      # c2 weak scaling at 8 ranks: 40 000 rows per rank
+    assert default_overlap_chunks(400000, 8) == 8             # c5 strong scaling: 50 000 rows per rank
+    assert default_overlap_chunks(7200, 8) == 1               # c4: 900 rows per rank, one all-gather
+    assert default_overlap_chunks(400000, 2) == 8

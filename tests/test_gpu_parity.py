@@ -1036,12 +1036,37 @@ def test_sorted_grad_value_in_query_rounds(oracle, td):
         _lib.set_option("value_path", 0)
 
 
+def test_sorted_pipeline_is_bitwise_reproducible_by_default():
+    """Round 4: the level-major place pass lets its waves take their cursor atomics in turns, so wherever it runs — the
+    sorted pipeline on problems with at least as many samples as cell-table entries: c2 @ 5k / 10k, c3, c5 — grad_value
+    is bitwise reproducible WITHOUT any option, at no measurable cost.  Repeated calls, other work
+    in flight, the other workgroup -> plane mapping."""
+    from msda_triton_amd import _lib, synth
+    ops = _ops()
+    wl = synth.WORKLOADS["c2_q5k"]
+    d = synth.make_inputs_torch(wl, DEV, seed=8)
+    args = (d["grad_out"], d["value"], d["shapes"], d["loc"], d["attn"])
+    try:
+        runs = []
+        for k in range(4):
+            if k == 2:
+                _lib.set_option("xcd_map", 0)
+                noise = torch.randn(1 << 22, device=DEV).sin_()  # noqa: F841
+            runs.append(ops.msda_hip_bwd(*args, wl.padding_mode, wl.align_corners))
+            torch.cuda.synchronize()
+            _lib.set_option("xcd_map", 1)
+        for r in runs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+    finally:
+        _lib.set_option("xcd_map", 1)
+
+
 def test_deterministic_option_gives_bitwise_reproducible_grad_value(oracle):
-    """msda_set_option("deterministic", 1): the place pass ranks the samples of a cell by index instead of by the
-    order LDS atomics retire in, so the whole backward is bitwise reproducible — across repeated calls, with other
-    work interleaved on the device, and against a run under a different workgroup -> plane mapping.  Checked on a
-    shape with long cell lists (a 1 x 1 level takes a quarter of all samples) and on a c2-sized problem; the result
-    still matches the oracle."""
+    """msda_set_option("deterministic", 1): bitwise reproducible EVERYWHERE — problems the single-launch kernel or the
+    plane-major place pass would take (their record order follows LDS atomics) go through the level-major place pass
+    too.  Across repeated calls, with other work interleaved on the device, and against a run under a different
+    workgroup -> plane mapping.  Checked on a shape with long cell lists (a 1 x 1 level takes a quarter of all samples)
+    and on a c2-sized problem; the result still matches the oracle."""
     from msda_triton_amd import _lib, synth
     ops = _ops()
     rng = np.random.default_rng(515)
