@@ -527,7 +527,8 @@ def main():
     pm, ac = wl.padding_mode, wl.align_corners
     # Weak scaling: the global problem has B batch elements of world*Q queries; rank r owns B*Q contiguous rows of
     # the flattened (b, q) row space — whole batch elements while the ranks divide B.
-    gwl = synth.Workload(wl.name, wl.B, wl.Q * world, wl.H, wl.D, wl.levels, wl.P, wl.dtype, pm, ac)
+    import dataclasses
+    gwl = dataclasses.replace(wl, Q=wl.Q * world)  # (keeps the workload's sampling-point distribution, synth loc_mode)
     in_dt = None if on_gpu else torch.float32
     if use_dist:
         r0, r1 = row_shard_bounds(gwl.B * gwl.Q, world, rank)
