@@ -5,9 +5,12 @@ The default path (``functional._HipMultiscaleDeformableAttentionFunction``) is a
 launchers are registered as custom ops with fake (meta) kernels and an autograd formula, so the
 operator survives ``torch.compile(fullgraph=True)`` / ``torch.export`` as one opaque node per direction:
 
-    torch.ops.msda_amd.forward(img, img_shapes, sampling_points, attention_weights, zeros, align_corners)
+    torch.ops.msda_amd.forward(img, img_shapes, sampling_points, attention_weights, zeros, align_corners, level_cells)
     torch.ops.msda_amd.backward(out_grad, img, img_shapes, sampling_points, attention_weights, zeros,
-                                align_corners, need_value, need_sample)
+                                align_corners, need_value, need_sample, level_cells)
+
+``level_cells`` is ``functional.level_cells_of(level_shapes)`` — a host integer (0: unknown), a constant of the traced
+graph — which only the backward reads.
 
 ``compiled_multiscale_deformable_attention`` is the functional entry that uses them;
 ``functional.multiscale_deformable_attention`` switches to it automatically while being traced.
@@ -25,12 +28,12 @@ _PAD = {True: "zeros", False: "border"}
 
 @torch.library.custom_op("msda_amd::forward", mutates_args=(), device_types="cuda")
 def msda_forward(img: torch.Tensor, img_shapes: torch.Tensor, sampling_points: torch.Tensor,
-                 attention_weights: torch.Tensor, zeros: bool, align_corners: bool) -> torch.Tensor:
+                 attention_weights: torch.Tensor, zeros: bool, align_corners: bool, level_cells: int = 0) -> torch.Tensor:
     return F.msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, _PAD[zeros], align_corners)
 
 
 @msda_forward.register_fake
-def _(img, img_shapes, sampling_points, attention_weights, zeros, align_corners):
+def _(img, img_shapes, sampling_points, attention_weights, zeros, align_corners, level_cells=0):
     B, _, H, D = img.shape
     return sampling_points.new_empty((B, sampling_points.shape[1], H, D))  # (mixed storage: the result is fp32)
 
@@ -38,9 +41,9 @@ def _(img, img_shapes, sampling_points, attention_weights, zeros, align_corners)
 @torch.library.custom_op("msda_amd::backward", mutates_args=(), device_types="cuda")
 def msda_backward(out_grad: torch.Tensor, img: torch.Tensor, img_shapes: torch.Tensor, sampling_points: torch.Tensor,
                   attention_weights: torch.Tensor, zeros: bool, align_corners: bool, need_value: bool,
-                  need_sample: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                  need_sample: bool, level_cells: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     g_img, g_pts, g_att = F.msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, _PAD[zeros],
-                                         align_corners, (need_value, need_sample, need_sample))
+                                         align_corners, (need_value, need_sample, need_sample), level_cells=level_cells)
     # custom ops cannot return None: unneeded gradients come back as empty tensors
     return (g_img if g_img is not None else img.new_empty(0),
             g_pts if g_pts is not None else img.new_empty(0),
@@ -48,16 +51,17 @@ def msda_backward(out_grad: torch.Tensor, img: torch.Tensor, img_shapes: torch.T
 
 
 @msda_backward.register_fake
-def _(out_grad, img, img_shapes, sampling_points, attention_weights, zeros, align_corners, need_value, need_sample):
+def _(out_grad, img, img_shapes, sampling_points, attention_weights, zeros, align_corners, need_value, need_sample,
+      level_cells=0):
     return (torch.empty_like(img, memory_format=torch.contiguous_format) if need_value else img.new_empty(0),
             torch.empty_like(sampling_points, memory_format=torch.contiguous_format) if need_sample else img.new_empty(0),
             torch.empty_like(attention_weights, memory_format=torch.contiguous_format) if need_sample else img.new_empty(0))
 
 
 def _setup_context(ctx, inputs, output):
-    img, img_shapes, sampling_points, attention_weights, zeros, align_corners = inputs
+    img, img_shapes, sampling_points, attention_weights, zeros, align_corners, level_cells = inputs
     ctx.save_for_backward(img, img_shapes, sampling_points, attention_weights)
-    ctx.zeros, ctx.align_corners = zeros, align_corners
+    ctx.zeros, ctx.align_corners, ctx.level_cells = zeros, align_corners, level_cells
 
 
 def _backward(ctx, out_grad):
@@ -65,24 +69,25 @@ def _backward(ctx, out_grad):
     need_value = ctx.needs_input_grad[0]
     need_sample = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
     g_img, g_pts, g_att = msda_backward(out_grad.contiguous(), img, img_shapes, sampling_points, attention_weights,
-                                        ctx.zeros, ctx.align_corners, need_value, need_sample)
+                                        ctx.zeros, ctx.align_corners, need_value, need_sample, ctx.level_cells)
     return (g_img if need_value else None, None, g_pts if ctx.needs_input_grad[2] else None,
-            g_att if ctx.needs_input_grad[3] else None, None, None)
+            g_att if ctx.needs_input_grad[3] else None, None, None, None)
 
 
 msda_forward.register_autograd(_backward, setup_context=_setup_context)
 
 
 def compiled_multiscale_deformable_attention(img, img_shapes, sampling_points, attention_weights, padding_mode,
-                                             align_corners) -> torch.Tensor:
+                                             align_corners, level_cells: int = 0) -> torch.Tensor:
     """Same contract as ``hip_multiscale_deformable_attention`` but through the registered custom ops
     (traceable).  Like the default path, the op computes in fp32 under autocast."""
     F._padding_code(padding_mode)
     if torch.is_autocast_enabled("cuda"):
         with torch.autocast("cuda", enabled=False):
             return msda_forward(img.float(), img_shapes, sampling_points.float(), attention_weights.float(),
-                                padding_mode == "zeros", bool(align_corners))
-    return msda_forward(img, img_shapes, sampling_points, attention_weights, padding_mode == "zeros", bool(align_corners))
+                                padding_mode == "zeros", bool(align_corners), int(level_cells))
+    return msda_forward(img, img_shapes, sampling_points, attention_weights, padding_mode == "zeros", bool(align_corners),
+                        int(level_cells))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -91,7 +96,7 @@ def compiled_multiscale_deformable_attention(img, img_shapes, sampling_points, a
 # ---------------------------------------------------------------------------------------------
 @torch.library.custom_op("msda_amd::fused_forward", mutates_args=(), device_types="cuda")
 def msda_fused_forward(img: torch.Tensor, img_shapes: torch.Tensor, proj: torch.Tensor, reference_points: torch.Tensor,
-                       zeros: bool, align_corners: bool) -> torch.Tensor:
+                       zeros: bool, align_corners: bool, level_cells: int = 0) -> torch.Tensor:
     out = F.msda_hip_fwd_fused(img, img_shapes, proj, reference_points, _PAD[zeros], align_corners)
     if out is None:  # (callers check fused_lp_ok first; kept for safety)
         pts, att = F.module_sampling_inputs(proj, img_shapes, reference_points)
@@ -100,7 +105,7 @@ def msda_fused_forward(img: torch.Tensor, img_shapes: torch.Tensor, proj: torch.
 
 
 @msda_fused_forward.register_fake
-def _(img, img_shapes, proj, reference_points, zeros, align_corners):
+def _(img, img_shapes, proj, reference_points, zeros, align_corners, level_cells=0):
     B, _, H, D = img.shape
     return proj.new_empty((B, proj.shape[1], H, D))
 
@@ -108,8 +113,9 @@ def _(img, img_shapes, proj, reference_points, zeros, align_corners):
 @torch.library.custom_op("msda_amd::fused_backward", mutates_args=(), device_types="cuda")
 def msda_fused_backward(out_grad: torch.Tensor, img: torch.Tensor, img_shapes: torch.Tensor, proj: torch.Tensor,
                         reference_points: torch.Tensor, zeros: bool, align_corners: bool,
-                        need_value: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    res = F.msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, _PAD[zeros], align_corners, need_value)
+                        need_value: bool, level_cells: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    res = F.msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, _PAD[zeros], align_corners, need_value,
+                               level_cells=level_cells)
     if res is None:
         raise RuntimeError("msda_amd::fused_backward: L*P too large for the fused kernels (check fused_lp_ok first)")
     g_img, g_proj, g_ref = res
@@ -117,24 +123,24 @@ def msda_fused_backward(out_grad: torch.Tensor, img: torch.Tensor, img_shapes: t
 
 
 @msda_fused_backward.register_fake
-def _(out_grad, img, img_shapes, proj, reference_points, zeros, align_corners, need_value):
+def _(out_grad, img, img_shapes, proj, reference_points, zeros, align_corners, need_value, level_cells=0):
     return (torch.empty_like(img, memory_format=torch.contiguous_format) if need_value else img.new_empty(0),
             torch.empty_like(proj, memory_format=torch.contiguous_format),
             torch.empty_like(reference_points, memory_format=torch.contiguous_format))
 
 
 def _fused_setup_context(ctx, inputs, output):
-    img, img_shapes, proj, reference_points, zeros, align_corners = inputs
+    img, img_shapes, proj, reference_points, zeros, align_corners, level_cells = inputs
     ctx.save_for_backward(img, img_shapes, proj, reference_points)
-    ctx.zeros, ctx.align_corners = zeros, align_corners
+    ctx.zeros, ctx.align_corners, ctx.level_cells = zeros, align_corners, level_cells
 
 
 def _fused_backward(ctx, out_grad):
     img, img_shapes, proj, reference_points = ctx.saved_tensors
     g_img, g_proj, g_ref = msda_fused_backward(out_grad.contiguous(), img, img_shapes, proj, reference_points, ctx.zeros,
-                                               ctx.align_corners, ctx.needs_input_grad[0])
+                                               ctx.align_corners, ctx.needs_input_grad[0], ctx.level_cells)
     return (g_img if ctx.needs_input_grad[0] else None, None, g_proj if ctx.needs_input_grad[2] else None,
-            g_ref if ctx.needs_input_grad[3] else None, None, None)
+            g_ref if ctx.needs_input_grad[3] else None, None, None, None)
 
 
 msda_fused_forward.register_autograd(_fused_backward, setup_context=_fused_setup_context)
@@ -151,11 +157,13 @@ def fused_lp_ok(img: torch.Tensor, proj: torch.Tensor) -> bool:
     return int(proj.shape[3]) * int(proj.shape[4]) <= _fused_lp_limit(int(img.shape[-1]), proj.element_size())
 
 
-def compiled_fused_module_core(img, img_shapes, proj, reference_points, padding_mode, align_corners) -> torch.Tensor:
+def compiled_fused_module_core(img, img_shapes, proj, reference_points, padding_mode, align_corners,
+                               level_cells: int = 0) -> torch.Tensor:
     """``fused_module_core`` through the registered custom ops (traceable); fp32 under autocast like the eager path."""
     F._padding_code(padding_mode)
     if torch.is_autocast_enabled("cuda"):
         with torch.autocast("cuda", enabled=False):
             return msda_fused_forward(img.float(), img_shapes, proj.float(), reference_points.float(),
-                                      padding_mode == "zeros", bool(align_corners))
-    return msda_fused_forward(img, img_shapes, proj, reference_points, padding_mode == "zeros", bool(align_corners))
+                                      padding_mode == "zeros", bool(align_corners), int(level_cells))
+    return msda_fused_forward(img, img_shapes, proj, reference_points, padding_mode == "zeros", bool(align_corners),
+                              int(level_cells))

@@ -403,7 +403,8 @@ def hip_multiscale_deformable_attention(
     if torch.compiler.is_compiling():  # traced by torch.compile / export: use the registered custom ops
         from .compile_op import compiled_multiscale_deformable_attention
         return compiled_multiscale_deformable_attention(
-            img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners)
+            img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners,
+            level_cells_of(level_shapes, img_shapes.shape[0], img.shape[1]))
     # Optional C++ autograd glue over the same C ABI (csrc/msda_torch_ext.cpp): same kernels, a fraction of the host
     # time per call.  The Python Function below serves autocast (fp32 casting), per-kernel timing and every
     # installation where the binding was not built.
@@ -618,9 +619,9 @@ def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, ali
         from . import compile_op  # traced: keep the fused kernels as one custom op per direction
         if compile_op.fused_lp_ok(img, proj):
             return compile_op.compiled_fused_module_core(img, img_shapes, proj, reference_points, padding_mode,
-                                                         align_corners)
+                                                         align_corners, level_cells)
     pts, att = module_sampling_inputs(proj, img_shapes, reference_points)
-    return multiscale_deformable_attention(img, img_shapes, pts, att, padding_mode, align_corners)
+    return multiscale_deformable_attention(img, img_shapes, pts, att, padding_mode, align_corners, level_shapes=level_shapes)
 
 
 # ------------------------------------------------------------------------------------------

@@ -240,6 +240,8 @@ def test_bench_dry_run_world2_prints_the_contract_line():
     assert r["ms_per_step"] == min(ex["all_gather"]["fwd_bwd_ms"], ex["pieces"]["fwd_bwd_ms"])
     s = r["strong_scaling_c5"]
     assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["ms_per_step"] > 0
+    # the unsharded leg timed on rank 0 of the same job (not only the cross-run record)
+    assert s["n1_same_job_ms"] > 0 and abs(s["speedup_vs_n1_same_job"] - s["n1_same_job_ms"] / s["ms_per_step"]) < 1e-9
     assert "failed_legs" not in r
 
 

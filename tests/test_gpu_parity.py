@@ -953,6 +953,41 @@ def test_level_shapes_hint_opens_the_single_launch_kernel_on_image_sized_pyramid
         assert lib.msda_bwd_workspace_bytes(*dims) > 0       # withdrawn again (this thread; the engine's thread set its own)
 
 
+def test_level_shapes_reach_the_backward_of_the_compiled_op(oracle):
+    """torch.compile: `level_shapes` becomes the custom ops' `level_cells` constant, so the compiled
+    operator's backward takes the single-launch grad_value kernel on an image-sized pyramid like the eager one — read
+    off the library's own kernel records."""
+    from msda_triton_amd import _lib
+    ops = _ops()
+    import msda_triton_amd.compile_op  # noqa: F401
+    levels = [(100, 134), (50, 67), (25, 34), (13, 17)]
+    c = rand_case(np.random.default_rng(78), 1, 60, 2, 32, levels, 4, lo=-0.05, hi=1.05)
+    r_gv, _, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in c.items()}
+
+    def with_hint(v, l, a):
+        return ops.multiscale_deformable_attention(v, t["shapes"], l, a, "zeros", False, level_shapes=levels)
+
+    def without(v, l, a):
+        return ops.multiscale_deformable_attention(v, t["shapes"], l, a, "zeros", False)
+
+    for fn, kernel in ((with_hint, "msda_value_small_kernel"), (without, "msda_value_gather_kernel")):
+        f = torch.compile(fn, fullgraph=True, backend="aot_eager")
+        v, l, a = (t[k].clone().requires_grad_(True) for k in ("value", "loc", "attn"))
+        out = f(v, l, a)
+        _lib.set_option("profile", 1)
+        try:
+            _lib.profile_read()
+            out.backward(t["grad_out"])
+            torch.cuda.synchronize()
+            ran = _lib.profile_read()
+        finally:
+            _lib.set_option("profile", 0)
+        assert kernel in ran, (fn.__name__, sorted(ran))
+        np.testing.assert_allclose(v.grad.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
+        np.testing.assert_allclose(a.grad.cpu().numpy(), r_ga, **BWD_TOL[torch.float32])
+
+
 def test_level_shapes_hint_through_the_fused_module_core_and_the_module():
     """The same promise through fused_module_core (C++ node or Python Function) and MultiscaleDeformableAttention's
     forward(level_shapes=...): same outputs and gradients as without it (the route differs, the numbers may in the
