@@ -249,14 +249,15 @@ MSDA_API const char *msda_last_error(void);
  *                   measured to pay (next to the sorted pipeline from 4M samples when rows have >= 128 bytes; never
  *                   next to the single-launch kernel): the fork/join itself costs ~14 us of host time and ~19 us of
  *                   latency;  0: never;  1: always
- *   "deterministic" 0 (default): grad_value is bitwise reproducible wherever the level-major place pass runs — the
- *                   sorted pipeline on problems with at least as many samples per plane as cell-table entries (c2 @ 5k /
- *                   10k, c3, c5): its waves take their cursor atomics in turns, at no measurable cost.  The single-launch
- *                   kernel (small problems) and the plane-major place pass (pyramids larger than the sample count) order a
- *                   cell's records by LDS atomic retirement: there grad_value may differ in the last bit from run to run
- *                   (as the reference's global atomics do).  out, grad_loc and grad_attn are always reproducible.
- *                1: reproducible everywhere: those problems take the sorted pipeline with the level-major place pass too
- *                   (workspace needed; c4: 0.117 -> 0.164 ms fwd+bwd)
+ *   "deterministic" accepted and stored, without effect since ABI 9: grad_value is bitwise reproducible ALWAYS (for
+ *                   P <= 1024 points per level) — the place pass of the sorted pipeline and the single-launch kernel of
+ *                   the small problems both let their waves take the list-cursor atomics in turns, so a cell's records
+ *                   are in the same order in every run (cost: 1.5 us of 46 in the place pass, 2.2 us of 48 in the
+ *                   single-launch kernel at the Grounding-DINO decoder shape).  out, grad_loc and grad_attn always were.
+ *                   (ABI 8: 1 routed every problem through a one-wave place pass, 2.9x the fwd+bwd time.)
+ *   "place_path" 0 (default) / 2: the level-major place pass;  1: the plane-major one where it is faster (pyramids much
+ *                   larger than the sample count: 14 us against 21) — its record order follows LDS atomics, grad_value
+ *                   may then differ in the last bit from run to run (measurement only)
  *   "records_in_grads" 1 (default): msda_bwd_<dtype> with all three gradients keeps sorted records in the grad_loc /
  *                   grad_attn buffers until the sample-gradient kernel overwrites them;  0: never
  *   "profile"    0 (default);  1: event pairs around every kernel launch, read with msda_profile_read (measurement only)

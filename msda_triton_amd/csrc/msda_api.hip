@@ -111,7 +111,7 @@ void set_thread_level_cells(int64_t n) { t_level_cells = n > 0 ? n : 0; }
 int64_t get_thread_level_cells() { return t_level_cells; }
 int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
 int option_gather_win() { return g_gather_win.load(std::memory_order_relaxed); }
-int option_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
+int option_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }  // (stored, without effect)
 int option_place_path() { return g_place_path.load(std::memory_order_relaxed); }
 int option_pairs() { return g_pairs.load(std::memory_order_relaxed); }
 int option_profile() { return g_profile.load(std::memory_order_relaxed); }

@@ -377,16 +377,13 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
     }
     constexpr int VECF = 16 / sizeof(T);
     const int g3_cell = p.grid3d, cell_cap_pm = p.cell_cap;
-    // level-major place pass with LDS-staged runs (msda_value_place.hpp) unless the deterministic option asks for the
-    // one-wave kernel; 512 threads: two workgroups per CU at its register count
-    // The level-major place pass (msda_value_place.hpp; reproducible record order) where a plane has at least as many
-    // samples as its cell tables have entries: every workgroup loads its level's whole table, so on pyramids much larger
-    // than the sample count (a decoder over a real image: 14 k samples against 36 k cells per plane) the tables outweigh
-    // the samples and the plane-major pass is faster (14 us against 21) — unless the caller asked for reproducible
-    // results everywhere (option "deterministic").
-    const bool place_lm = d.P >= 1 && d.P <= kPlaceBlock &&
-                          (option_deterministic() || (option_place_path() == 0 ? (int64_t)w.q_round * d.L * d.P >= (int64_t)w.nc_cap
-                                                                               : option_place_path() == 2));
+    // The level-major place pass (msda_value_place.hpp; reproducible record order) serves every shape it can (P <= its
+    // workgroup).  On pyramids much larger than the sample count (a decoder over a real image without the level-size
+    // bound: 14 k samples against 36 k cells per plane) every workgroup loads its level's whole table and the
+    // plane-major pass would be faster (14 us against 21 of a 147 us group) — but its record order follows LDS atomics,
+    // and one rule — grad_value is bitwise reproducible — is worth more than 3 % on that shape.  place_path = 1 keeps
+    // the plane-major pass reachable for measurements.
+    const bool place_lm = d.P >= 1 && d.P <= kPlaceBlock && option_place_path() != 1;
     const int place_cells = place_cell_cap(w.nc_cap, (size_t)kMaxDynLds);
     dim3 gplace;
     int g3_place = 0;
@@ -626,7 +623,6 @@ template <typename T> inline bool small_fits(const Dims &d)
 }
 template <typename T> inline bool small_path_chosen(const Dims &d)
 {
-    if (option_deterministic()) return false;  // (its LDS placing order follows the atomics)
     return small_fits<T>(d) && (option_value_path() == 3 || (option_value_path() == 0 && d.Q * d.P <= 4096));
 }
 
@@ -642,7 +638,7 @@ template <typename T> inline bool value_ws_ok(const Params &p, const Dims &d, co
     const size_t need = fits ? sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), sizeof(T), value_vec_ok<T>(p), p.ent_alt0 != nullptr).total : 0;
     const bool sorted = fits && workspace != nullptr && aligned_to(workspace, 256) && workspace_bytes >= 0 &&
                         (uint64_t)workspace_bytes >= need;
-    return sorted || small_path_chosen<T>(d) || (option_value_path() != 2 && !option_deterministic() && small_fits<T>(d));
+    return sorted || small_path_chosen<T>(d) || (option_value_path() != 2 && small_fits<T>(d));
 }
 
 template <typename T, typename TV = T>
@@ -654,7 +650,7 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
     const size_t need = fits ? sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p), p.ent_alt0 != nullptr).total : 0;
     const bool sorted = fits && workspace != nullptr && aligned_to(workspace, 256) && (uint64_t)workspace_bytes >= need;
     const bool small_path = small_path_chosen<T>(d) ||
-                            (option_value_path() != 2 && !option_deterministic() && !sorted && small_fits<T>(d));
+                            (option_value_path() != 2 && !sorted && small_fits<T>(d));
     // (no workspace: the single-launch kernel serves whatever fits its LDS)
     int rc;
     if (small_path) {

@@ -18,6 +18,8 @@
 // Replaces tl.atomic_add of the reference (kernels.py:543-553) for these shapes.
 #pragma once
 
+#include <type_traits>
+
 #include "msda_value_sorted.hpp"
 
 namespace msda {
@@ -121,8 +123,10 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     uint16_t *s_order = reinterpret_cast<uint16_t *>(sm + o);  // [blocks of the level] heaviest first
 
     __shared__ int s_red[kSmallBlock / kWave];
+    __shared__ int s_turn;
 
     for (int i = tid; i <= ncl; i += kSmallBlock) s_off[i] = 0;
+    if (tid == 0) s_turn = 0;
     __syncthreads();
 
     auto walk = [&](auto &&visit) {  // visit(q, attention weight, in-level cell, dx, dy)
@@ -183,16 +187,85 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
         if (tid == kSmallBlock - 1) s_off[ncl] = base;  // (the last thread's run ends at ncl, possibly empty)
         __syncthreads();
     }
-    // 3 place: cursor = list start (restored afterwards by shifting: list c ends where list c + 1 began)
-    walk([&](int q, A at, int cell, A dx, A dy) {
-        const int pos = atomicAdd(&s_off[cell], 1);
-        SmallRec<A> r;
-        r.q = (uint32_t)q;
-        r.dx = dx;
-        r.dy = dy;
-        r.a = at;
-        s_rec[pos] = r;
-    });
+    // 3 place: cursor = list start (restored afterwards by shifting: list c ends where list c + 1 began).
+    // REPRODUCIBLE ORDER (as msda_value_place.hpp): the waves take their cursor atomics in turns — batch n of wave w
+    // goes when the turn counter reads n * waves + w — so a list's order, and with it every sum of the gather below,
+    // is the same in every run; the cells are computed before the turn, the records written after it.  Every wave
+    // runs the same number of batches (inactive threads pass with nothing to place).  Cost: 16 hand-overs of ~140 ns
+    // per batch, c4 48.1 -> 50.3 us, c1 22.5 -> 24.6 us (same-box A/B; spinning without s_sleep: the same).
+    {
+        constexpr int NW = kSmallBlock / kWave;
+        const int wid = tid / kWave;
+        auto batch = [&](int my, auto nconst, const int *qs, const Pack<T, 2> *xys, const T *ats) {
+            constexpr int N = decltype(nconst)::value;
+            int cell[N];
+            A dx[N], dy[N];
+            bool ok[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                uint32_t cellw;
+                ok[k] = qs[k] >= 0 && sample_cell<A>(TR::to_acc(xys[k].v[0]), TR::to_acc(xys[k].v[1]), lh, lw, 0, 0, 0, p.zeros,
+                                                     p.align, cell[k], cellw, dx[k], dy[k]) && cell[k] < ncl;
+            }
+            while (__hip_atomic_load(&s_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != my) __builtin_amdgcn_s_sleep(1);
+            int pos[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) pos[k] = ok[k] ? atomicAdd(&s_off[cell[k]], 1) : -1;
+            // (DS operations of one wave execute in order: the hand-over is behind the atomics)
+            if ((tid & (kWave - 1)) == 0) __hip_atomic_store(&s_turn, my + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                if (pos[k] < 0) continue;
+                SmallRec<A> r;
+                r.q = (uint32_t)qs[k];
+                r.dx = dx[k];
+                r.dy = dy[k];
+                r.a = TR::to_acc(ats[k]);
+                s_rec[pos[k]] = r;
+            }
+        };
+        if (p.P <= kSmallBlock && (p.Q + dq - 1) / dq <= kPre) {  // (uniform) the prefetched samples: one batch
+            int qs[kPre];
+#pragma unroll
+            for (int k = 0; k < kPre; ++k) qs[k] = pre && q0 + k * dq < p.Q ? q0 + k * dq : -1;
+            batch(wid, std::integral_constant<int, kPre>{}, qs, pre_xy, pre_a);
+        } else if (p.P <= kSmallBlock) {
+            const int rounds = (p.Q + kPre * dq - 1) / (kPre * dq);
+            for (int r = 0; r < rounds; ++r) {
+                int qs[kPre];
+                Pack<T, 2> xys[kPre];
+                T ats[kPre];
+#pragma unroll
+                for (int k = 0; k < kPre; ++k) {
+                    const int q = q0 + (r * kPre + k) * dq;
+                    qs[k] = active && q < p.Q ? q : -1;
+                    xys[k].v[0] = xys[k].v[1] = ats[k] = TR::from_acc((A)0);
+                    if (qs[k] >= 0) {
+                        const int sidx = q * HLP + lvl * p.P + pt;
+                        xys[k] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                        ats[k] = attn[sidx];
+                    }
+                }
+                batch(r * NW + wid, std::integral_constant<int, kPre>{}, qs, xys, ats);
+            }
+        } else {
+            int it = 0;
+            for (int q = 0; q < p.Q; ++q)
+                for (int pp0 = 0; pp0 < p.P; pp0 += kSmallBlock, ++it) {
+                    const int pp = pp0 + tid;
+                    int qs[1] = {pp < p.P ? q : -1};
+                    Pack<T, 2> xys[1];
+                    T ats[1];
+                    xys[0].v[0] = xys[0].v[1] = ats[0] = TR::from_acc((A)0);
+                    if (qs[0] >= 0) {
+                        const int sidx = q * HLP + lvl * p.P + pp;
+                        xys[0] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                        ats[0] = attn[sidx];
+                    }
+                    batch(it * NW + wid, std::integral_constant<int, 1>{}, qs, xys, ats);
+                }
+        }
+    }
     __syncthreads();
     // after placing, s_off[c] = END of list c (= start of list c + 1); list c = [c ? s_off[c-1] : 0, s_off[c])
 

@@ -867,7 +867,6 @@ struct SortedWsLayout {
 int option_q_round();  // queries per round of the sorted path (0: automatic), msda_api.hip
 
 int option_cell_slices();  // 0: automatic (msda_api.hip)
-int option_deterministic();  // 1: bitwise reproducible grad_value everywhere (level-major place pass always, no single-launch kernel)
 int option_gather_win();   // records per gather window (0: automatic)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -254,14 +254,20 @@ def level_cells_of(level_shapes, num_levels: Optional[int] = None, num_pixels: O
             raise ValueError("`level_shapes` should be host numbers (a device tensor would need a synchronisation); "
                              "pass e.g. `spatial_shapes_list`")
         level_shapes = level_shapes.tolist()
-    level_shapes = [(int(h), int(w)) for h, w in level_shapes]
+    # (plain loops: torch.compile traces this function with the list as a constant)
+    levels, pixels, cells = 0, 0, 0
+    for h, w in level_shapes:
+        h, w = int(h), int(w)
+        levels += 1
+        pixels += h * w
+        cells = max(cells, (h + 1) * (w + 1))
     # what can be checked without reading `img_shapes` back from the device: the level count and the pixel total of
     # the call it is supposed to describe (a list describing another pyramid would give NaN grad_value rows)
-    if num_levels is not None and len(level_shapes) != num_levels:
-        raise ValueError(f"`level_shapes` has {len(level_shapes)} levels, `img_shapes` {num_levels}")
-    if num_pixels is not None and sum(h * w for h, w in level_shapes) != num_pixels:
-        raise ValueError(f"`level_shapes` describes {sum(h * w for h, w in level_shapes)} pixels, `img` has {num_pixels}")
-    return max(((h + 1) * (w + 1) for h, w in level_shapes), default=0)
+    if num_levels is not None and levels != num_levels:
+        raise ValueError(f"`level_shapes` has {levels} levels, `img_shapes` {num_levels}")
+    if num_pixels is not None and pixels != num_pixels:
+        raise ValueError(f"`level_shapes` describes {pixels} pixels, `img` has {num_pixels}")
+    return cells
 
 
 def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, padding_mode, align_corners,

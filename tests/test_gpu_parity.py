@@ -1096,12 +1096,50 @@ def test_sorted_pipeline_is_bitwise_reproducible_by_default():
         _lib.set_option("xcd_map", 1)
 
 
-def test_deterministic_option_gives_bitwise_reproducible_grad_value(oracle):
-    """msda_set_option("deterministic", 1): bitwise reproducible EVERYWHERE — problems the single-launch kernel or the
-    plane-major place pass would take (their record order follows LDS atomics) go through the level-major place pass
-    too.  Across repeated calls, with other work interleaved on the device, and against a run under a different
-    workgroup -> plane mapping.  Checked on a shape with long cell lists (a 1 x 1 level takes a quarter of all samples)
-    and on a c2-sized problem; the result still matches the oracle."""
+@pytest.mark.parametrize("case", ["long_lists", "c4", "many_points"])
+def test_single_launch_kernel_is_bitwise_reproducible_by_default(case):
+    """Round 4: the single-launch grad_value kernel places its LDS records in turns too (msda_value_small.hpp), so
+    the small problems are bitwise reproducible with no option either: repeated calls, other work in flight, another
+    workgroup -> plane mapping, 1 / 2 / 4 workgroups per (plane, level) each against itself."""
+    from msda_triton_amd import _lib, synth
+    ops = _ops()
+    if case == "c4":
+        wl = synth.WORKLOADS["c4_gdino_dec"]
+        d = synth.make_inputs_torch(wl, DEV, seed=3)
+        args, pm, ac = (d["grad_out"], d["value"], d["shapes"], d["loc"], d["attn"]), wl.padding_mode, wl.align_corners
+    else:
+        rng = np.random.default_rng(516)
+        if case == "long_lists":   # a 1 x 1 level takes a quarter of all samples; more than four samples per thread
+            c = rand_case(rng, 2, 700, 4, 32, [(9, 7), (4, 4), (1, 1)], 8, lo=-0.2, hi=1.2)
+        else:                      # P does not divide the workgroup: whole waves have nothing to place
+            c = rand_case(rng, 1, 90, 2, 16, [(6, 5), (3, 3)], 24, lo=-0.2, hi=1.2)
+        args, pm, ac = tuple(torch.from_numpy(c[k]).to(DEV) for k in ("grad_out", "value", "shapes", "loc", "attn")), "zeros", False
+    try:
+        _lib.set_option("value_path", 3)
+        for ns in (0, 1, 2, 4):
+            _lib.set_option("small_ns", ns)
+            runs = []
+            for k in range(4):
+                if k == 2:
+                    _lib.set_option("xcd_map", 0)
+                    noise = torch.randn(1 << 22, device=DEV).sin_()  # noqa: F841
+                runs.append(ops.msda_hip_bwd(*args, pm, ac)[0])
+                torch.cuda.synchronize()
+                _lib.set_option("xcd_map", 1)
+            for r in runs[1:]:
+                assert torch.equal(r, runs[0]), (case, ns)
+    finally:
+        _lib.set_option("small_ns", 0)
+        _lib.set_option("value_path", 0)
+        _lib.set_option("xcd_map", 1)
+
+
+def test_grad_value_is_bitwise_reproducible_everywhere(oracle):
+    """No option needed (round 4): a problem of the single-launch kernel with long cell lists (a
+    1 x 1 level takes a quarter of all samples), a c2-sized problem of the sorted pipeline, and a decoder call over an
+    image-sized pyramid (more cells than samples: the shape the plane-major place pass used to take).  Across repeated
+    calls, with other work interleaved on the device, and against a run under a different workgroup -> plane mapping;
+    the result still matches the oracle.  msda_set_option("deterministic", 1) is still accepted (and changes nothing)."""
     from msda_triton_amd import _lib, synth
     ops = _ops()
     rng = np.random.default_rng(515)
@@ -1110,21 +1148,31 @@ def test_deterministic_option_gives_bitwise_reproducible_grad_value(oracle):
     wl = synth.WORKLOADS["c2_q5k"]
     d = synth.make_inputs_torch(wl, DEV, seed=8)
     big = (d["grad_out"], d["value"], d["shapes"], d["loc"], d["attn"])
+    cs = rand_case(rng, 2, 300, 2, 32, [(100, 134), (50, 67), (25, 34), (13, 17)], 4, lo=-0.05, hi=1.05)
+    sparse = tuple(torch.from_numpy(cs[k]).to(DEV) for k in ("grad_out", "value", "shapes", "loc", "attn"))
+    lib = _lib.load()
+    assert lib.msda_bwd_workspace_bytes(2, 17821, 2, 32, 300, 4, 4, 4) > 0  # (the sorted pipeline)
     try:
-        _lib.set_option("deterministic", 1)
-        for args, pm, ac in ((small, "zeros", False), (small, "border", True), (big, wl.padding_mode, wl.align_corners)):
-            runs = []
-            for k in range(4):
-                if k == 2:  # different scheduling: other kernels in flight, plain block mapping
-                    _lib.set_option("xcd_map", 0)
-                    noise = torch.randn(1 << 22, device=DEV).sin_()
-                runs.append(ops.msda_hip_bwd(*args, pm, ac))
-                torch.cuda.synchronize()
-                _lib.set_option("xcd_map", 1)
-            for r in runs[1:]:
-                assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
-        gv = runs and ops.msda_hip_bwd(*small, "zeros", False)[0]
+        for det in (0, 1):
+            _lib.set_option("deterministic", det)
+            assert lib.msda_get_option(b"deterministic") == det
+            for args, pm, ac in ((small, "zeros", False), (small, "border", True), (big, wl.padding_mode, wl.align_corners),
+                                 (sparse, "zeros", False)):
+                runs = []
+                for k in range(4):
+                    if k == 2:  # different scheduling: other kernels in flight, plain block mapping
+                        _lib.set_option("xcd_map", 0)
+                        noise = torch.randn(1 << 22, device=DEV).sin_()  # noqa: F841
+                    runs.append(ops.msda_hip_bwd(*args, pm, ac))
+                    torch.cuda.synchronize()
+                    _lib.set_option("xcd_map", 1)
+                for r in runs[1:]:
+                    assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+        gv = ops.msda_hip_bwd(*small, "zeros", False)[0]
         r_gv, _, _ = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
+        np.testing.assert_allclose(gv.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
+        gv = ops.msda_hip_bwd(*sparse, "zeros", False)[0]
+        r_gv, _, _ = oracle.backward(cs["grad_out"], cs["value"], cs["shapes"], cs["loc"], cs["attn"], "zeros", False)
         np.testing.assert_allclose(gv.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
     finally:
         _lib.set_option("deterministic", 0)

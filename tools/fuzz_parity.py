@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Long differential fuzz of the HIP operator against the C oracle (fp64 cases at 1e-8, fp32 at the test suite's
 tolerances): wider than tests/test_gpu_parity.py::test_random_shapes_against_oracle — more queries (cells that span
-many gather windows and workgroups), 1 x N levels, hot spots, far out-of-range coordinates, both grad_value paths, the
-deterministic option, query rounds.  Usage: fuzz_parity.py [seconds] [first_seed]; prints one line per failure and a
+many gather windows and workgroups), 1 x N levels, hot spots, far out-of-range coordinates, both grad_value paths,
+both place passes, query rounds.  Usage: fuzz_parity.py [seconds] [first_seed]; prints one line per failure and a
 summary; exit status 1 if anything failed."""
 import json
 import os
@@ -51,7 +51,7 @@ while time.time() - t0 < budget:
         m = rng.uniform(size=c["loc"].shape[:-1]) < 0.8
         c["loc"][m] = (hot + rng.normal(0, 0.002, size=(int(m.sum()), 2))).astype(c["loc"].dtype)
     td = torch.float64 if f64 else torch.float32
-    opts = {"value_path": int(rng.choice([0, 2, 3])), "deterministic": int(rng.integers(0, 2)),
+    opts = {"value_path": int(rng.choice([0, 2, 3])), "place_path": int(rng.choice([0, 0, 1])),
             "q_round": int(rng.choice([0, 0, 0, max(1, Q // 3)])), "small_ns": int(rng.choice([0, 0, 1, 2, 3, 5]))}
     desc = dict(seed=seed, B=B, Q=Q, H=H, D=D, levels=levels, P=P, range=(lo, hi), pm=pm, ac=ac, f64=f64, **opts)
     try:
