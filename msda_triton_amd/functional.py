@@ -43,6 +43,11 @@ def dtypes_supported(img_dtype: torch.dtype, compute_dtype: torch.dtype) -> bool
     return compute_dtype == torch.float32 and img_dtype in _MIXED_SUFFIX
 
 
+# (img, sampling_points, attention_weights) dtypes the kernels take, for the fast path's single lookup
+_DTYPE_TRIPLES = frozenset([(t, t, t) for t in _SUFFIX] + [(t, torch.float32, torch.float32) for t in _MIXED_SUFFIX])
+_SHAPE_DTYPES = frozenset((torch.int64, torch.int32, torch.int16, torch.int8, torch.uint8))
+
+
 def _suffix_for(img_dtype: torch.dtype, compute_dtype: torch.dtype) -> str:
     if not dtypes_supported(img_dtype, compute_dtype):
         raise ValueError(
@@ -397,6 +402,20 @@ def hip_multiscale_deformable_attention(
     """GPU path.  Same contract as the reference's ``triton_multiscale_deformable_attention``
     (frontend.py:71-105): ``ValueError`` on unsupported dtype or non-GPU inputs.  ``level_shapes`` (an addition): the
     pyramid's (h, w) pairs as host numbers, see :func:`level_cells_of`."""
+    # Fast path (the small decoder / README shapes spend more host time than device time per call): every check below
+    # as one conjunction; whatever fails it — or needs the Python Function — takes the checks that carry the messages.
+    dev, dt, shp, ish = img.device, sampling_points.dtype, sampling_points.shape, img.shape
+    if dev.type == "cuda" and not torch.compiler.is_compiling() and (ext := _ext.load()) is not None and \
+            KernelTimer.active is None and \
+            (img.dtype, dt, attention_weights.dtype) in _DTYPE_TRIPLES and padding_mode in _lib.PADDING_MODES and \
+            img_shapes.device == dev and sampling_points.device == dev and attention_weights.device == dev and \
+            len(ish) == 4 and len(shp) == 6 and shp[0] == ish[0] and shp[2] == ish[2] and shp[5] == 2 and \
+            attention_weights.shape == shp[:5] and img_shapes.shape == (shp[3], 2) and \
+            img_shapes.dtype in _SHAPE_DTYPES and not _autocast_on():
+        if img.requires_grad and torch.is_grad_enabled():
+            check_backward_supported(img, sampling_points)
+        return ext.msda(img, img_shapes, sampling_points, attention_weights, _lib.PADDING_MODES[padding_mode],
+                        bool(align_corners), level_cells_of(level_shapes, shp[3], ish[1]) if level_shapes is not None else 0)
     for name, t in (("img", img), ("sampling_points", sampling_points), ("attention_weights", attention_weights)):
         if t.dtype not in VALID_DTYPES:
             raise ValueError(f"Dtype of `{name}` should be in {list(VALID_DTYPES)}, but got {t.dtype}.")
