@@ -157,10 +157,12 @@ MSDA_DECLARE_EX(f32_vf16)
 #undef MSDA_DECLARE_EX
 /* elem_size: of everything but `value`; value_elem_size: of `value` / `grad_value` (0: the same — 2 next to elem_size 4
  * for the mixed-storage entry points) */
-/* flags: MSDA_WS_RECORDS_IN_GRADS — the call will ALSO ask for grad_loc / grad_attn (both non-NULL, 16-byte aligned):
- * the sorted sample records are dead once grad_value is done and those two buffers are written last, so the records of
- * as many (batch, head) planes as fit are kept in them and the workspace shrinks (c2 @ 10k: 180 -> 119 MB).  A call
- * with such a workspace but without grad_loc / grad_attn is rejected (MSDA_ERR_BAD_ARG); a larger workspace is fine. */
+/* flags: MSDA_WS_RECORDS_IN_GRADS — the call will ALSO ask for grad_loc / grad_attn (all three gradient buffers
+ * non-NULL and 16-byte aligned): the sorted sample records are dead once the gather has run, grad_loc / grad_attn are
+ * written last and grad_value only by the finish kernel behind the gather, so the records of as many (batch, head)
+ * planes as fit are kept in those buffers and the workspace shrinks (c2 @ 10k: 180 -> 98 MB).  A call with such a
+ * workspace but without grad_loc / grad_attn (or misaligned buffers) is rejected (MSDA_ERR_BAD_ARG); a larger workspace
+ * is fine. */
 #define MSDA_WS_RECORDS_IN_GRADS 1
 MSDA_API int64_t msda_bwd_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
                                              int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells,

@@ -161,7 +161,7 @@ extern "C" int msda_abi_version(void) { return MSDA_ABI_VERSION; }
 extern "C" void msda_hint_level_cells(int64_t max_level_cells) { msda::set_thread_level_cells(max_level_cells); }
 
 // the layout lives in a device header (msda_value_sorted.hpp); msda_f32.hip exposes its size formula
-extern "C" int64_t msda_bwd_workspace_bytes_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int);
+extern "C" int64_t msda_bwd_workspace_bytes_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int);
 
 // room for the x-pair table (rows of exactly 64 bytes of the value storage type; msda_launch.hpp pair_table_bytes)
 static int64_t pair_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int value_elem_size)
@@ -180,7 +180,7 @@ extern "C" int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int
                                             int64_t P, int elem_size)
 {
     if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0) return 0;
-    return pair_bytes(B, I, H, D, elem_size) + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0);
+    return pair_bytes(B, I, H, D, elem_size) + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0, 0);
 }
 
 extern "C" int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
@@ -190,7 +190,7 @@ extern "C" int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t 
     // the derived sampling points + attention weights (3 elements per sample, rounded up to 256 bytes), then
     // the sorted pipeline's own workspace (msda_launch.hpp: fused_mat_bytes)
     const int64_t mat = (B * Q * H * L * P * 3 * (int64_t)elem_size + 255) / 256 * 256;
-    return pair_bytes(B, I, H, D, elem_size) + mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0);
+    return pair_bytes(B, I, H, D, elem_size) + mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0, 0);
 }
 
 // the level-size bound as an argument: it becomes the thread's promise for the duration of the call
@@ -216,7 +216,8 @@ extern "C" int64_t msda_bwd_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, 
     if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0) return 0;
     const msda::LevelCellsScope scope(max_level_cells);
     return pair_bytes(B, I, H, D, value_elem_size > 0 ? value_elem_size : elem_size) +
-           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, (flags & MSDA_WS_RECORDS_IN_GRADS) ? 1 : 0);
+           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, (flags & MSDA_WS_RECORDS_IN_GRADS) ? 1 : 0,
+                                         value_elem_size > 0 ? value_elem_size : elem_size);
 }
 
 extern "C" int64_t msda_bwd_fused_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
@@ -226,7 +227,7 @@ extern "C" int64_t msda_bwd_fused_workspace_bytes_ex(int64_t B, int64_t I, int64
     const msda::LevelCellsScope scope(max_level_cells);
     const int64_t mat = (B * Q * H * L * P * 3 * (int64_t)elem_size + 255) / 256 * 256;
     return pair_bytes(B, I, H, D, value_elem_size > 0 ? value_elem_size : elem_size) + mat +
-           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0);
+           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0, 0);
 }
 
 extern "C" int msda_bwd_supported_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);

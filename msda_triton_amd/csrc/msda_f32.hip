@@ -5,7 +5,8 @@ MSDA_DEFINE_ENTRY_POINTS(f32, float)
 
 // size of the backward workspace (shared by every dtype: the accumulate type decides the record sizes)
 extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_bytes_impl(
-    int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int elem_size, int records_in_grads)
+    int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int elem_size, int records_in_grads,
+    int value_elem_size)
 {
     // problems the single-launch kernel takes need no workspace at all
     const msda::Dims d{B, I, H, D, Q, L, P};
@@ -16,8 +17,8 @@ extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_byte
     // grad_out / grad_value pointers (a slice of a shard's buffers can be misaligned), and a workspace that is too
     // small would be rejected (MSDA_ERR_BAD_ARG)
     const bool rg = records_in_grads != 0 && msda::option_records_in_grads() != 0;
-    const size_t vec = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, true, rg).total;
-    const size_t sca = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, false, rg).total;
+    const size_t vec = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, true, rg, (size_t)value_elem_size).total;
+    const size_t sca = msda::sorted_ws_layout(B, I, H, D, Q, L, P, acc, (size_t)elem_size, false, rg, (size_t)value_elem_size).total;
     return (int64_t)(vec > sca ? vec : sca);
 }
 

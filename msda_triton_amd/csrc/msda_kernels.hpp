@@ -55,8 +55,10 @@ struct Params {
     // ... the records of the first ent_n0 planes live in the caller's grad_loc buffer, those of the next ent_n1 in
     // grad_attn (both are written only after the gather has consumed the records): 0 / 0 unless the caller asked for
     // the sample gradients in the same call and sized the workspace accordingly (MSDA_WS_RECORDS_IN_GRADS)
-    void *ent_alt0, *ent_alt1;
-    int ent_n0, ent_n1;
+    // ... and those of the next ent_n2 in grad_value itself, which only the finish kernel writes (single-round
+    // problems: with several rounds the finish of one round precedes the place pass of the next)
+    void *ent_alt0, *ent_alt1, *ent_alt2;
+    int ent_n0, ent_n1, ent_n2;
     void *ws_scratch;   // [pairs][I][4][D]   acc-typed partial rows: slot k of a pixel = what the cell having it as corner k left
     void *ws_cont;      // [pairs][cont_cap][4][D] acc-typed continuation rows: one set per gather workgroup
     int nc_cap, nblk_cap, win_cap, cont_cap;

@@ -326,7 +326,7 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
 {
     using A = typename Traits<T>::acc;
     const bool vec_ok = value_vec_ok<T>(p);
-    const SortedWsLayout w = sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), sizeof(T), vec_ok, p.ent_alt0 != nullptr);
+    const SortedWsLayout w = sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), sizeof(T), vec_ok, p.ent_alt0 != nullptr, sizeof(TV));
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     p.ws_part = reinterpret_cast<int *>(ws + w.off_part);
     p.ws_blocktot = reinterpret_cast<int *>(ws + w.off_blocktot);
@@ -345,8 +345,9 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
     p.cont_cap = w.cont_cap;
     p.nsplit = w.nsplit;
     p.ent_cap = (int)((int64_t)w.q_round * d.L * d.P);
-    p.ent_n0 = w.ent_n0;  // (0 / 0 unless run_bwd offered the caller's grad_loc / grad_attn buffers: p.ent_alt0 / ent_alt1)
+    p.ent_n0 = w.ent_n0;  // (0 / 0 / 0 unless run_bwd offered the caller's gradient buffers: p.ent_alt0 / ent_alt1 / ent_alt2)
     p.ent_n1 = w.ent_n1;
+    p.ent_n2 = w.ent_n2;
     // cells a count / place workgroup keeps in LDS at a time: what the LDS holds next to the level table and the
     // per-block totals
     {
@@ -631,11 +632,11 @@ template <typename T> inline bool small_path_chosen(const Dims &d)
 // shapes beyond the sorted pipeline's record format (I >= 2^22 pixels per plane, D beyond 32-bit slot offsets) are
 // unsupported for grad_value when they are also too large for the single-launch kernel.
 // would run_value find a route with this workspace?  (the single-launch kernel, or the sorted pipeline with enough room)
-template <typename T> inline bool value_ws_ok(const Params &p, const Dims &d, const void *workspace, int64_t workspace_bytes)
+template <typename T, typename TV = T> inline bool value_ws_ok(const Params &p, const Dims &d, const void *workspace, int64_t workspace_bytes)
 {
     using A = typename Traits<T>::acc;
     const bool fits = sorted_fits<T>(d);
-    const size_t need = fits ? sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), sizeof(T), value_vec_ok<T>(p), p.ent_alt0 != nullptr).total : 0;
+    const size_t need = fits ? sorted_ws_layout(d.B, d.I, d.H, d.D, d.Q, d.L, d.P, sizeof(A), sizeof(T), value_vec_ok<T>(p), p.ent_alt0 != nullptr, sizeof(TV)).total : 0;
     const bool sorted = fits && workspace != nullptr && aligned_to(workspace, 256) && workspace_bytes >= 0 &&
                         (uint64_t)workspace_bytes >= need;
     return sorted || small_path_chosen<T>(d) || (option_value_path() != 2 && small_fits<T>(d));
@@ -647,7 +648,7 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
     using A = typename Traits<T>::acc;
     const int64_t B = d.B, I = d.I, H = d.H, D = d.D, Q = d.Q, L = d.L, P = d.P;
     const bool fits = sorted_fits<T>(d);
-    const size_t need = fits ? sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p), p.ent_alt0 != nullptr).total : 0;
+    const size_t need = fits ? sorted_ws_layout(B, I, H, D, Q, L, P, sizeof(A), sizeof(T), value_vec_ok<T>(p), p.ent_alt0 != nullptr, sizeof(TV)).total : 0;
     const bool sorted = fits && workspace != nullptr && aligned_to(workspace, 256) && (uint64_t)workspace_bytes >= need;
     const bool small_path = small_path_chosen<T>(d) ||
                             (option_value_path() != 2 && !sorted && small_fits<T>(d));
@@ -720,14 +721,16 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     fill_params(p, d, padding_mode, align_corners);
     // Both halves wanted, one after the other: the sorted records are dead once the gather has run and grad_loc /
     // grad_attn are written only by the sample-gradient kernel, so that kernel goes LAST and the records of as many
-    // planes as fit live in those two buffers (three quarters of them in fp32: 61 of 82 MB at c2 @ 10k).  The workspace
-    // layout shrinks accordingly (msda_bwd_workspace_bytes_ex with MSDA_WS_RECORDS_IN_GRADS); a caller that passes the
-    // full size loses nothing.
+    // planes as fit live in those two buffers (three quarters of them in fp32: 61 of 82 MB at c2 @ 10k); the rest go
+    // into grad_value itself, which only the finish kernel writes, behind the gather (single-round problems).  The
+    // workspace layout shrinks accordingly (msda_bwd_workspace_bytes_ex with MSDA_WS_RECORDS_IN_GRADS); a caller that
+    // passes the full size loses nothing.
     const bool records_in_grads = want_sample && want_value && option_records_in_grads() != 0 && option_overlap() != 1 &&
-                                  aligned_to(grad_loc, 16) && aligned_to(grad_attn, 16);
+                                  aligned_to(grad_loc, 16) && aligned_to(grad_attn, 16) && aligned_to(grad_value, 16);
     if (records_in_grads) {
         p.ent_alt0 = grad_loc;
         p.ent_alt1 = grad_attn;
+        p.ent_alt2 = grad_value;
     }
     // The workspace's front may carry the x-pair table for the sample-gradient kernel (64-byte value rows): only when
     // what follows it still covers what grad_value needs.
@@ -735,7 +738,7 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     bool use_pairs = false;
     if (want_sample && pairs_ok<T, TV>(p, d, vec_sample, workspace, workspace_bytes)) {
         const int64_t pb = (int64_t)pair_table_bytes(B, I, H);
-        const bool value_fits = !want_value || value_ws_ok<T>(p, d, static_cast<unsigned char *>(workspace) + pb, workspace_bytes - pb);
+        const bool value_fits = !want_value || value_ws_ok<T, TV>(p, d, static_cast<unsigned char *>(workspace) + pb, workspace_bytes - pb);
         if (value_fits) {
             use_pairs = true;
             p.pairs = workspace;

@@ -138,10 +138,11 @@ public:
         }
         if (want_value) {
             g_img = at::empty_like(img);
-            // all three gradients in one call: the sorted records may use the grad_loc / grad_attn buffers (the library's
+            // all three gradients in one call: the sorted records may use the gradient buffers themselves (the library's
             // own conditions: 16-byte aligned buffers, no forced side-stream fork)
             const bool in_grads = want_sample && reinterpret_cast<uintptr_t>(g_pts.data_ptr()) % 16 == 0 &&
-                                  reinterpret_cast<uintptr_t>(g_att.data_ptr()) % 16 == 0 && msda_get_option("overlap") != 1;
+                                  reinterpret_cast<uintptr_t>(g_att.data_ptr()) % 16 == 0 &&
+                                  reinterpret_cast<uintptr_t>(g_img.data_ptr()) % 16 == 0 && msda_get_option("overlap") != 1;
             ws_bytes = msda_bwd_workspace_bytes_ex(B, I, H, D, Q, L, P, (int)pts.element_size(), (int)img.element_size(),
                                                    level_cells, in_grads ? MSDA_WS_RECORDS_IN_GRADS : 0);
             ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));  // scratch: no initialisation needed

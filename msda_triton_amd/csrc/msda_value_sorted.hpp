@@ -97,13 +97,16 @@ template <> struct alignas(16) Entry<double> {
     __device__ __forceinline__ double dy() const { return ddy; }
 };
 
-// the record array of plane `pair` (uniform): the caller's gradient buffers first, then the workspace
+// the record array of plane `pair` (uniform): the caller's gradient buffers first (grad_loc, grad_attn, grad_value),
+// then the workspace
 template <typename A> __device__ __forceinline__ Entry<A> *plane_entries(const Params &p, int pair)
 {
     if (pair < p.ent_n0) return static_cast<Entry<A> *>(p.ent_alt0) + (size_t)pair * p.ent_cap;
     pair -= p.ent_n0;
     if (pair < p.ent_n1) return static_cast<Entry<A> *>(p.ent_alt1) + (size_t)pair * p.ent_cap;
-    return static_cast<Entry<A> *>(p.ws_entries) + (size_t)(pair - p.ent_n1) * p.ent_cap;
+    pair -= p.ent_n1;
+    if (pair < p.ent_n2) return static_cast<Entry<A> *>(p.ent_alt2) + (size_t)pair * p.ent_cap;
+    return static_cast<Entry<A> *>(p.ws_entries) + (size_t)(pair - p.ent_n2) * p.ent_cap;
 }
 
 __device__ __forceinline__ int plane_cells(const LevelTab &tab, int L)
@@ -122,8 +125,13 @@ __device__ __forceinline__ bool sample_cell(A x, A y, int h, int w, int cstart, 
         px = x * (W - (A)1);
         py = y * (Hh - (A)1);
     } else {
-        px = x * W - (A)0.5;
-        py = y * Hh - (A)0.5;
+        // An EXPLICIT fused multiply-add: every copy of this function — the count pass, the place pass before and
+        // after its turn, the single-launch kernel's two walks — must put a sample into the same cell, and under
+        // -ffp-contract=fast the compiler fuses `x * W - 0.5` in one inlined copy and not in another (a packed multiply
+        // + add before the turn, v_pk_fma behind it): a coordinate within an ulp of a cell boundary then landed in one
+        // cell's list carrying the other cell's word (found by tools/fuzz_parity.py, seed 1000117).
+        px = fma_t(x, W, (A)-0.5);
+        py = fma_t(y, Hh, (A)-0.5);
     }
     A x0, y0;
     if (zeros) {
@@ -860,7 +868,7 @@ __global__ __launch_bounds__(kBlock) void msda_value_finish_kernel(const Params 
 struct SortedWsLayout {
     int nc_cap, nblk_cap, win, win_cap, cont_cap, nsplit;
     int q_round, rounds;  // queries per round and rounds over the queries (1: everything at once)
-    int ent_n0, ent_n1;   // planes whose records live in the caller's grad_loc / grad_attn buffer
+    int ent_n0, ent_n1, ent_n2;   // planes whose records live in the caller's grad_loc / grad_attn / grad_value buffer
     size_t off_part, off_blocktot, off_off, off_total, off_meta, off_entries, off_scratch, off_cont, off_accum, total;
 };
 
@@ -882,10 +890,12 @@ inline int gather_group_lanes(int64_t D, size_t elem_bytes, bool vec)
 // `vec`: size for the 16-byte vector path (aligned grad_out / grad_value, D a multiple of 16 bytes of elements);
 // the scalar path has fewer windows per workgroup and needs more continuation rows (msda_bwd_workspace_bytes reports
 // the larger of the two layouts)
-// records_in_grads: the caller's grad_loc / grad_attn buffers (of elem_bytes elements) hold the records of as many
-// planes as fit them (MSDA_WS_RECORDS_IN_GRADS); ent_n0 / ent_n1 say how many
+// records_in_grads: the caller's grad_loc / grad_attn buffers (of elem_bytes elements) and — single-round problems —
+// its grad_value buffer (of value_elem_bytes elements; 0: elem_bytes) hold the records of as many planes as fit them
+// (MSDA_WS_RECORDS_IN_GRADS); ent_n0 / ent_n1 / ent_n2 say how many
 inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P,
-                                       size_t acc_bytes, size_t elem_bytes, bool vec = true, bool records_in_grads = false)
+                                       size_t acc_bytes, size_t elem_bytes, bool vec = true, bool records_in_grads = false,
+                                       size_t value_elem_bytes = 0)
 {
     SortedWsLayout w;
     const size_t pairs = (size_t)(B * H);
@@ -949,17 +959,20 @@ inline SortedWsLayout sorted_ws_layout(int64_t B, int64_t I, int64_t H, int64_t 
     w.off_off = o;      o = align_up(o + pairs * ((size_t)w.nc_cap + 1) * 4, 256);
     w.off_total = o;    o = align_up(o + pairs * 4, 256);
     w.off_meta = o;     o = align_up(o + 256, 256);
-    w.ent_n0 = w.ent_n1 = 0;
+    w.ent_n0 = w.ent_n1 = w.ent_n2 = 0;
     if (records_in_grads && samples > 0) {
         const size_t plane_bytes = samples * entry_bytes;
         const size_t loc_bytes = (size_t)(B * Q * H * L * P) * 2 * elem_bytes, attn_bytes = loc_bytes / 2;
-        size_t n0 = loc_bytes / plane_bytes, n1 = attn_bytes / plane_bytes;
+        const size_t value_bytes = (size_t)(B * I * H * D) * (value_elem_bytes ? value_elem_bytes : elem_bytes);
+        size_t n0 = loc_bytes / plane_bytes, n1 = attn_bytes / plane_bytes, n2 = w.rounds == 1 ? value_bytes / plane_bytes : 0;
         if (n0 > pairs) n0 = pairs;
         if (n1 > pairs - n0) n1 = pairs - n0;
+        if (n2 > pairs - n0 - n1) n2 = pairs - n0 - n1;
         w.ent_n0 = (int)n0;
         w.ent_n1 = (int)n1;
+        w.ent_n2 = (int)n2;
     }
-    w.off_entries = o;  o = align_up(o + (pairs - w.ent_n0 - w.ent_n1) * samples * entry_bytes, 256);
+    w.off_entries = o;  o = align_up(o + (pairs - w.ent_n0 - w.ent_n1 - w.ent_n2) * samples * entry_bytes, 256);
     w.off_scratch = o;  o = align_up(o + pairs * (size_t)I * 4 * (size_t)D * acc_bytes, 256);
     w.off_cont = o;     o = align_up(o + pairs * (size_t)w.cont_cap * 4 * (size_t)D * acc_bytes, 256);
     w.off_accum = o;    if (w.rounds > 1) o = align_up(o + pairs * (size_t)I * (size_t)D * acc_bytes, 256);

@@ -325,11 +325,12 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
         if not want_value:  # only the x-pair table, if the shape takes one
             ws, ws_bytes = _fwd_workspace(lib, img)
         else:  # scratch: the inverted index (grad_value), in front of it the x-pair table
-            # all three gradients in ONE call: the sorted records may use the grad_loc / grad_attn buffers (smaller
+            # all three gradients in ONE call: the sorted records may use the gradient buffers themselves (smaller
             # workspace); the per-kernel timer issues the halves as two calls and needs the full size
             # (the library's own conditions: 16-byte aligned gradient buffers, no forced side-stream fork)
             flags = _lib.WS_RECORDS_IN_GRADS if (want_sample and KernelTimer.active is None
                                                  and g_pts.data_ptr() % 16 == 0 and g_att.data_ptr() % 16 == 0
+                                                 and g_img.data_ptr() % 16 == 0
                                                  and _lib.get_option("overlap") != 1) else 0
             key = (B, I, H, D, Q, L, P, sampling_points.element_size(), img.element_size(), _lib.OPTION_EPOCH, level_cells,
                    flags)

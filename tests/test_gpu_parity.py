@@ -692,6 +692,41 @@ def test_grad_value_without_workspace(oracle):
     torch.cuda.synchronize()
     _, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
     np.testing.assert_allclose(ga.cpu().numpy(), r_ga, **BWD_TOL[torch.float32])
+    # a pyramid large enough for the third home of the records: plane 0's in grad_loc, plane 1's in grad_value itself
+    # (written only by the finish kernel, behind the gather) — no record region left in the workspace
+    c = rand_case(np.random.default_rng(34), 1, 2500, 2, 32, [(40, 40), (20, 20)], 2, lo=-0.05, hi=1.05)
+    v, l, a, g = (torch.from_numpy(c[k]).to(DEV) for k in ("value", "loc", "attn", "grad_out"))
+    s = torch.from_numpy(c["shapes"]).to(DEV)
+    B, I, H, D = v.shape
+    _, Q, _, L, P, _ = l.shape
+    gvb = torch.empty(v.numel() + 4, device=DEV)
+    gv, gl, ga = gvb[:v.numel()].view_as(v), torch.empty_like(l), torch.empty_like(a)
+    args = (g.data_ptr(), v.data_ptr(), s.data_ptr(), l.data_ptr(), a.data_ptr())
+    dims = (B, I, H, D, Q, L, P, 1, 0)
+    full = lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, 4)
+    lean = lib.msda_bwd_workspace_bytes_ex(B, I, H, D, Q, L, P, 4, 4, 0, _lib.WS_RECORDS_IN_GRADS)
+    assert 0 < lean <= full - 2 * Q * L * P * 16  # both planes' records are gone from it
+    lean_ws = torch.empty(lean, dtype=torch.uint8, device=DEV)
+    assert lib.msda_bwd_f32(*args, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), *dims, lean_ws.data_ptr(), lean, st) == 0
+    torch.cuda.synchronize()
+    r_gv, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
+    np.testing.assert_allclose(gv.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
+    np.testing.assert_allclose(ga.cpu().numpy(), r_ga, **BWD_TOL[torch.float32])
+    full_ws = torch.empty(full, dtype=torch.uint8, device=DEV)
+    gv2 = torch.empty_like(v)
+    assert lib.msda_bwd_f32(*args, gv2.data_ptr(), None, None, *dims, full_ws.data_ptr(), full, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(gv2, gv)  # same records, same order, wherever they were kept
+    # a grad_value buffer that is not 16-byte aligned holds no records (the call keeps them in the workspace: either the
+    # lean size happens to cover that layout, or the call is rejected before anything is launched); the full size always works
+    gv_off = gvb[1:1 + v.numel()].view_as(v)
+    for ws_t, nbytes, may_reject in ((lean_ws, lean, True), (full_ws, full, False)):
+        gv_off.fill_(float("nan"))
+        rc = lib.msda_bwd_f32(*args, gv_off.data_ptr(), gl.data_ptr(), ga.data_ptr(), *dims, ws_t.data_ptr(), nbytes, st)
+        assert rc == 0 or (may_reject and rc == -1)
+        torch.cuda.synchronize()
+        if rc == 0:
+            np.testing.assert_allclose(gv_off.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
 
 
 def test_c_abi_rejects_bad_arguments_without_launching():
@@ -1132,6 +1167,47 @@ def test_single_launch_kernel_is_bitwise_reproducible_by_default(case):
         _lib.set_option("small_ns", 0)
         _lib.set_option("value_path", 0)
         _lib.set_option("xcd_map", 1)
+
+
+def _boundary_coordinates(n):
+    """float32 coordinates next to the cell boundaries of an n-pixel axis for which x * n - 0.5 lands in different
+    cells when it is computed with one rounding (fused multiply-add) and with two"""
+    x = ((np.arange(n) + 0.5) / n).astype(np.float32)
+    for _ in range(4):
+        x = np.nextafter(x, np.float32(-2))
+    out = []
+    for _ in range(9):
+        p = x.astype(np.float64) * n
+        two = (p.astype(np.float32) - np.float32(0.5)).astype(np.float32)
+        one = (p - 0.5).astype(np.float32)
+        out.extend(x[np.floor(two) != np.floor(one)].tolist())
+        x = np.nextafter(x, np.float32(2))
+    return np.array(out, dtype=np.float32)
+
+
+@pytest.mark.parametrize("value_path", [2, 3], ids=["sorted_gather", "single_launch"])
+@pytest.mark.parametrize("pm", ["zeros", "border"])
+def test_samples_within_an_ulp_of_a_cell_boundary(oracle, value_path, pm):
+    """Found by tools/fuzz_parity.py (seed 1000117, round 4): the count pass, the place pass (twice: before and after its
+    turn) and the single-launch kernel's walks each inline the sample -> cell arithmetic, and the compiler fused
+    `x * W - 0.5` in one copy and not in the other; a coordinate within an ulp of a cell boundary was then placed in one
+    cell's list carrying the other cell's word.  Here most samples sit on exactly such coordinates (align_corners=False:
+    the expression in question)."""
+    from msda_triton_amd import _lib
+    levels = [(25, 25), (40, 100)]
+    assert len(_boundary_coordinates(25)) >= 3 and len(_boundary_coordinates(100)) >= 3
+    rng = np.random.default_rng(1000117)
+    c = rand_case(rng, 2, 900 if value_path == 3 else 2500, 2, 32, levels, 4, lo=-0.02, hi=1.02)
+    for l, (h, w) in enumerate(levels):
+        for axis, n in ((0, w), (1, h)):
+            adv = _boundary_coordinates(n)
+            m = rng.uniform(size=c["loc"].shape[:3] + (c["loc"].shape[4],)) < 0.7
+            c["loc"][:, :, :, l, :, axis][m] = rng.choice(adv, size=int(m.sum()))
+    try:
+        _lib.set_option("value_path", value_path)
+        check_against_oracle(oracle, c, pm, False, FWD_TOL[torch.float32], BWD_TOL[torch.float32])
+    finally:
+        _lib.set_option("value_path", 0)
 
 
 def test_grad_value_is_bitwise_reproducible_everywhere(oracle):

@@ -3,7 +3,7 @@
 tolerances): wider than tests/test_gpu_parity.py::test_random_shapes_against_oracle — more queries (cells that span
 many gather windows and workgroups), 1 x N levels, hot spots, far out-of-range coordinates, both grad_value paths,
 both place passes, query rounds.  Usage: fuzz_parity.py [seconds] [first_seed]; prints one line per failure and a
-summary; exit status 1 if anything failed."""
+summary; exit status 1 if anything failed.  fuzz_parity.py --repro SEED [TIMES] [option=value ...] repeats one case."""
 import json
 import os
 import sys
@@ -19,14 +19,9 @@ import test_gpu_parity as tp
 from msda_triton_amd import _lib
 from oracle import msda_oracle
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-msda_oracle.build()
-t0 = time.time()
-n = fails = 0
-seen = {}
-seed = seed0
-while time.time() - t0 < budget:
+
+def make_case(seed):
+    """-> (inputs, padding mode, align_corners, torch dtype, library options, description) of fuzz case `seed`"""
     rng = np.random.default_rng(77000 + seed)
     kind = seed % 6
     B, H = int(rng.integers(1, 4)), int(rng.integers(1, 5))
@@ -54,18 +49,55 @@ while time.time() - t0 < budget:
     opts = {"value_path": int(rng.choice([0, 2, 3])), "place_path": int(rng.choice([0, 0, 1])),
             "q_round": int(rng.choice([0, 0, 0, max(1, Q // 3)])), "small_ns": int(rng.choice([0, 0, 1, 2, 3, 5]))}
     desc = dict(seed=seed, B=B, Q=Q, H=H, D=D, levels=levels, P=P, range=(lo, hi), pm=pm, ac=ac, f64=f64, **opts)
+    return c, pm, ac, td, opts, desc, kind
+
+
+def run_case(c, pm, ac, td, opts):
     try:
         for k, v in opts.items():
             _lib.set_option(k, v)
         tp.check_against_oracle(msda_oracle, c, pm, ac, tp.FWD_TOL[td], tp.BWD_TOL[td])
+    finally:
+        for k in opts:
+            _lib.set_option(k, 0)
+
+
+msda_oracle.build()
+if len(sys.argv) > 1 and sys.argv[1] == "--repro":  # fuzz_parity.py --repro SEED [TIMES] [k=v ...]: one case, repeated
+    seed, times = int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    c, pm, ac, td, opts, desc, _ = make_case(seed)
+    extra = {}
+    for kv in sys.argv[4:]:
+        k, v = kv.split("=")
+        extra[k] = int(v)
+    opts.update({k: v for k, v in extra.items() if k in opts})
+    pre = {k: v for k, v in extra.items() if k not in opts}
+    for k, v in pre.items():
+        _lib.set_option(k, v)
+    bad = 0
+    for i in range(times):
+        try:
+            run_case(c, pm, ac, td, opts)
+        except AssertionError as e:
+            bad += 1
+            print("FAIL run", i, str(e).strip().splitlines()[0:5], flush=True)
+    print(f"repro {json.dumps(desc)} with {opts} {pre}: {bad} of {times} runs failed")
+    sys.exit(1 if bad else 0)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+t0 = time.time()
+n = fails = 0
+seen = {}
+seed = seed0
+while time.time() - t0 < budget:
+    c, pm, ac, td, opts, desc, kind = make_case(seed)
+    try:
+        run_case(c, pm, ac, td, opts)
     except Exception as e:  # noqa: BLE001
         fails += 1
         print("FAIL", json.dumps(desc), "::", str(e).strip().splitlines()[0:6], flush=True)
         if not isinstance(e, AssertionError):
             traceback.print_exc()
-    finally:
-        for k in opts:
-            _lib.set_option(k, 0)
     n += 1
     seen[kind] = seen.get(kind, 0) + 1
     seed += 1
