@@ -314,7 +314,7 @@ extern "C" int msda_set_option(const char *key, int value)
         return 0;
     }
     if (key && strcmp(key, "place_path") == 0) {
-        msda::g_place_path.store(value == 1 || value == 2 ? value : 0, std::memory_order_relaxed);
+        msda::g_place_path.store(value >= 1 && value <= 3 ? value : 0, std::memory_order_relaxed);
         return 0;
     }
     if (key && strcmp(key, "pairs") == 0) {

@@ -385,7 +385,24 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
     // and one rule — grad_value is bitwise reproducible — is worth more than 3 % on that shape.  place_path = 1 keeps
     // the plane-major pass reachable for measurements.
     const bool place_lm = d.P >= 1 && d.P <= kPlaceBlock && option_place_path() != 1;
-    const int place_cells = place_cell_cap(w.nc_cap, (size_t)kMaxDynLds);
+    // ... with 256-thread workgroups when one round of them covers a slice's queries (decoder-sized calls: few samples
+    // per (level, slice)): the waves' turns are a chain of 4 hand-overs instead of 16, and more workgroups are in flight
+    const int64_t q_slice = (w.q_round + p.nsplit - 1) / p.nsplit;
+    const bool place_small = place_lm && d.P <= kPlaceBlockSmall &&
+                             (option_place_path() == 3 || (option_place_path() == 0 && q_slice <= 6 * (kPlaceBlockSmall / d.P)));
+    // Cells of its LDS table: the host knows only the plane's bound (2 I + 2 L) or the caller's promise about the largest
+    // level; a table for that can fill the CU's LDS (c3: 142 KB, one workgroup per CU) although the largest level needs
+    // 40 % of it.  The kernel walks a level larger than its table in several trips, so the table is capped at what lets
+    // TWO workgroups share a CU: c3 66.3 -> 48.6 us, the 800 x 1066 decoder pyramid 29.0 -> 20.7, c5 unchanged (same-box
+    // A/B, tools/ab_dbg.sh).
+    int place_cells;
+    {
+        int64_t bound = w.nc_cap;
+        const int64_t hint = option_level_cells();
+        if (hint > 0 && hint < bound) bound = hint;
+        place_cells = place_cell_cap(bound, (size_t)kMaxDynLds);
+        if (place_cells > kPlaceCellsTwoPerCu) place_cells = kPlaceCellsTwoPerCu;
+    }
     dim3 gplace;
     int g3_place = 0;
     if (place_lm) {
@@ -394,8 +411,9 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
             return MSDA_ERR_TOO_LARGE;
         }
         g3_place = p.grid3d;
-        static std::atomic<uint64_t> big_lds_lm{0};
+        static std::atomic<uint64_t> big_lds_lm{0}, big_lds_lm_small{0};
         allow_big_lds(msda_cell_place_lm_kernel<T, kPlaceBlock>, big_lds_lm);
+        allow_big_lds(msda_cell_place_lm_kernel<T, kPlaceBlockSmall>, big_lds_lm_small);
     }
     for (int r = 0; r < w.rounds; ++r) {  // one round unless Q is so large that a plane's grad_out rows leave L2
         p.q_begin = r * w.q_round;
@@ -416,7 +434,10 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
         if (place_lm) {
             p.grid3d = g3_place;
             p.cell_cap = place_cells;
-            hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, kPlaceBlock>), gplace, dim3(kPlaceBlock), (size_t)place_cells * 4, stream, p);
+            if (place_small)
+                hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, kPlaceBlockSmall>), gplace, dim3(kPlaceBlockSmall), (size_t)place_cells * 4, stream, p);
+            else
+                hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, kPlaceBlock>), gplace, dim3(kPlaceBlock), (size_t)place_cells * 4, stream, p);
         } else {
             hipLaunchKernelGGL((msda_cell_pass_kernel<T, true>), gcell, dim3(kCellBlock), cell_lds, stream, p);
         }

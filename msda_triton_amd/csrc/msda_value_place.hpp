@@ -21,6 +21,8 @@
 namespace msda {
 
 constexpr int kPlaceBlock = 1024;  // threads per workgroup (two per CU at 64 VGPRs; 512 x 3 per CU: 60 us against 44.5 at c2 @ 10k)
+constexpr int kPlaceBlockSmall = 256;  // ... for decoder-sized calls (msda_launch.hpp)
+constexpr int kPlaceCellsTwoPerCu = 19456;  // LDS table cells (76 KB) that still let two workgroups share a CU's 160 KB
 
 // REPRODUCIBLE ORDER: the order inside a cell's list must not depend on when LDS atomics retire (the gather sums in
 // list order).  The workgroup's waves take their cursor atomics in TURNS — wave w of round r goes when the turn counter
