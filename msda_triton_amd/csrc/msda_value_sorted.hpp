@@ -445,8 +445,12 @@ template <int N> __device__ __forceinline__ void lds_read_u32s(const uint32_t *s
 constexpr uint32_t kSegStart = 1u;  // first record of a segment (a new cell, or the window's first record)
 constexpr uint32_t kSegCarry = 2u;  // ... and the cell is the right-hand x-neighbour of the previous record's cell
 
+// Occupancy: four workgroups per CU (<= 128 VGPRs, <= 40 KB of LDS).  The compiler left the 16-bit variants at 136
+// VGPRs; asked for four waves per SIMD, 4-lane groups (D = 32 in bf16 / fp16) take 118 without a spill — c3's
+// grad_value group 175.5 -> 171.5 us, same-box A/B — while 8-lane groups and wider spill (c5: no gain), so those keep
+// the compiler's choice.
 template <typename T, int VEC, int G, int GB>
-__global__ __launch_bounds__(GB) void msda_value_gather_kernel(const Params p)
+__global__ __launch_bounds__(GB, (VEC == 8 && G > 4) ? 1 : 4) void msda_value_gather_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
@@ -473,8 +477,9 @@ __global__ __launch_bounds__(GB) void msda_value_gather_kernel(const Params p)
     __shared__ __attribute__((aligned(32))) uint32_t s_flag[kGatherItemBlock];  // kSegStart | kSegCarry
     __shared__ uint32_t s_cellw[kGatherItemBlock];  // cell word of the record
     __shared__ __attribute__((aligned(32))) A s_rows[kGatherItemBlock * 4 * VEC];  // [unit][corner][G * VEC]: parked continuation rows
-    __shared__ int s_cont[NU];   // the unit's first segment continues the previous window's cell
-    __shared__ int s_pure[NU];   // ... and is the unit's only segment
+    __shared__ unsigned char s_cont[NU];   // the unit's first segment continues the previous window's cell
+    __shared__ unsigned char s_pure[NU];   // ... and is the unit's only segment (bytes: with 4-lane groups the kernel's
+                                           // LDS is 40 KB, and four workgroups must fit a CU's 160 KB)
 
     const Entry<A> *entries = plane_entries<A>(p, pair);
     const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
