@@ -247,10 +247,11 @@ MSDA_API const char *msda_last_error(void);
  *   "value_path" 0 (default): grad_value by the single-launch LDS kernel when a (plane, level) fits one workgroup
  *                   (small problems; no workspace needed), else by the sorted gather in the caller's workspace
  *                2: the sorted gather always   3: the single-launch kernel whenever it fits
- *   "overlap"    -1 (default): grad_loc/grad_attn run on a forked side stream next to grad_value where that was
- *                   measured to pay (next to the sorted pipeline from 4M samples when rows have >= 128 bytes; never
- *                   next to the single-launch kernel): the fork/join itself costs ~14 us of host time and ~19 us of
- *                   latency;  0: never;  1: always
+ *   "overlap"    -1 (default) / 0: the backward's kernels run one after the other on the caller's stream (since ABI 9:
+ *                   with the level-major place pass a fork no longer pays at any measured size, and the records kept in
+ *                   the gradient buffers want the sample-gradient kernel last);  1: grad_loc / grad_attn run on a forked
+ *                   side stream next to grad_value (fork / join with events inside the call, graph-capturable; costs
+ *                   ~14 us of host time and ~19 us of latency)
  *   "deterministic" accepted and stored, without effect since ABI 9: grad_value is bitwise reproducible ALWAYS (for
  *                   P <= 1024 points per level) — the place pass of the sorted pipeline and the single-launch kernel of
  *                   the small problems both let their waves take the list-cursor atomics in turns, so a cell's records
