@@ -326,3 +326,30 @@ def test_backward_support_query_and_forward_time_rejection():
     with pytest.raises(ValueError, match="grad_value is not available"):
         check_backward_supported(img, pts)
     check_backward_supported(torch.empty(4, 5440, 8, 32, device="meta"), torch.empty(4, 10000, 8, 4, 4, 2, device="meta"))
+
+
+def test_workspace_size_queries_are_consistent():
+    """Host arithmetic only (no GPU): the lean backward workspace (MSDA_WS_RECORDS_IN_GRADS: sorted records inside the
+    caller's gradient buffers) is never larger than the full one and, at c2 @ 10k, smaller by the whole record array;
+    problems of the single-launch kernel need none; the level-size bound turns a decoder call over an image-sized
+    pyramid into such a problem; several rounds over the queries (c5) keep grad_value out of the record homes."""
+    from msda_triton_amd import _lib
+    lib = _lib.load()
+    flag = _lib.WS_RECORDS_IN_GRADS
+    c2 = (4, 5440, 8, 32, 10000, 4, 4)
+    full, lean = lib.msda_bwd_workspace_bytes_ex(*c2, 4, 4, 0, 0), lib.msda_bwd_workspace_bytes_ex(*c2, 4, 4, 0, flag)
+    assert full == lib.msda_bwd_workspace_bytes(*c2, 4)
+    records = 4 * 8 * 10000 * 16 * 16  # planes x samples per plane x 16 bytes
+    assert 0 < lean <= full - records and lean < 110e6
+    for dims, es, ves in (((4, 5440, 8, 32, 5000, 4, 4), 4, 4), ((2, 17821, 8, 32, 17821, 4, 4), 2, 2),
+                          ((2, 17821, 8, 32, 17821, 4, 4), 4, 2), ((4, 21824, 8, 64, 100000, 5, 8), 2, 2)):
+        f, le = lib.msda_bwd_workspace_bytes_ex(*dims, es, ves, 0, 0), lib.msda_bwd_workspace_bytes_ex(*dims, es, ves, 0, flag)
+        assert 0 < le < f, dims
+    c5 = (4, 21824, 8, 64, 100000, 5, 8)  # two rounds: grad_loc / grad_attn hold records, grad_value does not
+    per_round = 4 * 8 * 50000 * 40 * 16
+    assert lib.msda_bwd_workspace_bytes_ex(*c5, 2, 2, 0, 0) - lib.msda_bwd_workspace_bytes_ex(*c5, 2, 2, 0, flag) < per_round
+    assert lib.msda_bwd_workspace_bytes_ex(2, 5440, 8, 32, 900, 4, 4, 4, 4, 0, flag) == 0          # c1: single launch
+    dec = (8, 17821, 8, 32, 900, 4, 4)
+    assert lib.msda_bwd_workspace_bytes_ex(*dec, 4, 4, 0, 0) > 0
+    assert lib.msda_bwd_workspace_bytes_ex(*dec, 4, 4, 101 * 135, 0) == 0                           # with the bound
+    assert lib.msda_fwd_workspace_bytes(2, 17821, 8, 32, 2) == 0                                     # pairs are off
