@@ -1169,6 +1169,23 @@ def test_single_launch_kernel_is_bitwise_reproducible_by_default(case):
         _lib.set_option("xcd_map", 1)
 
 
+@pytest.mark.parametrize("place_path", [0, 3], ids=["auto", "256_threads"])
+def test_level_larger_than_the_place_pass_lds_table(oracle, place_path):
+    """The level-major place pass keeps ONE level's cell cursors in LDS, capped at 19 456 cells so that two workgroups
+    share a CU; a larger level (here 150 x 160 = 24 311 cells, next to a small one) is walked in several trips over
+    its samples.  Sorted pipeline, both workgroup sizes, zeros and border."""
+    from msda_triton_amd import _lib
+    c = rand_case(np.random.default_rng(2024), 1, 2600, 2, 32, [(150, 160), (7, 9)], 4, lo=-0.03, hi=1.03)
+    try:
+        _lib.set_option("value_path", 2)
+        _lib.set_option("place_path", place_path)
+        for pm, ac in (("zeros", False), ("border", True)):
+            check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float32], BWD_TOL[torch.float32])
+    finally:
+        _lib.set_option("value_path", 0)
+        _lib.set_option("place_path", 0)
+
+
 def _boundary_coordinates(n):
     """float32 coordinates next to the cell boundaries of an n-pixel axis for which x * n - 0.5 lands in different
     cells when it is computed with one rounding (fused multiply-add) and with two"""
