@@ -1186,6 +1186,21 @@ def test_level_larger_than_the_place_pass_lds_table(oracle, place_path):
         _lib.set_option("place_path", 0)
 
 
+@pytest.mark.parametrize("value_path", [2, 3], ids=["sorted_gather", "single_launch"])
+def test_more_points_per_level_than_a_workgroup_has_threads(oracle, value_path):
+    """P = 1100 > 1024: the single-launch kernel walks a query's points in strides of the workgroup (its ordered placing
+    takes one turn per stride), the sorted pipeline falls back to the plane-major place pass (the level-major one maps a
+    thread to one point)."""
+    from msda_triton_amd import _lib
+    c = rand_case(np.random.default_rng(1100), 1, 3, 2, 8, [(5, 4), (2, 3)], 1100, lo=-0.2, hi=1.2)
+    try:
+        _lib.set_option("value_path", value_path)
+        for pm, ac in (("zeros", False), ("border", True)):
+            check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float32], BWD_TOL[torch.float32])
+    finally:
+        _lib.set_option("value_path", 0)
+
+
 def _boundary_coordinates(n):
     """float32 coordinates next to the cell boundaries of an n-pixel axis for which x * n - 0.5 lands in different
     cells when it is computed with one rounding (fused multiply-add) and with two"""
