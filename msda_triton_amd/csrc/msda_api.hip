@@ -31,6 +31,7 @@ static std::atomic<int> g_place_path{0};
 static std::atomic<int> g_pairs{0};
 static std::atomic<int> g_profile{0};
 static std::atomic<int> g_records_in_grads{1};
+static std::atomic<int> g_lds_levels{1};
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
 // Per THREAD, because the fork (record on the user's stream, wait on the side stream) and the join are two calls
@@ -116,6 +117,22 @@ int option_place_path() { return g_place_path.load(std::memory_order_relaxed); }
 int option_pairs() { return g_pairs.load(std::memory_order_relaxed); }
 int option_profile() { return g_profile.load(std::memory_order_relaxed); }
 int option_records_in_grads() { return g_records_in_grads.load(std::memory_order_relaxed); }
+int option_lds_levels() { return g_lds_levels.load(std::memory_order_relaxed); }
+// CUs of the current device, asked once per device (the LDS-level gather variants size their grid by it)
+int device_cu_count()
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        n = 256;  // MI355X
+    }
+    cached[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
 
 // ---- measurement only: device time of every kernel the library launches on this thread (option "profile") ----
 struct ProfileRec {
@@ -329,6 +346,10 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_profile.store(value ? 1 : 0, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "lds_levels") == 0 && value >= 0 && value <= 2) {
+        msda::g_lds_levels.store(value, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "cell_slices") == 0 && value >= 0 && value <= 64) {
         msda::g_cell_slices.store(value, std::memory_order_relaxed);
         return 0;
@@ -358,6 +379,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "pairs") == 0) return msda::option_pairs();
     if (key && strcmp(key, "profile") == 0) return msda::option_profile();
     if (key && strcmp(key, "records_in_grads") == 0) return msda::option_records_in_grads();
+    if (key && strcmp(key, "lds_levels") == 0) return msda::option_lds_levels();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

@@ -11,6 +11,7 @@ namespace msda {
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;          // threads per workgroup of the gather kernels
+constexpr int kBlockLds = 1024;      // ... of their variants that keep the coarsest levels in LDS (one workgroup per CU)
 constexpr int kMaxLevels = MSDA_MAX_LEVELS;
 constexpr uint32_t kMaskedOffset = 0x80000000u;  // >= any buffer size we accept -> buffer_load returns 0
 
@@ -255,6 +256,31 @@ template <int G> __device__ __forceinline__ float group_sum(float v)
     if constexpr (G >= 32) v += __shfl_xor(v, 16, kWave);
     if constexpr (G >= 64) v += __shfl_xor(v, 32, kWave);
     return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Reduce-SCATTER over the lanes of a unit (G = 4 or 8): every lane brings K partial sums for each of G items
+// (e[item][k]); afterwards lane j of the unit holds the K COMPLETE sums of item j.  A butterfly whose every step
+// halves the items a lane keeps: G = 8 costs 16 + 8 + 4 exchanged adds per k-quadruple instead of the 8 * 3 * K / 4
+// of all-reducing item by item, and the work behind the sums is then done once per item, on its owner lane, instead
+// of G times.  quarter_step / pair_step are the two quad-internal steps; the 8-lane step (row_half_mirror: lane j
+// meets lane 7 - j, lanes 0..3 keep items 0..3, lanes 4..7 items 4..7) is split so that the kernel can run it on one
+// half of the items as soon as that half's partial sums exist (half_step).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_step(float v) { return v + dpp_f32<0x141>(v); }  // row_half_mirror partner
+template <int K> __device__ __forceinline__ void quad_steps(const float (&e)[4][K], int j, float (&out)[K])
+{
+    const bool hi2 = (j & 2) != 0, hi1 = (j & 1) != 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        // lanes {0,1} of a quad keep items 0, 1; lanes {2,3} items 2, 3 (partner: lane ^ 2)
+        const float a0 = e[0][k] + dpp_f32<0x4E>(e[0][k]), a1 = e[1][k] + dpp_f32<0x4E>(e[1][k]);
+        const float b0 = e[2][k] + dpp_f32<0x4E>(e[2][k]), b1 = e[3][k] + dpp_f32<0x4E>(e[3][k]);
+        const float f0 = hi2 ? b0 : a0, f1 = hi2 ? b1 : a1;
+        // even lanes keep the first of their two items, odd lanes the second (partner: lane ^ 1)
+        const float c0 = f0 + dpp_f32<0xB1>(f0), c1 = f1 + dpp_f32<0xB1>(f1);
+        out[k] = hi1 ? c1 : c0;
+    }
 }
 
 // max over the G lanes of a unit (same lane choreography as group_sum)

@@ -74,6 +74,7 @@ struct Params {
     // x-pair table of the value pyramid (PAIR kernels): [B][H][I][2][D], entry p = the rows of pixels p and p + 1 of one
     // head, one 128-byte line when a row has 64 bytes — a bilinear footprint's two x-corners then come from ONE line
     const void *pairs;
+    int lds_lev_bytes;  // LDSL gather kernels: LDS bytes set aside for the rows of the coarsest levels
     int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
     int small_ns;       // ... workgroups per (plane, level)
     int small_hinted;   // ... small_cells is the caller's promise (msda_hint_level_cells), not the bound from I
@@ -124,6 +125,33 @@ __device__ __forceinline__ void pair_offsets(uint32_t (&off)[4], uint32_t entry_
     if (off[3] == off[2] + entry_bytes) off[3] = off[2] + entry_bytes / 2;
 }
 
+// LDSL kernels: which levels are served from LDS — the longest suffix of the level list whose pixels fit `budget` bytes
+// (pyramids list their levels fine to coarse; any other order only costs the speed-up).  Uniform: every thread derives
+// the same answer from the level table.
+struct CoarseLevels {
+    int first;   // levels [first, L) are LDS-resident (first == L: none)
+    int pixels;  // ... their pixels, rows in level-packed order
+};
+__device__ __forceinline__ CoarseLevels coarse_levels(const LevelTab *tab, int L, uint32_t row_bytes, int budget)
+{
+    CoarseLevels c{L, 0};
+    const int cap = budget / (int)row_bytes;
+    for (int l = L - 1; l >= 0; --l) {
+        const int n = tab->h[l] * tab->w[l];
+        if (n > cap - c.pixels) break;
+        c.pixels += n;
+        c.first = l;
+    }
+    return c;
+}
+// VEC consecutive elements of an LDS-resident row at byte offset `off` of the workgroup's LDS, widened
+template <typename T, int VEC> __device__ __forceinline__ void lds_row(uint32_t off, typename Traits<T>::acc (&dst)[VEC])
+{
+    const Pack<T, VEC> pk = *reinterpret_cast<const Pack<T, VEC> *>(msda_smem + off);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dst[i] = Traits<T>::to_acc(pk.v[i]);
+}
+
 // ==========================================================================================
 // forward.  After the one-time staging barrier every wave runs on its own: it parks the records of
 // ITS 64/G units, gathers, stores, and moves to its next query chunk without any block barrier.
@@ -134,13 +162,19 @@ __device__ __forceinline__ void pair_offsets(uint32_t (&off)[4], uint32_t entry_
 // left half gathers the rows of the x0 corners, the right half those of the x1 corners — for x1 = x0 + 1 both sit in
 // the line of pixel x0, so a footprint costs two 128-byte lines instead of four half-used ones (64-byte rows: 15.5 ->
 // 8.1 ps per sample in the gather alone, profiles/r04_row_pair_bench.txt).  The halves' sums meet once per unit.
-template <typename T, int VEC, int G, bool FUSED, typename TV = T, bool PAIR = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void msda_fwd_kernel(const Params p)
+// LDSL (BLK = kBlockLds threads): the coarsest levels of the plane — the longest SUFFIX of the level list whose rows fit
+// Params::lds_lev_bytes — are copied into LDS once per workgroup and their samples read from there (coarse_levels()).
+// The gather is bound by the vector-memory path (64 B/clk/CU); an LDS row read costs a quarter of that,
+// on another pipe.  One large workgroup per CU, so that 16 waves share ONE copy (round 2 tried it with 256-thread
+// workgroups: the copies ate the occupancy).  Same arithmetic in the same order: results are bit-identical.
+template <typename T, int VEC, int G, bool FUSED, typename TV = T, bool PAIR = false, int BLK = kBlock, bool LDSL = false>
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlock ? 5 : 4))) void msda_fwd_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
-    constexpr int NU = kBlock / G;     // units per workgroup and query chunk
+    static_assert(!(LDSL && (PAIR || VEC == 1)), "the LDS-served levels use the plain 16-byte vector path");
+    constexpr int NU = BLK / G;        // units per workgroup and query chunk
     constexpr int UPW = kWave / G;     // units per wave
     constexpr int GH = PAIR ? G / 2 : G;  // lanes across one row's channels
 
@@ -203,6 +237,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     }
     load_level_table(tab, p.shapes, p.L);
     __syncthreads();
+    // LDSL: levels [fl, L) live in LDS behind the records, rows D * sizeof(TV) bytes apart, then one row of zeros
+    // (what a corner masked by "zeros" padding reads)
+    int fl = p.L;
+    uint32_t lev_base = 0, lev_zero = 0;
+    constexpr uint32_t kPiece = VEC * sizeof(TV);  // bytes a lane loads of a row
+    const uint32_t lrow_bytes = (uint32_t)p.D * (uint32_t)sizeof(TV);
+    if constexpr (LDSL) {
+        lev_base = (uint32_t)((kGatherLdsFixed + (size_t)NU * scp * (sizeof(uint4) + sizeof(Rec4<A>)) + 127) / 128 * 128);
+        const CoarseLevels cl = coarse_levels(tab, p.L, lrow_bytes, p.lds_lev_bytes);
+        fl = cl.first;
+        lev_zero = lev_base + (uint32_t)cl.pixels * lrow_bytes;
+        const int ppr = (int)(lrow_bytes / kPiece);  // pieces per row (<= G)
+        const int npieces = cl.pixels * ppr;
+        const float inv_ppr = 1.0f / (float)ppr;
+        const uint32_t first_row = (uint32_t)(fl < p.L ? tab->start[fl] : 0);
+        using RLV = RawLoad<kPiece>;
+        for (int i = tid; i < npieces; i += BLK) {
+            const int r = div_small(i, ppr, inv_ppr), c = i - imul24(r, ppr);
+            const typename RLV::type v = RLV::load(rs, mul24(first_row + (uint32_t)r, row_bytes) + (uint32_t)c * kPiece);
+            *reinterpret_cast<typename RLV::type *>(msda_smem + lev_base + (uint32_t)i * kPiece) = v;
+        }
+        for (int i = tid; i < ppr; i += BLK) {
+            typename RLV::type z{};
+            *reinterpret_cast<typename RLV::type *>(msda_smem + lev_zero + (uint32_t)i * kPiece) = z;
+        }
+        __syncthreads();
+    }
 
     for (int qc = slot * p.qw; qc < qc_end; ++qc) {
         const int wq0 = qc * NU + wave * UPW;  // first query of this wave
@@ -291,7 +352,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                             a = TR::to_acc(attn[sidx]);
                         }
                         Taps<A> t;
-                        make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l], p.zeros, p.align, row_bytes, t);
+                        if (LDSL && l >= fl) {  // an LDS-resident level: offsets into the workgroup's copy
+                            make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l] - tab->start[fl], p.zeros, p.align, lrow_bytes, t);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) t.off[c] = t.off[c] == kMaskedOffset ? lev_zero : t.off[c] + lev_base;
+                        } else {
+                            make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l], p.zeros, p.align, row_bytes, t);
+                        }
                         const A wy0 = (A)1 - t.dy, wx0 = (A)1 - t.dx;
                         Rec4<A> w;
                         w.v[0] = a * (wy0 * wx0);
@@ -334,8 +401,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                             }
                         }
                     } else {
+                    // samples [0, s_lds) of this trip gather from memory, [s_lds, sc) from the LDS-resident levels
+                    const int s_lds = LDSL ? min(max(imul24(fl, p.P) - s0, 0), sc) : sc;
 #pragma unroll 4
-                    for (int s = 0; s < sc; ++s) {
+                    for (int s = 0; s < s_lds; ++s) {
                         const uint4 o = uo[s];
                         const Rec4<A> w = uw[s];
                         A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
@@ -349,6 +418,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
                             acc[i] = fma_t(w.v[1], v1[i], acc[i]);
                             acc[i] = fma_t(w.v[2], v2[i], acc[i]);
                             acc[i] = fma_t(w.v[3], v3[i], acc[i]);
+                        }
+                    }
+                    if constexpr (LDSL) {
+#pragma unroll 4
+                        for (int s = s_lds; s < sc; ++s) {
+                            const uint4 o = uo[s];
+                            const Rec4<A> w = uw[s];
+                            A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                            lds_row<TV, VEC>(o.x + lane_off, v0);
+                            lds_row<TV, VEC>(o.y + lane_off, v1);
+                            lds_row<TV, VEC>(o.z + lane_off, v2);
+                            lds_row<TV, VEC>(o.w + lane_off, v3);
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) {
+                                acc[i] = fma_t(w.v[0], v0[i], acc[i]);
+                                acc[i] = fma_t(w.v[1], v1[i], acc[i]);
+                                acc[i] = fma_t(w.v[2], v2[i], acc[i]);
+                                acc[i] = fma_t(w.v[3], v3[i], acc[i]);
+                            }
                         }
                     }
                     }
@@ -387,6 +475,8 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
     constexpr int NU = kBlock / G;
     constexpr int UPW = kWave / G;
     constexpr int GH = PAIR ? G / 2 : G;  // lanes across one row's channels
+    // units of 4 / 8 lanes hand every sample's dot products to ONE owner lane (reduce-scatter) instead of all-reducing
+    constexpr bool kScatter = !PAIR && sizeof(A) == 4 && (G == 4 || G == 8);
 
     const int slots = (p.nqc + p.qw - 1) / p.qw;
     int pair, slot;
@@ -641,6 +731,80 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                                     up[sb + u] = res;
                                 }
                             }
+                        }
+                    }
+                } else if (kScatter && nchan_chunks == 1) {
+                    // fast path, units of 4 or 8 lanes: the partial dot products of G samples are reduce-SCATTERED over
+                    // the unit (quad_steps / half_step, msda_common.hpp) — lane j ends up with the four complete dot
+                    // products of sample sb + j, combines them ONCE and parks the result itself.  (Until round 5 every
+                    // lane combined every sample and three all-reduces followed: 50 M vector instructions per launch at
+                    // c2 @ 10k against the forward's 21 M for the same gather.)  Rows of UB samples in flight at once;
+                    // an 8-lane unit runs two such half-batches per exchange.
+                    if constexpr (kScatter) {
+                        constexpr int UB = 4, NH = G / UB;
+                        const int c0 = j * VEC;
+                        const bool lane_in = c0 < p.D;
+                        const uint32_t lo = lane_in ? (uint32_t)c0 * (uint32_t)sizeof(TV) : 0u;
+                        Pack<T, VEC> gp;
+    #pragma unroll
+                        for (int i = 0; i < VEC; ++i) gp.v[i] = TR::from_acc((A)0);
+                        if (lane_in) gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
+                        A g[VEC];
+    #pragma unroll
+                        for (int i = 0; i < VEC; ++i) g[i] = TR::to_acc(gp.v[i]);
+                        using RLV = RawLoad<sizeof(TV) * VEC>;
+                        for (int sb = 0; sb < sc; sb += G) {
+                            float e[UB][4];
+    #pragma unroll
+                            for (int hb = 0; hb < NH; ++hb) {
+                                Pack<TV, VEC> v[UB][4];  // (kept packed until they are consumed)
+    #pragma unroll
+                                for (int u = 0; u < UB; ++u) {
+                                    const uint4 o = uo[min(sb + hb * UB + u, sc - 1)];  // tail: the last sample again, not stored
+                                    v[u][0] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.x + lo));
+                                    v[u][1] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.y + lo));
+                                    v[u][2] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.z + lo));
+                                    v[u][3] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.w + lo));
+                                }
+    #pragma unroll
+                                for (int u = 0; u < UB; ++u) {
+    #pragma unroll
+                                    for (int k = 0; k < 4; ++k) {
+                                        float d = 0.0f;
+                                        if constexpr (TR::kDot2 && (VEC % 2) == 0 && sizeof(TV) == sizeof(T)) {
+                                            // 16-bit rows: straight from the packed pairs (v_dot2c_f32_f16 / _bf16)
+                                            using P2 = typename TR::pair_t;
+                                            struct Pairs {
+                                                P2 p[VEC / 2];
+                                            };
+                                            const Pairs gq = __builtin_bit_cast(Pairs, gp), vq = __builtin_bit_cast(Pairs, v[u][k]);
+    #pragma unroll
+                                            for (int i = 0; i < VEC / 2; ++i) d = TR::dot2(gq.p[i], vq.p[i], d);
+                                        } else {
+    #pragma unroll
+                                            for (int i = 0; i < VEC; ++i) d = fma_t(g[i], Traits<TV>::to_acc(v[u][k].v[i]), d);
+                                        }
+                                        if constexpr (G == 8) {
+                                            const float t = half_step(d);
+                                            e[u][k] = (hb == 0 || (j & 4)) ? t : e[u][k];
+                                        } else {
+                                            e[u][k] = d;
+                                        }
+                                    }
+                                }
+                            }
+                            float dd[4];
+                            quad_steps<4>(e, j, dd);
+                            const int s = sb + j;  // this lane's sample
+                            const Rec4<A> r = up[min(s, sc - 1)];
+                            const A dx = r.v[0], dy = r.v[1];
+                            const A wy0 = (A)1 - dy, wx0 = (A)1 - dx;
+                            Rec4<A> res;
+                            res.v[0] = (wy0 * wx0) * dd[0] + (wy0 * dx) * dd[1] + (dy * wx0) * dd[2] + (dy * dx) * dd[3];
+                            res.v[1] = r.v[2] * (wy0 * (dd[1] - dd[0]) + dy * (dd[3] - dd[2]));
+                            res.v[2] = r.v[3] * (wx0 * (dd[2] - dd[0]) + dx * (dd[3] - dd[1]));
+                            res.v[3] = (A)0;
+                            if (s < sc) up[s] = res;
                         }
                     }
                 } else if (nchan_chunks == 1) {

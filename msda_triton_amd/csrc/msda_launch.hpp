@@ -154,10 +154,10 @@ inline int pick_group(int lanes_needed)
 }
 
 // samples of a unit parked in LDS at a time (records) and the total dynamic LDS
-inline void plan_gather(int NU, int LP, size_t acc_bytes, int &sc, size_t &lds, bool aux = false)
+inline void plan_gather(int NU, int LP, size_t acc_bytes, int &sc, size_t &lds, bool aux = false, size_t budget = kRecordLdsBudget)
 {
     const size_t rec = 16 + (aux ? 7 : 4) * acc_bytes;  // aux: the fused backward's (a, ox, oy) per slot
-    int cap = (int)((size_t)kRecordLdsBudget / (NU * rec)) - 1;
+    int cap = (int)(budget / (NU * rec)) - 1;
     if (cap < 1) cap = 1;
     sc = LP < cap ? LP : cap;
     lds = kGatherLdsFixed + (size_t)NU * (sc + 1) * rec;
@@ -165,10 +165,74 @@ inline void plan_gather(int NU, int LP, size_t acc_bytes, int &sc, size_t &lds, 
 
 // MODE 0: forward, 1: grad_loc/grad_attn, 2: fused forward, 3: fused backward (sample half)
 // PAIR: value rows from the x-pair table (p.pairs); G then counts both halves of a unit's lanes
+// ---- the gather kernels with the coarsest levels in LDS (msda_kernels.hpp, LDSL): ONE 1024-thread workgroup per CU,
+// every (b, h) plane cut into as many runs of query chunks as fill the chip once ----
+int option_lds_levels();  // 0: never, 1: where lds_levels_plan says so, 2: wherever the kernels exist
+int device_cu_count();    // CUs of the current device (cached; msda_api.hip)
+constexpr size_t kRecordLdsBudgetLds = 72 * 1024;  // the records of 16 waves
+
+struct LdsLevelsPlan {
+    bool use;
+    int nqc, qw, slots, sc;
+    size_t lds;
+    int lev_bytes;
+};
+template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(const Params &p, bool aux)
+{
+    using A = typename Traits<T>::acc;
+    constexpr int NU = kBlockLds / G;
+    LdsLevelsPlan pl{};
+    size_t rec_lds;
+    plan_gather(NU, p.LP, sizeof(A), pl.sc, rec_lds, aux, kRecordLdsBudgetLds);
+    const size_t lev_base = (rec_lds + 127) / 128 * 128, row = (size_t)p.D * sizeof(TV);
+    const long long room = (long long)kMaxDynLds - (long long)lev_base - (long long)((row + 15) / 16 * 16);
+    pl.nqc = (p.Q + NU - 1) / NU;
+    const int npairs = p.B * p.H, ncu = device_cu_count();
+    int slots = npairs >= ncu ? 1 : (ncu + npairs / 2) / npairs;
+    if (slots > pl.nqc) slots = pl.nqc;
+    if (slots < 1) slots = 1;
+    pl.qw = (pl.nqc + slots - 1) / slots;
+    pl.slots = (pl.nqc + pl.qw - 1) / pl.qw;
+    // the whole plane at most; the kernel takes the longest suffix of the level list that fits
+    const long long plane = (long long)p.I * (long long)row;
+    pl.lev_bytes = (int)(room < plane ? (room < 0 ? 0 : room) : plane);
+    pl.lds = lev_base + (size_t)pl.lev_bytes + (row + 15) / 16 * 16;
+    const long long wgs = (long long)npairs * pl.slots, rounds = (wgs + ncu - 1) / ncu;
+    const int opt = option_lds_levels();
+    // worth it when a workgroup amortises its copy over >= 4 chunks and the workgroups fill the CUs evenly
+    const bool pays = pl.qw >= 4 && wgs * 10 >= rounds * ncu * 8 && pl.lev_bytes >= (int)(64 * row);
+    pl.use = opt == 2 ? pl.lev_bytes >= (int)row : opt == 1 && pays;
+    return pl;
+}
+
+template <typename T, int VEC, int G, int MODE, typename TV> inline int launch_gather_lds(Params &p, const LdsLevelsPlan &pl, hipStream_t stream)
+{
+    static_assert(MODE == 0, "LDS-served levels: plain forward so far");
+    p.sc = pl.sc;
+    p.nqc = pl.nqc;
+    p.qw = pl.qw;
+    p.lds_lev_bytes = pl.lev_bytes;
+    dim3 grid;
+    if (!plane_grid(p, p.B * p.H, pl.slots, grid)) {
+        set_error("grid too large");
+        return MSDA_ERR_TOO_LARGE;
+    }
+    static std::atomic<uint64_t> big_lds_done{0};
+    const ProfileScope prof("msda_fwd_kernel", stream);
+    auto kernel = msda_fwd_kernel<T, VEC, G, false, TV, false, kBlockLds, true>;
+    allow_big_lds(kernel, big_lds_done);
+    hipLaunchKernelGGL(kernel, grid, dim3(kBlockLds), pl.lds, stream, p);
+    return (int)hipGetLastError();
+}
+
 template <typename T, int VEC, int G, int MODE, typename TV = T, bool PAIR = false> inline int launch_gather(Params &p, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
     constexpr int NU = kBlock / G;
+    if constexpr (MODE == 0 && !PAIR && VEC * sizeof(T) == 16 && G <= 16) {
+        const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, false);
+        if (pl.use) return launch_gather_lds<T, VEC, G, MODE, TV>(p, pl, stream);
+    }
     size_t lds;
     plan_gather(NU, p.LP, sizeof(A), p.sc, lds, MODE == 3);
     p.nqc = (p.Q + NU - 1) / NU;

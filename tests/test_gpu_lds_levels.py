@@ -1,0 +1,72 @@
+"""The gather kernels that keep the coarsest pyramid levels in LDS (``msda_set_option("lds_levels", …)``: 0 never,
+1 where the launcher's plan says it pays, 2 wherever the variant exists) against the plain kernels and the oracle.
+The variant runs the same arithmetic in the same order, so its results must be BIT-identical to the plain kernels'."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import MODES, mode_key
+from test_gpu_parity import DEV, FWD_TOL, rand_case
+
+pytestmark = pytest.mark.gpu
+
+# name: (B, Q, H, D, levels, P, dtype)
+CASES = {
+    "c2_like_f32": (2, 700, 4, 32, [(16, 16), (8, 8), (4, 4), (2, 2)], 4, torch.float32),
+    "all_levels_fit": (1, 300, 2, 32, [(6, 5), (3, 3)], 4, torch.float32),
+    "no_level_fits_but_last": (1, 260, 2, 32, [(40, 40), (33, 31), (2, 2)], 2, torch.float32),
+    "nothing_fits": (1, 200, 1, 32, [(64, 64), (40, 40)], 2, torch.float32),
+    "coarse_first_order": (1, 150, 2, 16, [(2, 2), (4, 4), (9, 7)], 3, torch.float32),
+    "odd_points_boundary": (2, 333, 3, 32, [(9, 9), (5, 4), (3, 2)], 3, torch.float32),
+    "many_samples_two_trips": (1, 140, 2, 32, [(8, 8), (4, 4), (2, 2), (1, 1), (3, 3)], 8, torch.float32),
+    "bf16_g4": (2, 520, 4, 32, [(20, 17), (10, 9), (5, 4)], 4, torch.bfloat16),
+    "fp16_d64": (1, 300, 4, 64, [(16, 16), (8, 8), (4, 4)], 8, torch.float16),
+    "f64": (1, 130, 2, 8, [(7, 6), (4, 3)], 3, torch.float64),
+    "d64_f32_g16": (1, 200, 2, 64, [(12, 12), (6, 6), (3, 3)], 2, torch.float32),
+}
+
+
+def _forward(c, td, pm, ac, opt):
+    from msda_triton_amd import _lib, multiscale_deformable_attention
+    old = _lib.get_option("lds_levels")
+    _lib.set_option("lds_levels", opt)
+    try:
+        v = torch.from_numpy(c["value"]).to(DEV, td)
+        l = torch.from_numpy(c["loc"]).to(DEV, td)
+        a = torch.from_numpy(c["attn"]).to(DEV, td)
+        s = torch.from_numpy(c["shapes"]).to(DEV)
+        with torch.no_grad():
+            out = multiscale_deformable_attention(v, s, l, a, pm, ac)
+        torch.cuda.synchronize()
+        return out
+    finally:
+        _lib.set_option("lds_levels", old)
+
+
+@pytest.mark.parametrize("name", list(CASES), ids=list(CASES))
+@pytest.mark.parametrize("pm,ac", MODES, ids=[mode_key(*m) for m in MODES])
+def test_lds_served_levels_forward_is_bit_identical(oracle, name, pm, ac):
+    B, Q, H, D, levels, P, td = CASES[name]
+    c = rand_case(np.random.default_rng(zlib.crc32(name.encode())), B, Q, H, D, levels, P,
+                  dtype=np.float64 if td == torch.float64 else np.float32)
+    plain = _forward(c, td, pm, ac, 0)
+    lds = _forward(c, td, pm, ac, 2)
+    assert torch.equal(plain, lds), f"max diff {(plain.double() - lds.double()).abs().max().item():.3e}"
+    if td in FWD_TOL:
+        ref = oracle.forward(c["value"], c["shapes"], c["loc"], c["attn"], pm, ac)
+        np.testing.assert_allclose(lds.cpu().numpy(), ref, **FWD_TOL[td])
+
+
+def test_lds_served_levels_are_chosen_by_default_at_c2_size():
+    """the launcher's own plan (option 1, the default) takes the variant at the headline shape — and the result is
+    still bit-identical to the plain kernel's"""
+    from msda_triton_amd import _lib, synth
+    assert _lib.get_option("lds_levels") in (1, 2)
+    wl = synth.WORKLOADS["c2_q10k"]
+    d = synth.make_inputs_numpy(wl, seed=3)
+    c = {k: (v if k == "shapes" else v.astype(np.float32)) for k, v in d.items()}
+    a = _forward(c, torch.float32, "border", True, 1)
+    b = _forward(c, torch.float32, "border", True, 0)
+    assert torch.equal(a, b)
