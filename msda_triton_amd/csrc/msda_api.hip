@@ -32,6 +32,8 @@ static std::atomic<int> g_pairs{0};
 static std::atomic<int> g_profile{0};
 static std::atomic<int> g_records_in_grads{1};
 static std::atomic<int> g_lds_levels{1};
+static std::atomic<int> g_lds_budget{-1};
+static std::atomic<int> g_lds_stagger{8};
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
 // Per THREAD, because the fork (record on the user's stream, wait on the side stream) and the join are two calls
@@ -118,6 +120,8 @@ int option_pairs() { return g_pairs.load(std::memory_order_relaxed); }
 int option_profile() { return g_profile.load(std::memory_order_relaxed); }
 int option_records_in_grads() { return g_records_in_grads.load(std::memory_order_relaxed); }
 int option_lds_levels() { return g_lds_levels.load(std::memory_order_relaxed); }
+int option_lds_stagger() { return g_lds_stagger.load(std::memory_order_relaxed); }
+int option_lds_budget() { return g_lds_budget.load(std::memory_order_relaxed); }  // dev knob: cap on the level bytes (-1: none)
 // CUs of the current device, asked once per device (the LDS-level gather variants size their grid by it)
 int device_cu_count()
 {
@@ -346,6 +350,14 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_profile.store(value ? 1 : 0, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "lds_stagger") == 0 && value >= 0 && value <= 4096) {
+        msda::g_lds_stagger.store(value, std::memory_order_relaxed);
+        return 0;
+    }
+    if (key && strcmp(key, "lds_budget") == 0) {
+        msda::g_lds_budget.store(value, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "lds_levels") == 0 && value >= 0 && value <= 2) {
         msda::g_lds_levels.store(value, std::memory_order_relaxed);
         return 0;
@@ -380,6 +392,8 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "profile") == 0) return msda::option_profile();
     if (key && strcmp(key, "records_in_grads") == 0) return msda::option_records_in_grads();
     if (key && strcmp(key, "lds_levels") == 0) return msda::option_lds_levels();
+    if (key && strcmp(key, "lds_budget") == 0) return msda::option_lds_budget();
+    if (key && strcmp(key, "lds_stagger") == 0) return msda::option_lds_stagger();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;
 }

@@ -17,6 +17,8 @@
 //  groups with 9 / 15 / 41 KiB in round 2 — and removed: -7 % on c2 @ 10k only, slower on c1 / c3 / c5)
 #pragma once
 
+#include <type_traits>
+
 #include "msda_common.hpp"
 
 namespace msda {
@@ -75,6 +77,7 @@ struct Params {
     // head, one 128-byte line when a row has 64 bytes — a bilinear footprint's two x-corners then come from ONE line
     const void *pairs;
     int lds_lev_bytes;  // LDSL gather kernels: LDS bytes set aside for the rows of the coarsest levels
+    int lds_stagger;    // ... wave w starts w * lds_stagger * 64 cycles late
     int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
     int small_ns;       // ... workgroups per (plane, level)
     int small_hinted;   // ... small_cells is the caller's promise (msda_hint_level_cells), not the bound from I
@@ -95,6 +98,8 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// level table + one 16-byte slot (the LDSL kernels' work counter) in front of the records
+constexpr size_t kGatherLdsFixedBytes = (sizeof(LevelTab) + 15) / 16 * 16 + 16;
 // shared LDS carve-up of the two gather kernels
 template <typename A> struct GatherLds {
     LevelTab *tab;
@@ -105,7 +110,7 @@ template <typename A> struct GatherLds {
     {
         unsigned char *p = msda_smem;
         tab = reinterpret_cast<LevelTab *>(p);
-        p += (sizeof(LevelTab) + 15) / 16 * 16;
+        p += kGatherLdsFixedBytes;
         s_off = reinterpret_cast<uint4 *>(p);
         p += (size_t)units * scp * sizeof(uint4);
         s_rec = reinterpret_cast<Rec4<A> *>(p);
@@ -113,7 +118,7 @@ template <typename A> struct GatherLds {
         s_aux = reinterpret_cast<A *>(p);
     }
 };
-constexpr size_t kGatherLdsFixed = (sizeof(LevelTab) + 15) / 16 * 16;
+constexpr size_t kGatherLdsFixed = kGatherLdsFixedBytes;
 
 // PAIR: the four corner offsets in pair-table addressing.  make_taps was given the table's entry stride, so every
 // offset points at its pixel's OWN entry (left half); an x1 corner that is the x0 corner's right-hand neighbour
@@ -123,6 +128,26 @@ __device__ __forceinline__ void pair_offsets(uint32_t (&off)[4], uint32_t entry_
 {
     if (off[1] == off[0] + entry_bytes) off[1] = off[0] + entry_bytes / 2;
     if (off[3] == off[2] + entry_bytes) off[3] = off[2] + entry_bytes / 2;
+}
+
+// LDSL kernels: the workgroup's waves take their work — runs of 64 / G queries out of the workgroup's query range — from
+// a counter in LDS instead of a fixed share, and start it staggered (wave w waits w * Params::lds_stagger * 64 cycles).
+// Sixteen waves released by one barrier otherwise run their phases in lockstep — all wait for their sampling points,
+// then all gather from memory, then all read LDS — and the three pipes take turns instead of overlapping (measured at
+// c2 @ 10k: a chunk took the SUM of its phases, forward 83 us; the plain kernel's waves are staggered by the dispatcher).
+__device__ __forceinline__ int *gather_work_counter()
+{
+    return reinterpret_cast<int *>(msda_smem + (sizeof(LevelTab) + 15) / 16 * 16);
+}
+__device__ __forceinline__ int next_slice(int lane)
+{
+    int t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(gather_work_counter(), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(t);
+}
+__device__ __forceinline__ void stagger_wave(int wave, int units)
+{
+    for (int i = 0; i < wave * units; ++i) __builtin_amdgcn_s_sleep(1);
 }
 
 // LDSL kernels: which levels are served from LDS — the longest suffix of the level list whose pixels fit `budget` bytes
@@ -143,6 +168,48 @@ __device__ __forceinline__ CoarseLevels coarse_levels(const LevelTab *tab, int L
         c.first = l;
     }
     return c;
+}
+// ... and the copy itself: every thread of the workgroup moves 16-byte (VEC elements of TV) pieces of the rows of levels
+// [first, L) from the plane into LDS at `lds_off` (rounded up to 128), a row of zeros behind them; ends with a barrier.
+struct CoarseStage {
+    int first;                  // levels [first, L) are LDS-resident
+    uint32_t base, zero;        // LDS byte offsets of the first row and of the row of zeros
+    uint32_t row_bytes;         // D * sizeof(TV): distance of two rows in LDS
+    // byte offsets relative to the first staged row -> LDS offsets; a corner masked by "zeros" padding reads the zero row
+    __device__ __forceinline__ void relocate(uint32_t (&off)[4]) const
+    {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) off[c] = off[c] == kMaskedOffset ? zero : off[c] + base;
+    }
+};
+template <typename TV, int VEC, int BLK>
+__device__ __forceinline__ CoarseStage stage_coarse_levels(const LevelTab *tab, const Params &p, rsrc_t rs, uint32_t plane_row_bytes, size_t lds_off)
+{
+    constexpr uint32_t kPiece = VEC * sizeof(TV);  // bytes a lane loads of a row
+    CoarseStage cs;
+    cs.row_bytes = (uint32_t)p.D * (uint32_t)sizeof(TV);
+    cs.base = (uint32_t)((lds_off + 127) / 128 * 128);
+    const CoarseLevels cl = coarse_levels(tab, p.L, cs.row_bytes, p.lds_lev_bytes);
+    cs.first = cl.first;
+    cs.zero = cs.base + (uint32_t)cl.pixels * cs.row_bytes;
+    const int ppr = (int)(cs.row_bytes / kPiece);  // pieces per row
+    const int npieces = cl.pixels * ppr;
+    const float inv_ppr = 1.0f / (float)ppr;
+    const uint32_t first_row = (uint32_t)(cl.first < p.L ? tab->start[cl.first] : 0);
+    using RLV = RawLoad<kPiece>;
+    const int tid = threadIdx.x;
+    if (tid == 0) *gather_work_counter() = 0;
+    for (int i = tid; i < npieces; i += BLK) {
+        const int r = div_small(i, ppr, inv_ppr), c = i - imul24(r, ppr);
+        const typename RLV::type v = RLV::load(rs, mul24(first_row + (uint32_t)r, plane_row_bytes) + (uint32_t)c * kPiece);
+        *reinterpret_cast<typename RLV::type *>(msda_smem + cs.base + (uint32_t)i * kPiece) = v;
+    }
+    for (int i = tid; i < ppr; i += BLK) {
+        typename RLV::type z{};
+        *reinterpret_cast<typename RLV::type *>(msda_smem + cs.zero + (uint32_t)i * kPiece) = z;
+    }
+    __syncthreads();
+    return cs;
 }
 // VEC consecutive elements of an LDS-resident row at byte offset `off` of the workgroup's LDS, widened
 template <typename T, int VEC> __device__ __forceinline__ void lds_row(uint32_t off, typename Traits<T>::acc (&dst)[VEC])
@@ -218,7 +285,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     // rocprofv3 runs on different boxes had called it noise.)  Plain operator, one channel chunk, all L * P samples
     // parked at once, at most kPre per lane.
     constexpr int kPre = 2;
-    const bool pre = !FUSED && nchan_chunks == 1 && p.sc >= p.LP && UPW * p.LP <= kPre * kWave;
+    // (not with LDS-served levels: the wave does not know its first queries before the staging barrier)
+    const bool pre = !FUSED && !LDSL && nchan_chunks == 1 && p.sc >= p.LP && UPW * p.LP <= kPre * kWave;
     Pack<T, 2> pxy[kPre];
     T pa[kPre];
 #pragma unroll
@@ -239,38 +307,29 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     __syncthreads();
     // LDSL: levels [fl, L) live in LDS behind the records, rows D * sizeof(TV) bytes apart, then one row of zeros
     // (what a corner masked by "zeros" padding reads)
-    int fl = p.L;
-    uint32_t lev_base = 0, lev_zero = 0;
-    constexpr uint32_t kPiece = VEC * sizeof(TV);  // bytes a lane loads of a row
-    const uint32_t lrow_bytes = (uint32_t)p.D * (uint32_t)sizeof(TV);
-    if constexpr (LDSL) {
-        lev_base = (uint32_t)((kGatherLdsFixed + (size_t)NU * scp * (sizeof(uint4) + sizeof(Rec4<A>)) + 127) / 128 * 128);
-        const CoarseLevels cl = coarse_levels(tab, p.L, lrow_bytes, p.lds_lev_bytes);
-        fl = cl.first;
-        lev_zero = lev_base + (uint32_t)cl.pixels * lrow_bytes;
-        const int ppr = (int)(lrow_bytes / kPiece);  // pieces per row (<= G)
-        const int npieces = cl.pixels * ppr;
-        const float inv_ppr = 1.0f / (float)ppr;
-        const uint32_t first_row = (uint32_t)(fl < p.L ? tab->start[fl] : 0);
-        using RLV = RawLoad<kPiece>;
-        for (int i = tid; i < npieces; i += BLK) {
-            const int r = div_small(i, ppr, inv_ppr), c = i - imul24(r, ppr);
-            const typename RLV::type v = RLV::load(rs, mul24(first_row + (uint32_t)r, row_bytes) + (uint32_t)c * kPiece);
-            *reinterpret_cast<typename RLV::type *>(msda_smem + lev_base + (uint32_t)i * kPiece) = v;
-        }
-        for (int i = tid; i < ppr; i += BLK) {
-            typename RLV::type z{};
-            *reinterpret_cast<typename RLV::type *>(msda_smem + lev_zero + (uint32_t)i * kPiece) = z;
-        }
-        __syncthreads();
-    }
+    CoarseStage cs{p.L, 0, 0, (uint32_t)p.D * (uint32_t)sizeof(TV)};
+    if constexpr (LDSL)
+        cs = stage_coarse_levels<TV, VEC, BLK>(tab, p, rs, row_bytes, kGatherLdsFixed + (size_t)NU * scp * (sizeof(uint4) + sizeof(Rec4<A>)));
+    const int fl = cs.first;
 
-    for (int qc = slot * p.qw; qc < qc_end; ++qc) {
-        const int wq0 = qc * NU + wave * UPW;  // first query of this wave
-        if (wq0 >= p.Q) break;                 // wave-uniform
+    // LDSL: the workgroup's queries [q_lo, q_hi) go to its waves slice by slice (next_slice)
+    const int q_lo = imul24(slot * p.qw, NU), q_hi = min(p.Q, imul24(qc_end, NU));
+    const int q_end_ = LDSL ? q_hi : p.Q;  // queries beyond it are not this workgroup's
+    if constexpr (LDSL) stagger_wave(wave, p.lds_stagger);
+    for (int it = 0;; ++it) {
+        int wq0;  // first query of this wave (wave-uniform)
+        if constexpr (LDSL) {
+            wq0 = q_lo + next_slice(lane) * UPW;
+            if (wq0 >= q_hi) break;
+        } else {
+            const int qc = slot * p.qw + it;
+            if (qc >= qc_end) break;
+            wq0 = qc * NU + wave * UPW;
+            if (wq0 >= p.Q) break;
+        }
         const int q = wq0 + wunit;
-        const bool unit_ok = q < p.Q;
-        const bool use_pre = pre && qc == slot * p.qw;
+        const bool unit_ok = q < (LDSL ? q_hi : p.Q);
+        const bool use_pre = pre && it == 0;
         for (int cc = 0; cc < nchan_chunks; ++cc) {
             const int c0 = (cc * GH + j) * VEC;
             const bool lane_ok = unit_ok && (c0 < p.D);
@@ -292,7 +351,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                         const int fu = div_small(f, sc, inv_sc);
                         const int sl = f - imul24(fu, sc);
                         const int fq = wq0 + fu;
-                        if (fq < p.Q) {
+                        if (fq < q_end_) {
                             const int l = div_small(sl, p.P, inv_P);
                             const int sidx = imul24(fq, HLP) + sl;
                             const A ox = TR::to_acc(loc[3 * sidx]), oy = TR::to_acc(loc[3 * sidx + 1]);
@@ -332,7 +391,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                     const int fu = div_small(f, sc, inv_sc);
                     const int sl = s0 + (f - imul24(fu, sc));
                     const int fq = wq0 + fu;
-                    if (fq < p.Q) {
+                    if (fq < q_end_) {
                         const int l = div_small(sl, p.P, inv_P);
                         const int sidx = imul24(fq, HLP) + sl;
                         A sx, sy, a;
@@ -353,9 +412,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                         }
                         Taps<A> t;
                         if (LDSL && l >= fl) {  // an LDS-resident level: offsets into the workgroup's copy
-                            make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l] - tab->start[fl], p.zeros, p.align, lrow_bytes, t);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) t.off[c] = t.off[c] == kMaskedOffset ? lev_zero : t.off[c] + lev_base;
+                            make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l] - tab->start[fl], p.zeros, p.align, cs.row_bytes, t);
+                            cs.relocate(t.off);
                         } else {
                             make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l], p.zeros, p.align, row_bytes, t);
                         }
@@ -466,13 +524,15 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
 // PAIR: as in the forward — the value rows come from the x-pair table, the unit's left half of lanes takes the x0
 // corners, the right half the x1 corners; the three results are linear in the four dot products, so each half forms
 // its share and the usual reduction over the unit's lanes adds them up.
-template <typename T, int VEC, int G, bool FUSED, typename TV = T, bool PAIR = false>
-__global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
+// LDSL (BLK = kBlockLds): the coarsest levels served from LDS, as in the forward (reduce-scatter units only).
+template <typename T, int VEC, int G, bool FUSED, typename TV = T, bool PAIR = false, int BLK = kBlock, bool LDSL = false>
+__global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
-    constexpr int NU = kBlock / G;
+    static_assert(!LDSL || (!PAIR && !FUSED && VEC != 1 && sizeof(A) == 4 && (G == 4 || G == 8)), "LDS-served levels: plain reduce-scatter units");
+    constexpr int NU = BLK / G;
     constexpr int UPW = kWave / G;
     constexpr int GH = PAIR ? G / 2 : G;  // lanes across one row's channels
     // units of 4 / 8 lanes hand every sample's dot products to ONE owner lane (reduce-scatter) instead of all-reducing
@@ -515,7 +575,8 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
 
     // the workgroup's first chunk of samples requested before the level table is waited for, as in the forward
     constexpr int kPre = 2;
-    const bool pre = !FUSED && p.sc >= p.LP && UPW * p.LP <= kPre * kWave;
+    // (not with LDS-served levels: the wave does not know its first queries before the staging barrier)
+    const bool pre = !FUSED && !LDSL && p.sc >= p.LP && UPW * p.LP <= kPre * kWave;
     Pack<T, 2> pxy[kPre];
     T pa[kPre];
 #pragma unroll
@@ -534,13 +595,35 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
     }
     load_level_table(tab, p.shapes, p.L);
     __syncthreads();
+    CoarseStage cs{p.L, 0, 0, (uint32_t)p.D * (uint32_t)sizeof(TV)};
+    if constexpr (LDSL)
+        cs = stage_coarse_levels<TV, VEC, BLK>(tab, p, rs, row_bytes, kGatherLdsFixed + (size_t)NU * scp * (sizeof(uint4) + sizeof(Rec4<A>)));
+    // levels [fl, L) are SERVED from LDS: the first staged level whose first sample starts an exchange batch of G samples
+    // in every trip (P = 4 / 8: every level; a staged level in front of it is simply not used)
+    int fl = cs.first;
+    if constexpr (LDSL) {
+        while (fl < p.L && (imul24(fl, p.P) % G) != 0) ++fl;
+        if (p.sc < p.LP && (p.sc % G) != 0) fl = p.L;
+    }
 
-    for (int qc = slot * p.qw; qc < qc_end; ++qc) {
-        const int wq0 = qc * NU + wave * UPW;
-        if (wq0 >= p.Q) break;
+    // LDSL: the workgroup's queries [q_lo, q_hi) go to its waves slice by slice (next_slice)
+    const int q_lo = imul24(slot * p.qw, NU), q_hi = min(p.Q, imul24(qc_end, NU));
+    const int q_end_ = LDSL ? q_hi : p.Q;  // queries beyond it are not this workgroup's
+    if constexpr (LDSL) stagger_wave(wave, p.lds_stagger);
+    for (int it = 0;; ++it) {
+        int wq0;  // first query of this wave (wave-uniform)
+        if constexpr (LDSL) {
+            wq0 = q_lo + next_slice(lane) * UPW;
+            if (wq0 >= q_hi) break;
+        } else {
+            const int qc = slot * p.qw + it;
+            if (qc >= qc_end) break;
+            wq0 = qc * NU + wave * UPW;
+            if (wq0 >= p.Q) break;
+        }
         const int q = wq0 + wunit;
-        const bool unit_ok = q < p.Q;
-        const bool use_pre = pre && qc == slot * p.qw;
+        const bool unit_ok = q < (LDSL ? q_hi : p.Q);
+        const bool use_pre = pre && it == 0;
         for (int s0 = 0; s0 < p.LP; s0 += p.sc) {
             const int sc = min(p.sc, p.LP - s0);
             const float inv_sc = 1.0f / (float)sc;
@@ -553,7 +636,7 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                     const int fu = div_small(f, sc, inv_sc);
                     const int sl = f - imul24(fu, sc);
                     const int fq = wq0 + fu;
-                    if (fq < p.Q) {
+                    if (fq < q_end_) {
                         const int l = div_small(sl, p.P, inv_P);
                         const int sidx = imul24(fq, HLP) + sl;
                         const A ox = TR::to_acc(loc[3 * sidx]), oy = TR::to_acc(loc[3 * sidx + 1]);
@@ -594,7 +677,7 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                 const int fu = div_small(f, sc, inv_sc);
                 const int sl = s0 + (f - imul24(fu, sc));
                 const int fq = wq0 + fu;
-                if (fq < p.Q) {
+                if (fq < q_end_) {
                     const int l = div_small(sl, p.P, inv_P);
                     const int sidx = imul24(fq, HLP) + sl;
                     const int lh = tab->h[l], lw = tab->w[l];
@@ -618,7 +701,12 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                         a = TR::to_acc(attn[sidx]);
                     }
                     Taps<A> t;
-                    make_taps<A>(px, py, lh, lw, tab->start[l], p.zeros, p.align, row_bytes, t);
+                    if (LDSL && l >= fl) {  // an LDS-served level: offsets into the workgroup's copy
+                        make_taps<A>(px, py, lh, lw, tab->start[l] - tab->start[cs.first], p.zeros, p.align, cs.row_bytes, t);
+                        cs.relocate(t.off);
+                    } else {
+                        make_taps<A>(px, py, lh, lw, tab->start[l], p.zeros, p.align, row_bytes, t);
+                    }
                     const A sx = p.align ? (A)(lw - 1) : (A)lw;
                     const A sy = p.align ? (A)(lh - 1) : (A)lh;
                     Rec4<A> r;
@@ -746,29 +834,39 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                         const bool lane_in = c0 < p.D;
                         const uint32_t lo = lane_in ? (uint32_t)c0 * (uint32_t)sizeof(TV) : 0u;
                         Pack<T, VEC> gp;
-    #pragma unroll
+#pragma unroll
                         for (int i = 0; i < VEC; ++i) gp.v[i] = TR::from_acc((A)0);
                         if (lane_in) gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
                         A g[VEC];
-    #pragma unroll
+#pragma unroll
                         for (int i = 0; i < VEC; ++i) g[i] = TR::to_acc(gp.v[i]);
                         using RLV = RawLoad<sizeof(TV) * VEC>;
-                        for (int sb = 0; sb < sc; sb += G) {
+                        // one exchange: the samples [sb, sb + G) of this trip, their rows from memory or (LDS: a compile-time
+                        // tag, so that each loop below is straight-line code) from the LDS-resident levels
+                        auto batch = [&](int sb, auto lds_tag) {
+                            constexpr bool kLds = decltype(lds_tag)::value;
                             float e[UB][4];
-    #pragma unroll
+#pragma unroll
                             for (int hb = 0; hb < NH; ++hb) {
                                 Pack<TV, VEC> v[UB][4];  // (kept packed until they are consumed)
-    #pragma unroll
+#pragma unroll
                                 for (int u = 0; u < UB; ++u) {
                                     const uint4 o = uo[min(sb + hb * UB + u, sc - 1)];  // tail: the last sample again, not stored
-                                    v[u][0] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.x + lo));
-                                    v[u][1] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.y + lo));
-                                    v[u][2] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.z + lo));
-                                    v[u][3] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.w + lo));
+                                    if constexpr (kLds) {
+                                        v[u][0] = *reinterpret_cast<const Pack<TV, VEC> *>(msda_smem + o.x + lo);
+                                        v[u][1] = *reinterpret_cast<const Pack<TV, VEC> *>(msda_smem + o.y + lo);
+                                        v[u][2] = *reinterpret_cast<const Pack<TV, VEC> *>(msda_smem + o.z + lo);
+                                        v[u][3] = *reinterpret_cast<const Pack<TV, VEC> *>(msda_smem + o.w + lo);
+                                    } else {
+                                        v[u][0] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.x + lo));
+                                        v[u][1] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.y + lo));
+                                        v[u][2] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.z + lo));
+                                        v[u][3] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o.w + lo));
+                                    }
                                 }
-    #pragma unroll
+#pragma unroll
                                 for (int u = 0; u < UB; ++u) {
-    #pragma unroll
+#pragma unroll
                                     for (int k = 0; k < 4; ++k) {
                                         float d = 0.0f;
                                         if constexpr (TR::kDot2 && (VEC % 2) == 0 && sizeof(TV) == sizeof(T)) {
@@ -778,10 +876,10 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                                                 P2 p[VEC / 2];
                                             };
                                             const Pairs gq = __builtin_bit_cast(Pairs, gp), vq = __builtin_bit_cast(Pairs, v[u][k]);
-    #pragma unroll
+#pragma unroll
                                             for (int i = 0; i < VEC / 2; ++i) d = TR::dot2(gq.p[i], vq.p[i], d);
                                         } else {
-    #pragma unroll
+#pragma unroll
                                             for (int i = 0; i < VEC; ++i) d = fma_t(g[i], Traits<TV>::to_acc(v[u][k].v[i]), d);
                                         }
                                         if constexpr (G == 8) {
@@ -805,7 +903,13 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                             res.v[2] = r.v[3] * (wx0 * (dd[2] - dd[0]) + dx * (dd[3] - dd[1]));
                             res.v[3] = (A)0;
                             if (s < sc) up[s] = res;
-                        }
+                        };
+                        // samples [0, s_lds) of this trip gather from memory, [s_lds, sc) from the LDS-resident levels (the
+                        // boundary is a multiple of G: `fl` was chosen that way)
+                        const int s_lds = LDSL ? min(max(imul24(fl, p.P) - s0, 0), sc) : sc;
+                        for (int sb = 0; sb < s_lds; sb += G) batch(sb, std::false_type{});
+                        if constexpr (LDSL)
+                            for (int sb = s_lds; sb < sc; sb += G) batch(sb, std::true_type{});
                     }
                 } else if (nchan_chunks == 1) {
                     // fast path: grad_out row in registers, UB samples' rows (4 * UB loads) in flight at once
@@ -962,7 +1066,7 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_sample_kernel(const Params p)
                 const int fu = div_small(f, sc, inv_sc);
                 const int sl = s0 + (f - imul24(fu, sc));
                 const int fq = wq0 + fu;
-                if (fq < p.Q) {
+                if (fq < q_end_) {
                     const int sidx = imul24(fq, HLP) + sl;
                     const Rec4<A> res = w_rec[imul24(fu, scp) + (sl - s0)];
                     if constexpr (FUSED) {

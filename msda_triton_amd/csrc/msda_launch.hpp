@@ -168,6 +168,8 @@ inline void plan_gather(int NU, int LP, size_t acc_bytes, int &sc, size_t &lds, 
 // ---- the gather kernels with the coarsest levels in LDS (msda_kernels.hpp, LDSL): ONE 1024-thread workgroup per CU,
 // every (b, h) plane cut into as many runs of query chunks as fill the chip once ----
 int option_lds_levels();  // 0: never, 1: where lds_levels_plan says so, 2: wherever the kernels exist
+int option_lds_budget();  // dev knob: cap on the bytes of LDS-resident levels (-1: none)
+int option_lds_stagger();  // dev knob: start-up stagger of an LDSL workgroup's waves, in units of 64 cycles per wave
 int device_cu_count();    // CUs of the current device (cached; msda_api.hip)
 constexpr size_t kRecordLdsBudgetLds = 72 * 1024;  // the records of 16 waves
 
@@ -196,6 +198,7 @@ template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(c
     // the whole plane at most; the kernel takes the longest suffix of the level list that fits
     const long long plane = (long long)p.I * (long long)row;
     pl.lev_bytes = (int)(room < plane ? (room < 0 ? 0 : room) : plane);
+    if (option_lds_budget() >= 0 && option_lds_budget() < pl.lev_bytes) pl.lev_bytes = option_lds_budget();
     pl.lds = lev_base + (size_t)pl.lev_bytes + (row + 15) / 16 * 16;
     const long long wgs = (long long)npairs * pl.slots, rounds = (wgs + ncu - 1) / ncu;
     const int opt = option_lds_levels();
@@ -207,21 +210,28 @@ template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(c
 
 template <typename T, int VEC, int G, int MODE, typename TV> inline int launch_gather_lds(Params &p, const LdsLevelsPlan &pl, hipStream_t stream)
 {
-    static_assert(MODE == 0, "LDS-served levels: plain forward so far");
+    static_assert(MODE == 0 || MODE == 1, "LDS-served levels: the plain operator's forward and sample-gradient kernels");
     p.sc = pl.sc;
     p.nqc = pl.nqc;
     p.qw = pl.qw;
     p.lds_lev_bytes = pl.lev_bytes;
+    p.lds_stagger = option_lds_stagger();
     dim3 grid;
     if (!plane_grid(p, p.B * p.H, pl.slots, grid)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
     static std::atomic<uint64_t> big_lds_done{0};
-    const ProfileScope prof("msda_fwd_kernel", stream);
-    auto kernel = msda_fwd_kernel<T, VEC, G, false, TV, false, kBlockLds, true>;
-    allow_big_lds(kernel, big_lds_done);
-    hipLaunchKernelGGL(kernel, grid, dim3(kBlockLds), pl.lds, stream, p);
+    const ProfileScope prof(MODE == 0 ? "msda_fwd_kernel" : "msda_bwd_sample_kernel", stream);
+    if constexpr (MODE == 0) {
+        auto kernel = msda_fwd_kernel<T, VEC, G, false, TV, false, kBlockLds, true>;
+        allow_big_lds(kernel, big_lds_done);
+        hipLaunchKernelGGL(kernel, grid, dim3(kBlockLds), pl.lds, stream, p);
+    } else {
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, false, TV, false, kBlockLds, true>;
+        allow_big_lds(kernel, big_lds_done);
+        hipLaunchKernelGGL(kernel, grid, dim3(kBlockLds), pl.lds, stream, p);
+    }
     return (int)hipGetLastError();
 }
 
@@ -229,7 +239,8 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, bool PAIR = fal
 {
     using A = typename Traits<T>::acc;
     constexpr int NU = kBlock / G;
-    if constexpr (MODE == 0 && !PAIR && VEC * sizeof(T) == 16 && G <= 16) {
+    // (the sample-gradient kernel has the variant for its reduce-scatter units: float accumulation, 4 or 8 lanes)
+    if constexpr (!PAIR && VEC * sizeof(T) == 16 && ((MODE == 0 && G <= 16) || (MODE == 1 && sizeof(A) == 4 && (G == 4 || G == 8)))) {
         const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, false);
         if (pl.use) return launch_gather_lds<T, VEC, G, MODE, TV>(p, pl, stream);
     }

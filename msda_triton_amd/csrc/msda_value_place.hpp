@@ -133,12 +133,13 @@ template <typename T, int TB> __global__ __launch_bounds__(TB) void msda_cell_pl
                     }
                 }
                 const int my = r * nw + wid;
-                while (__hip_atomic_load(&s_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != my) __builtin_amdgcn_s_sleep(1);
+                while (__hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != my) __builtin_amdgcn_s_sleep(1);
                 int pos[NS];
 #pragma unroll
                 for (int j = 0; j < NS; ++j) pos[j] = rel[j] != 0xFFFFFFFFu ? atomicAdd(&s_gb[rel[j]], 1) : -1;
-                // (DS operations of one wave execute in order: the hand-over is behind the atomics)
-                if ((tid & (kWave - 1)) == 0) __hip_atomic_store(&s_turn, my + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // (acquire on the spin, release on the hand-over: the compiler may not move the cursor atomics across either —
+                // ADVICE r04; the hardware runs a wave's DS operations in order anyway, so this costs one s_waitcnt lgkmcnt(0))
+                if ((tid & (kWave - 1)) == 0) __hip_atomic_store(&s_turn, my + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {  // the records, after the turn
                     if (pos[j] < 0) continue;

@@ -207,12 +207,13 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
                 ok[k] = qs[k] >= 0 && sample_cell<A>(TR::to_acc(xys[k].v[0]), TR::to_acc(xys[k].v[1]), lh, lw, 0, 0, 0, p.zeros,
                                                      p.align, cell[k], cellw, dx[k], dy[k]) && cell[k] < ncl;
             }
-            while (__hip_atomic_load(&s_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != my) __builtin_amdgcn_s_sleep(1);
+            while (__hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != my) __builtin_amdgcn_s_sleep(1);
             int pos[N];
 #pragma unroll
             for (int k = 0; k < N; ++k) pos[k] = ok[k] ? atomicAdd(&s_off[cell[k]], 1) : -1;
-            // (DS operations of one wave execute in order: the hand-over is behind the atomics)
-            if ((tid & (kWave - 1)) == 0) __hip_atomic_store(&s_turn, my + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (acquire on the spin, release on the hand-over: the compiler may not move the cursor atomics across either —
+                // ADVICE r04; the hardware runs a wave's DS operations in order anyway, so this costs one s_waitcnt lgkmcnt(0))
+            if ((tid & (kWave - 1)) == 0) __hip_atomic_store(&s_turn, my + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 if (pos[k] < 0) continue;

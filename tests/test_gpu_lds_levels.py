@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import MODES, mode_key
-from test_gpu_parity import DEV, FWD_TOL, rand_case
+from test_gpu_parity import BWD_TOL, DEV, FWD_TOL, rand_case
 
 pytestmark = pytest.mark.gpu
 
@@ -57,6 +57,43 @@ def test_lds_served_levels_forward_is_bit_identical(oracle, name, pm, ac):
     if td in FWD_TOL:
         ref = oracle.forward(c["value"], c["shapes"], c["loc"], c["attn"], pm, ac)
         np.testing.assert_allclose(lds.cpu().numpy(), ref, **FWD_TOL[td])
+
+
+def _backward(c, td, pm, ac, opt):
+    from msda_triton_amd import _lib, multiscale_deformable_attention
+    old = _lib.get_option("lds_levels")
+    _lib.set_option("lds_levels", opt)
+    try:
+        v = torch.from_numpy(c["value"]).to(DEV, td).requires_grad_(True)
+        l = torch.from_numpy(c["loc"]).to(DEV, td).requires_grad_(True)
+        a = torch.from_numpy(c["attn"]).to(DEV, td).requires_grad_(True)
+        s = torch.from_numpy(c["shapes"]).to(DEV)
+        out = multiscale_deformable_attention(v, s, l, a, pm, ac)
+        out.backward(torch.from_numpy(c["grad_out"]).to(DEV, td))
+        torch.cuda.synchronize()
+        return out.detach(), v.grad, l.grad, a.grad
+    finally:
+        _lib.set_option("lds_levels", old)
+
+
+@pytest.mark.parametrize("name", list(CASES), ids=list(CASES))
+@pytest.mark.parametrize("pm,ac", MODES, ids=[mode_key(*m) for m in MODES])
+def test_lds_served_levels_backward_is_bit_identical(oracle, name, pm, ac):
+    """grad_loc / grad_attn from the sample-gradient kernel with LDS-served levels (the units of 4 / 8 lanes with float
+    accumulation have the variant; the others run the plain kernel under either option)"""
+    B, Q, H, D, levels, P, td = CASES[name]
+    c = rand_case(np.random.default_rng(zlib.crc32(name.encode()) + 1), B, Q, H, D, levels, P,
+                  dtype=np.float64 if td == torch.float64 else np.float32)
+    plain = _backward(c, td, pm, ac, 0)
+    lds = _backward(c, td, pm, ac, 2)
+    for nm, x, y in zip(("out", "grad_value", "grad_loc", "grad_attn"), plain, lds):
+        assert torch.equal(x, y), f"{nm}: max diff {(x.double() - y.double()).abs().max().item():.3e}"
+    if td in BWD_TOL:
+        from conftest import kink_mask
+        _, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], pm, ac)
+        np.testing.assert_allclose(lds[3].cpu().numpy(), r_ga, **BWD_TOL[td])
+        keep = ~kink_mask(c["loc"], c["shapes"], ac)
+        np.testing.assert_allclose(np.where(keep, lds[2].cpu().numpy(), 0), np.where(keep, r_gl, 0), **BWD_TOL[td])
 
 
 def test_lds_served_levels_are_chosen_by_default_at_c2_size():
