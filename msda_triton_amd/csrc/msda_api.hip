@@ -33,7 +33,7 @@ static std::atomic<int> g_profile{0};
 static std::atomic<int> g_records_in_grads{1};
 static std::atomic<int> g_lds_levels{1};
 static std::atomic<int> g_lds_budget{-1};
-static std::atomic<int> g_lds_stagger{8};
+static std::atomic<int> g_lds_stagger{0};  // (measured 0 / 4 / 12 / 24 at c2 @ 10k: 0 is fastest — the work counter desynchronises the waves by itself)
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
 // Per THREAD, because the fork (record on the user's stream, wait on the side stream) and the join are two calls

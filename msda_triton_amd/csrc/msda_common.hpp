@@ -67,6 +67,50 @@ __device__ __forceinline__ double fmin_t(double a, double b) { return __builtin_
 __device__ __forceinline__ float fmax_t(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double fmax_t(double a, double b) { return __builtin_fmax(a, b); }
 
+// acc[i] += w[0] v0[i] + w[1] v1[i] + w[2] v2[i] + w[3] v3[i], four chained FMAs per channel.  fp32: two channels per
+// instruction (v_pk_fma_f32 with the weight broadcast by op_sel) — every vector instruction of a wave64 holds its SIMD
+// for four cycles on gfx950, packed or not (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1 quad-cycle, round 5), so the pair
+// halves the blend's share of the forward's issue time.  Written as 2-vectors by hand: the SLP vectoriser finds the
+// same pairs but also builds others out of register shuffles (the fp32 translation units run without it).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int VEC>
+__device__ __forceinline__ void blend4(float (&acc)[VEC], const float (&w)[4], const float (&v0)[VEC], const float (&v1)[VEC],
+                                       const float (&v2)[VEC], const float (&v3)[VEC])
+{
+    if constexpr ((VEC % 2) == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; i += 2) {
+            f32x2 a = {acc[i], acc[i + 1]};
+            a = __builtin_elementwise_fma(f32x2{w[0], w[0]}, f32x2{v0[i], v0[i + 1]}, a);
+            a = __builtin_elementwise_fma(f32x2{w[1], w[1]}, f32x2{v1[i], v1[i + 1]}, a);
+            a = __builtin_elementwise_fma(f32x2{w[2], w[2]}, f32x2{v2[i], v2[i + 1]}, a);
+            a = __builtin_elementwise_fma(f32x2{w[3], w[3]}, f32x2{v3[i], v3[i + 1]}, a);
+            acc[i] = a.x;
+            acc[i + 1] = a.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            acc[i] = fma_t(w[0], v0[i], acc[i]);
+            acc[i] = fma_t(w[1], v1[i], acc[i]);
+            acc[i] = fma_t(w[2], v2[i], acc[i]);
+            acc[i] = fma_t(w[3], v3[i], acc[i]);
+        }
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void blend4(double (&acc)[VEC], const double (&w)[4], const double (&v0)[VEC], const double (&v1)[VEC],
+                                       const double (&v2)[VEC], const double (&v3)[VEC])
+{
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        acc[i] = fma_t(w[0], v0[i], acc[i]);
+        acc[i] = fma_t(w[1], v1[i], acc[i]);
+        acc[i] = fma_t(w[2], v2[i], acc[i]);
+        acc[i] = fma_t(w[3], v3[i], acc[i]);
+    }
+}
+
 // N elements of T with the natural alignment of the whole pack (so one load/store instruction).
 template <typename T, int N> struct alignas(sizeof(T) * N) Pack {
     T v[N];
@@ -175,9 +219,10 @@ __device__ __forceinline__ void load_level_table(LevelTab *tab, const int64_t *s
 // n / d for 0 <= n < 2^22, using a precomputed float reciprocal (exact after the fix-up steps).
 __device__ __forceinline__ int div_small(int n, int d, float inv_d)
 {
+    // (24-bit multiplies: v_mul_lo_u32 runs at a quarter of the rate, and these sit in every sample's phase 1)
     int q = (int)((float)n * inv_d);
-    if (q * d > n) --q;
-    if ((q + 1) * d <= n) ++q;
+    if (imul24(q, d) > n) --q;
+    if (imul24(q + 1, d) <= n) ++q;
     return q;
 }
 
@@ -192,9 +237,20 @@ template <typename A> struct Taps {
     bool gx_on, gy_on;  // location gradient alive (grid_sample border clipping zeroes it)
 };
 
+// a * b + c for a, b < 2^24 in one full-rate instruction (the compiler turns `c + mul24(a, b)` into the quarter-rate
+// v_mad_u64_u32)
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// base / masked: added to every corner's offset / what a corner masked by "zeros" padding gets instead (defaults: the
+// plane itself; the LDSL kernels pass the LDS position of their copy and of its row of zeros)
 template <typename A>
 __device__ __forceinline__ void make_taps(A x, A y, int h, int w, int start, bool zeros, bool align,
-                                          uint32_t row_bytes, Taps<A> &t)
+                                          uint32_t row_bytes, Taps<A> &t, uint32_t base = 0, uint32_t masked = kMaskedOffset)
 {
     const A W = (A)w, Hh = (A)h;
     A px, py;
@@ -214,18 +270,18 @@ __device__ __forceinline__ void make_taps(A x, A y, int h, int w, int start, boo
     const int y0c = (int)fmin_t(fmax_t(y0, (A)0), ym);
     const int y1c = (int)fmin_t(fmax_t(y1, (A)0), ym);
     // 24-bit multiplies are full rate (v_mul_lo_u32 is quarter rate); pixel indices and row sizes are < 2^24 (host check)
-    const uint32_t r0 = (uint32_t)start + mul24((uint32_t)y0c, (uint32_t)w), r1 = (uint32_t)start + mul24((uint32_t)y1c, (uint32_t)w);
-    t.off[0] = mul24(r0 + (uint32_t)x0c, row_bytes);
-    t.off[1] = mul24(r0 + (uint32_t)x1c, row_bytes);
-    t.off[2] = mul24(r1 + (uint32_t)x0c, row_bytes);
-    t.off[3] = mul24(r1 + (uint32_t)x1c, row_bytes);
+    const uint32_t r0 = mad24((uint32_t)y0c, (uint32_t)w, (uint32_t)start), r1 = mad24((uint32_t)y1c, (uint32_t)w, (uint32_t)start);
+    t.off[0] = mad24(r0 + (uint32_t)x0c, row_bytes, base);
+    t.off[1] = mad24(r0 + (uint32_t)x1c, row_bytes, base);
+    t.off[2] = mad24(r1 + (uint32_t)x0c, row_bytes, base);
+    t.off[3] = mad24(r1 + (uint32_t)x1c, row_bytes, base);
     if (zeros) {
         const bool mx0 = (x0 >= (A)0) && (x0 <= xm), mx1 = (x1 >= (A)0) && (x1 <= xm);
         const bool my0 = (y0 >= (A)0) && (y0 <= ym), my1 = (y1 >= (A)0) && (y1 <= ym);
-        if (!(my0 && mx0)) t.off[0] = kMaskedOffset;
-        if (!(my0 && mx1)) t.off[1] = kMaskedOffset;
-        if (!(my1 && mx0)) t.off[2] = kMaskedOffset;
-        if (!(my1 && mx1)) t.off[3] = kMaskedOffset;
+        if (!(my0 && mx0)) t.off[0] = masked;
+        if (!(my0 && mx1)) t.off[1] = masked;
+        if (!(my1 && mx0)) t.off[2] = masked;
+        if (!(my1 && mx1)) t.off[3] = masked;
         t.gx_on = true;
         t.gy_on = true;
     } else {
@@ -268,6 +324,27 @@ template <int G> __device__ __forceinline__ float group_sum(float v)
 // half of the items as soon as that half's partial sums exist (half_step).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float half_step(float v) { return v + dpp_f32<0x141>(v); }  // row_half_mirror partner
+// ... of a value that arrives as two partial sums: x = lo + partner's hi, then x + partner's x = lo + hi + lo' + hi' — two
+// DPP adds, the same count as adding lo + hi first
+__device__ __forceinline__ float half_step2(float lo, float hi)
+{
+    const float x = lo + dpp_f32<0x141>(hi);
+    return x + dpp_f32<0x141>(x);
+}
+// ... written only on lanes 4..7 of every 8 (DPP bank mask 0xA: the banks are groups of four lanes), the others keep
+// `e`: the second half-batch's step lands in the registers of the first without a select per value
+// (Inline assembly, because no builtin writes a DPP result under a bank mask into a register that keeps its other lanes.
+// The hazard pass does not look into it: a DPP operand written by the previous vector instruction needs two wait states
+// — `s_nop 1` in front; and `e` may be read through DPP right behind the LAST of a run of these — kLast adds the wait
+// states there.  volatile keeps the run in program order, so "last" means what it says.)
+template <bool kLast> __device__ __forceinline__ void half_step2_upper(float &e, float lo, float hi)
+{
+    const float x = lo + dpp_f32<0x141>(hi);
+    if constexpr (kLast)
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\ts_nop 1" : "+v"(e) : "v"(x));
+    else
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(e) : "v"(x));
+}
 template <int K> __device__ __forceinline__ void quad_steps(const float (&e)[4][K], int j, float (&out)[K])
 {
     const bool hi2 = (j & 2) != 0, hi1 = (j & 1) != 0;

@@ -175,12 +175,6 @@ struct CoarseStage {
     int first;                  // levels [first, L) are LDS-resident
     uint32_t base, zero;        // LDS byte offsets of the first row and of the row of zeros
     uint32_t row_bytes;         // D * sizeof(TV): distance of two rows in LDS
-    // byte offsets relative to the first staged row -> LDS offsets; a corner masked by "zeros" padding reads the zero row
-    __device__ __forceinline__ void relocate(uint32_t (&off)[4]) const
-    {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) off[c] = off[c] == kMaskedOffset ? zero : off[c] + base;
-    }
 };
 template <typename TV, int VEC, int BLK>
 __device__ __forceinline__ CoarseStage stage_coarse_levels(const LevelTab *tab, const Params &p, rsrc_t rs, uint32_t plane_row_bytes, size_t lds_off)
@@ -285,24 +279,32 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     // rocprofv3 runs on different boxes had called it noise.)  Plain operator, one channel chunk, all L * P samples
     // parked at once, at most kPre per lane.
     constexpr int kPre = 2;
-    // (not with LDS-served levels: the wave does not know its first queries before the staging barrier)
-    const bool pre = !FUSED && !LDSL && nchan_chunks == 1 && p.sc >= p.LP && UPW * p.LP <= kPre * kWave;
+    const bool pre = !FUSED && nchan_chunks == 1 && p.sc >= p.LP && UPW * p.LP <= kPre * kWave;
     Pack<T, 2> pxy[kPre];
     T pa[kPre];
+    // request the sampling points and weights of the wave's units [wq, wq + UPW) (queries below qlim), one sample per
+    // lane and trip
+    auto prefetch = [&](int wq, int qlim) {
 #pragma unroll
-    for (int t = 0; t < kPre; ++t) {
-        pxy[t].v[0] = pxy[t].v[1] = pa[t] = TR::from_acc((A)0);
-        if constexpr (!FUSED) {
-            const int f = lane + t * kWave;
-            const int fu = div_small(f, p.LP, 1.0f / (float)p.LP);
-            const int fq = (slot * p.qw) * NU + wave * UPW + fu;
-            if (pre && f < UPW * p.LP && fq < p.Q) {
-                const int sidx = imul24(fq, HLP) + (f - imul24(fu, p.LP));
-                pxy[t] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
-                pa[t] = attn[sidx];
+        for (int t = 0; t < kPre; ++t) {
+            if constexpr (!FUSED) {
+                const int f = lane + t * kWave;
+                const int fu = div_small(f, p.LP, 1.0f / (float)p.LP);
+                const int fq = wq + fu;
+#ifdef MSDA_DEV  // ablation 1024: no sampling-point loads (whatever the registers hold)
+                if (p.debug & 1024) continue;
+#endif
+                if (f < UPW * p.LP && fq < qlim) {
+                    const int sidx = imul24(fq, HLP) + (f - imul24(fu, p.LP));
+                    pxy[t] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
+                    pa[t] = attn[sidx];
+                }
             }
         }
-    }
+    };
+#pragma unroll
+    for (int t = 0; t < kPre; ++t) pxy[t].v[0] = pxy[t].v[1] = pa[t] = TR::from_acc((A)0);
+    if (!LDSL && pre) prefetch((slot * p.qw) * NU + wave * UPW, p.Q);
     load_level_table(tab, p.shapes, p.L);
     __syncthreads();
     // LDSL: levels [fl, L) live in LDS behind the records, rows D * sizeof(TV) bytes apart, then one row of zeros
@@ -315,11 +317,24 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     // LDSL: the workgroup's queries [q_lo, q_hi) go to its waves slice by slice (next_slice)
     const int q_lo = imul24(slot * p.qw, NU), q_hi = min(p.Q, imul24(qc_end, NU));
     const int q_end_ = LDSL ? q_hi : p.Q;  // queries beyond it are not this workgroup's
-    if constexpr (LDSL) stagger_wave(wave, p.lds_stagger);
+    // LDSL: a wave takes its NEXT slice as soon as phase 1 has consumed the current one's sampling points and requests
+    // that slice's points at once, so that their trip to memory runs under the gather instead of in front of the next
+    // phase 1 (a wave works through ~10 slices one after the other: what bounds these kernels is the latency chain of a
+    // slice, not a pipe — TA 53 %, LDS 35 %, VALU 41 % busy at c2 @ 10k)
+    int t_next = 0;
+    bool have_next = false;
+    if constexpr (LDSL) {
+        stagger_wave(wave, p.lds_stagger);
+        t_next = next_slice(lane);
+        have_next = true;
+        if (pre) prefetch(q_lo + t_next * UPW, q_hi);
+    }
     for (int it = 0;; ++it) {
         int wq0;  // first query of this wave (wave-uniform)
         if constexpr (LDSL) {
-            wq0 = q_lo + next_slice(lane) * UPW;
+            if (!have_next) t_next = next_slice(lane);
+            have_next = false;
+            wq0 = q_lo + t_next * UPW;
             if (wq0 >= q_hi) break;
         } else {
             const int qc = slot * p.qw + it;
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
         }
         const int q = wq0 + wunit;
         const bool unit_ok = q < (LDSL ? q_hi : p.Q);
-        const bool use_pre = pre && it == 0;
+        const bool use_pre = pre && (LDSL || it == 0);
         for (int cc = 0; cc < nchan_chunks; ++cc) {
             const int c0 = (cc * GH + j) * VEC;
             const bool lane_ok = unit_ok && (c0 < p.D);
@@ -411,9 +426,10 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                             a = TR::to_acc(attn[sidx]);
                         }
                         Taps<A> t;
-                        if (LDSL && l >= fl) {  // an LDS-resident level: offsets into the workgroup's copy
-                            make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l] - tab->start[fl], p.zeros, p.align, cs.row_bytes, t);
-                            cs.relocate(t.off);
+                        if constexpr (LDSL) {  // an LDS-served level: offsets into the workgroup's copy (selects, not two code paths)
+                            const bool inl = l >= fl;
+                            make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l] - (inl ? tab->start[cs.first] : 0), p.zeros, p.align,
+                                         inl ? cs.row_bytes : row_bytes, t, inl ? cs.base : 0u, inl ? cs.zero : kMaskedOffset);
                         } else {
                             make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l], p.zeros, p.align, row_bytes, t);
                         }
@@ -433,6 +449,11 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
 #pragma unroll
                     for (int t = 0; t < kPre; ++t)
                         if (lane + t * kWave < UPW * sc) tap_sample(lane + t * kWave, true, pxy[t], pa[t]);
+                    if constexpr (LDSL) {  // (pre: one channel chunk, one trip — this runs once per slice)
+                        t_next = next_slice(lane);
+                        have_next = true;
+                        prefetch(q_lo + t_next * UPW, q_hi);
+                    }
                 } else {
                     for (int f = lane; f < UPW * sc; f += kWave) tap_sample(f, false, pxy[0], pa[0]);
                 }
@@ -461,8 +482,13 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                     } else {
                     // samples [0, s_lds) of this trip gather from memory, [s_lds, sc) from the LDS-resident levels
                     const int s_lds = LDSL ? min(max(imul24(fl, p.P) - s0, 0), sc) : sc;
+#ifdef MSDA_DEV  // ablations (msda_set_option("debug", mask)): 256 no memory gather, 512 no LDS gather
+                    const int s_mem_end = (p.debug & 256) ? 0 : s_lds, s_lds_end = (p.debug & 512) ? s_lds : sc;
+#else
+                    const int s_mem_end = s_lds, s_lds_end = sc;
+#endif
 #pragma unroll 4
-                    for (int s = 0; s < s_lds; ++s) {
+                    for (int s = 0; s < s_mem_end; ++s) {
                         const uint4 o = uo[s];
                         const Rec4<A> w = uw[s];
                         A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
@@ -470,17 +496,11 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                         load_row<TV, VEC>(rs, o.y + lane_off, v1);
                         load_row<TV, VEC>(rs, o.z + lane_off, v2);
                         load_row<TV, VEC>(rs, o.w + lane_off, v3);
-#pragma unroll
-                        for (int i = 0; i < VEC; ++i) {  // four chained FMAs per channel: no product tree to re-pack
-                            acc[i] = fma_t(w.v[0], v0[i], acc[i]);
-                            acc[i] = fma_t(w.v[1], v1[i], acc[i]);
-                            acc[i] = fma_t(w.v[2], v2[i], acc[i]);
-                            acc[i] = fma_t(w.v[3], v3[i], acc[i]);
-                        }
+                        blend4<VEC>(acc, w.v, v0, v1, v2, v3);
                     }
                     if constexpr (LDSL) {
 #pragma unroll 4
-                        for (int s = s_lds; s < sc; ++s) {
+                        for (int s = s_lds; s < s_lds_end; ++s) {
                             const uint4 o = uo[s];
                             const Rec4<A> w = uw[s];
                             A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
@@ -488,13 +508,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                             lds_row<TV, VEC>(o.y + lane_off, v1);
                             lds_row<TV, VEC>(o.z + lane_off, v2);
                             lds_row<TV, VEC>(o.w + lane_off, v3);
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) {
-                                acc[i] = fma_t(w.v[0], v0[i], acc[i]);
-                                acc[i] = fma_t(w.v[1], v1[i], acc[i]);
-                                acc[i] = fma_t(w.v[2], v2[i], acc[i]);
-                                acc[i] = fma_t(w.v[3], v3[i], acc[i]);
-                            }
+                            blend4<VEC>(acc, w.v, v0, v1, v2, v3);
                         }
                     }
                     }
@@ -701,9 +715,10 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                         a = TR::to_acc(attn[sidx]);
                     }
                     Taps<A> t;
-                    if (LDSL && l >= fl) {  // an LDS-served level: offsets into the workgroup's copy
-                        make_taps<A>(px, py, lh, lw, tab->start[l] - tab->start[cs.first], p.zeros, p.align, cs.row_bytes, t);
-                        cs.relocate(t.off);
+                    if constexpr (LDSL) {  // an LDS-served level: offsets into the workgroup's copy (selects, not two code paths)
+                        const bool inl = l >= fl;
+                        make_taps<A>(px, py, lh, lw, tab->start[l] - (inl ? tab->start[cs.first] : 0), p.zeros, p.align,
+                                     inl ? cs.row_bytes : row_bytes, t, inl ? cs.base : 0u, inl ? cs.zero : kMaskedOffset);
                     } else {
                         make_taps<A>(px, py, lh, lw, tab->start[l], p.zeros, p.align, row_bytes, t);
                     }
@@ -868,7 +883,10 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                                 for (int u = 0; u < UB; ++u) {
 #pragma unroll
                                     for (int k = 0; k < 4; ++k) {
-                                        float d = 0.0f;
+                                        // the partial dot product as TWO partial sums (fp32 rows: even and odd channels, two
+                                        // v_pk_fma_f32 for four channels); an 8-lane unit's first exchange step adds them up
+                                        // on the way (half_step2), a 4-lane unit adds them here
+                                        float d_lo = 0.0f, d_hi = 0.0f;
                                         if constexpr (TR::kDot2 && (VEC % 2) == 0 && sizeof(TV) == sizeof(T)) {
                                             // 16-bit rows: straight from the packed pairs (v_dot2c_f32_f16 / _bf16)
                                             using P2 = typename TR::pair_t;
@@ -877,16 +895,28 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                                             };
                                             const Pairs gq = __builtin_bit_cast(Pairs, gp), vq = __builtin_bit_cast(Pairs, v[u][k]);
 #pragma unroll
-                                            for (int i = 0; i < VEC / 2; ++i) d = TR::dot2(gq.p[i], vq.p[i], d);
+                                            for (int i = 0; i < VEC / 2; i += 2) {
+                                                d_lo = TR::dot2(gq.p[i], vq.p[i], d_lo);
+                                                if (i + 1 < VEC / 2) d_hi = TR::dot2(gq.p[i + 1], vq.p[i + 1], d_hi);
+                                            }
+                                        } else if constexpr ((VEC % 2) == 0) {
+                                            f32x2 a2 = {0.0f, 0.0f};
+#pragma unroll
+                                            for (int i = 0; i < VEC; i += 2)
+                                                a2 = __builtin_elementwise_fma(f32x2{g[i], g[i + 1]},
+                                                                               f32x2{Traits<TV>::to_acc(v[u][k].v[i]), Traits<TV>::to_acc(v[u][k].v[i + 1])}, a2);
+                                            d_lo = a2.x;
+                                            d_hi = a2.y;
                                         } else {
 #pragma unroll
-                                            for (int i = 0; i < VEC; ++i) d = fma_t(g[i], Traits<TV>::to_acc(v[u][k].v[i]), d);
+                                            for (int i = 0; i < VEC; ++i) d_lo = fma_t(g[i], Traits<TV>::to_acc(v[u][k].v[i]), d_lo);
                                         }
                                         if constexpr (G == 8) {
-                                            const float t = half_step(d);
-                                            e[u][k] = (hb == 0 || (j & 4)) ? t : e[u][k];
+                                            if (hb == 0) e[u][k] = half_step2(d_lo, d_hi);
+                                            else if (u == UB - 1 && k == 3) half_step2_upper<true>(e[u][k], d_lo, d_hi);
+                                            else half_step2_upper<false>(e[u][k], d_lo, d_hi);
                                         } else {
-                                            e[u][k] = d;
+                                            e[u][k] = d_lo + d_hi;
                                         }
                                     }
                                 }

@@ -13,16 +13,17 @@ SETS=(
 n=0
 for g in "${SETS[@]}"; do
   rm -rf gpurun_out/pq_$n
-  timeout -k 10 200 rocprofv3 --pmc $g --output-format csv -d gpurun_out/pq_$n -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-strong-c5 $args > gpurun_out/pq_$n.log 2>&1 || echo "set $n failed"
+  timeout -k 10 200 rocprofv3 --pmc $g --output-format csv -d gpurun_out/pq_$n -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-strong-c5 --no-configs --no-do-bench --no-triton $args > gpurun_out/pq_$n.log 2>&1 || echo "set $n failed"
   n=$((n+1))
 done
 python3 - <<'PY'
-import csv, glob, collections, re
+import csv, glob, collections, re, os
+FILTER = os.environ.get('KFILTER', '')
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('gpurun_out/pq_*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'msda' not in k: continue
+        if 'msda' not in k or (FILTER and FILTER not in k): continue
         k = re.sub(r'^void msda::', '', k).split('(')[0]
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k in sorted(acc):
