@@ -299,7 +299,7 @@ extern "C" int msda_profile_read(char *buf, int cap)
 extern "C" int msda_set_option(const char *key, int value)
 {
     if (key && strcmp(key, "xcd_map") == 0) {
-        msda::g_xcd_map.store(value ? 1 : 0, std::memory_order_relaxed);
+        msda::g_xcd_map.store(value == 2 ? 2 : value ? 1 : 0, std::memory_order_relaxed);
         return 0;
     }
     if (key && strcmp(key, "value_path") == 0) {

@@ -404,11 +404,12 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv fd)
 // one L2.  Pure speed: any placement gives the same results.  Returns false for padding blocks.
 // grid3d: the launch used dim3(8, slots, ceil(pairs/8)) (xcd_map) or dim3(slots, pairs), whose
 // linear dispatch order equals the 1-D formula below, so no integer division is needed.
-__device__ __forceinline__ bool decode_block(int grid3d, int npairs, int slots, bool xcd_map, int &pair, int &slot)
+__device__ __forceinline__ bool decode_block(int grid3d, int npairs, int slots, int xcd_map, int &pair, int &slot)
 {
     if (grid3d) {
         if (xcd_map) {
-            pair = (int)(blockIdx.z * 8 + blockIdx.x);
+            // (xcd_map 2: the planes of one XCD rotate through the heads instead of all having the same one)
+            pair = (int)(blockIdx.z * 8 + (xcd_map == 2 ? ((blockIdx.x + blockIdx.z) & 7) : blockIdx.x));
             slot = (int)blockIdx.y;
         } else {
             pair = (int)blockIdx.y;

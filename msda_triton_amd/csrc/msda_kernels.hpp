@@ -130,6 +130,21 @@ __device__ __forceinline__ void pair_offsets(uint32_t (&off)[4], uint32_t entry_
     if (off[3] == off[2] + entry_bytes) off[3] = off[2] + entry_bytes / 2;
 }
 
+#ifdef MSDA_DEV
+// dev builds: a phase clock for the forward kernel (msda_set_option("debug", 2048)): every wave sums the cycles between
+// its stamps per phase and leaves eight floats at the START of `out` (which is garbage afterwards) — tools/phase_clock.py
+#define MSDA_STAMP(var)                                  \
+    do {                                                 \
+        __builtin_amdgcn_sched_barrier(0);               \
+        var = __builtin_amdgcn_s_memtime();              \
+        __builtin_amdgcn_sched_barrier(0);               \
+    } while (0)
+#else
+#define MSDA_STAMP(var) \
+    do {                \
+    } while (0)
+#endif
+
 // LDSL kernels: the workgroup's waves take their work — runs of 64 / G queries out of the workgroup's query range — from
 // a counter in LDS instead of a fixed share, and start it staggered (wave w waits w * Params::lds_stagger * 64 cycles).
 // Sixteen waves released by one barrier otherwise run their phases in lockstep — all wait for their sampling points,
@@ -323,6 +338,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     // slice, not a pipe — TA 53 %, LDS 35 %, VALU 41 % busy at c2 @ 10k)
     int t_next = 0;
     bool have_next = false;
+    [[maybe_unused]] unsigned long long clk_t0 = 0, clk_a = 0, clk_b = 0, clk_c = 0, clk_d = 0, clk_e = 0;
+    [[maybe_unused]] float clk_ph[5] = {0, 0, 0, 0, 0};
+    MSDA_STAMP(clk_t0);
     if constexpr (LDSL) {
         stagger_wave(wave, p.lds_stagger);
         t_next = next_slice(lane);
@@ -331,6 +349,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     }
     for (int it = 0;; ++it) {
         int wq0;  // first query of this wave (wave-uniform)
+        MSDA_STAMP(clk_a);
         if constexpr (LDSL) {
             if (!have_next) t_next = next_slice(lane);
             have_next = false;
@@ -458,6 +477,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                     for (int f = lane; f < UPW * sc; f += kWave) tap_sample(f, false, pxy[0], pa[0]);
                 }
                 wave_lds_sync();
+                MSDA_STAMP(clk_b);
                 // ---- phase 2: gather + blend ----
                 if (lane_ok) {
                     const uint4 *uo = w_off + imul24(wunit, scp);
@@ -487,6 +507,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
 #else
                     const int s_mem_end = s_lds, s_lds_end = sc;
 #endif
+                    // (a rolling window of 16 loads in flight — the next sample's loads issued as soon as the oldest sample's
+                    // rows are blended — measured no faster than "issue 16, wait": 75.2 vs 74.9 us at c2 @ 10k, round 5)
 #pragma unroll 4
                     for (int s = 0; s < s_mem_end; ++s) {
                         const uint4 o = uo[s];
@@ -498,6 +520,10 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                         load_row<TV, VEC>(rs, o.w + lane_off, v3);
                         blend4<VEC>(acc, w.v, v0, v1, v2, v3);
                     }
+#ifdef MSDA_DEV
+                    if (p.debug & 2048) asm volatile("" ::"v"(acc[0]));  // (the clock must see the gathered rows consumed)
+#endif
+                    MSDA_STAMP(clk_c);
                     if constexpr (LDSL) {
 #pragma unroll 4
                         for (int s = s_lds; s < s_lds_end; ++s) {
@@ -525,10 +551,39 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) o.v[i] = TR::from_acc(acc[i]);
                 T *dst = static_cast<T *>(p.out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D + c0;
+#ifdef MSDA_DEV
+                asm volatile("" ::"v"(o.v[0]));
+                MSDA_STAMP(clk_d);
+                if (!(p.debug & 2048))
+#endif
                 store_stream(dst, o);
             }
+            MSDA_STAMP(clk_e);
+#ifdef MSDA_DEV
+            clk_ph[0] += (float)(long long)(clk_b - clk_a);
+            clk_ph[1] += (float)(long long)(clk_c - clk_b);
+            clk_ph[2] += (float)(long long)(clk_d - clk_c);
+            clk_ph[3] += (float)(long long)(clk_e - clk_d);
+            clk_ph[4] += 1.0f;
+#endif
         }
     }
+#ifdef MSDA_DEV
+    if ((p.debug & 2048) && lane == 0) {
+        unsigned long long clk_end;
+        MSDA_STAMP(clk_end);
+        const int wg = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+        float *dbg = reinterpret_cast<float *>(p.out) + ((size_t)wg * (BLK / kWave) + wave) * 8;
+        dbg[0] = clk_ph[0];
+        dbg[1] = clk_ph[1];
+        dbg[2] = clk_ph[2];
+        dbg[3] = (float)(__builtin_amdgcn_s_getreg(0x1814) & 15);  // HW_REG_XCC_ID (in place of the store phase)
+        dbg[4] = clk_ph[4];
+        dbg[5] = (float)(long long)(clk_end - clk_t0);
+        dbg[6] = (float)wg;
+        dbg[7] = 12345.0f;
+    }
+#endif
 }
 
 // ==========================================================================================

@@ -1,0 +1,66 @@
+"""dev tool (needs a library built with -DMSDA_DEV, e.g. msda_triton_amd/libmsda_hip_dev.so copied over the shipped one):
+per-phase cycles of the forward kernel's waves from the in-kernel s_memtime stamps (msda_set_option("debug", 2048)).
+    python tools/phase_clock.py [workload] [k=v ...]"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from msda_triton_amd import _lib, synth  # noqa: E402
+from msda_triton_amd.functional import msda_hip_fwd  # noqa: E402
+
+wl = synth.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 and "=" not in sys.argv[1] else "c2_q10k"]
+for kv in sys.argv[1:]:
+    if "=" in kv:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
+d = synth.make_inputs_torch(wl, "cuda:0", seed=0) if hasattr(synth, "make_inputs_torch") else None
+if d is None:
+    h = synth.make_inputs_numpy(wl, seed=0)
+    dt = getattr(torch, wl.dtype)
+    d = {k: torch.from_numpy(v).to("cuda:0") if k == "shapes" else torch.from_numpy(v).to("cuda:0", dt) for k, v in h.items()}
+import os
+shift = int(os.environ.get("SHIFT", "0"))  # floats: move `value` (and with SHIFT_ALL=1 every tensor) off its allocation's start
+def shifted(t):
+    if not shift or t.dtype == torch.int64:
+        return t
+    buf = torch.empty(t.numel() + shift, dtype=t.dtype, device=t.device)
+    v = buf[shift:].view(t.shape)
+    v.copy_(t)
+    return v
+d["value"] = shifted(d["value"])
+if os.environ.get("SHIFT_ALL"):
+    d["loc"], d["attn"] = shifted(d["loc"]), shifted(d["attn"])
+print("value ptr % 1024 =", d["value"].data_ptr() % 1024, " loc ptr % 1024 =", d["loc"].data_ptr() % 1024)
+for _ in range(3):
+    out = msda_hip_fwd(d["value"], d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
+_lib.set_option("debug", 2048 | _lib.get_option("debug"))
+out = msda_hip_fwd(d["value"], d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
+torch.cuda.synchronize()
+r = out.float().reshape(-1)[: 8 * 65536 * 4].reshape(-1, 8).cpu().numpy()
+r = r[r[:, 7] == 12345.0]
+print("waves", len(r), "slices per wave", r[:, 4].mean())
+names = ["phase1(+wait for points)", "memory gather", "LDS gather"]
+tot = r[:, 5]
+print("wave life cycles: mean %.0f  min %.0f  max %.0f" % (tot.mean(), tot.min(), tot.max()))
+for i, n in enumerate(names):
+    print("  %-26s mean cycles per wave %9.0f  (%.1f %% of life)  per slice %.0f" % (n, r[:, i].mean(), 100 * r[:, i].mean() / tot.mean(), (r[:, i] / np.maximum(r[:, 4], 1)).mean()))
+wg = r[:, 6]
+per_wg = np.array([tot[wg == g].max() for g in np.unique(wg)])
+print("workgroup life (max over its waves): mean %.0f  min %.0f  max %.0f" % (per_wg.mean(), per_wg.min(), per_wg.max()))
+ids = np.unique(wg).astype(int)
+life = {g: tot[wg == g].max() for g in ids}
+by_x, by_xcc = {}, {}
+xcc = {g: int(r[wg == g][0, 3]) for g in ids}
+for g in ids:
+    by_x.setdefault(g % 8, []).append(life[g])
+    by_xcc.setdefault(xcc[g], []).append(life[g])
+print("by linear id % 8:", {int(k): int(np.mean(v)) for k, v in sorted(by_x.items())})
+print("by XCC_ID       :", {int(k): (len(v), int(np.mean(v))) for k, v in sorted(by_xcc.items())})
+order = sorted(ids, key=lambda g: life[g])
+print("fastest:", [(int(g), int(life[g])) for g in order[:6]])
+print("slowest:", [(int(g), int(life[g])) for g in order[-10:]])
+ph = {g: r[wg == g][:, :3].mean(0) for g in order[:3] + order[-3:]}
+for g, v in ph.items():
+    print("  wg %4d phases per wave" % g, v.astype(int))
