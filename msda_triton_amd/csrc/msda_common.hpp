@@ -73,11 +73,13 @@ __device__ __forceinline__ double fmax_t(double a, double b) { return __builtin_
 // halves the blend's share of the forward's issue time.  Written as 2-vectors by hand: the SLP vectoriser finds the
 // same pairs but also builds others out of register shuffles (the fp32 translation units run without it).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int VEC>
+// kPacked: only where the rows ARE fp32 — rows widened from 16 bits take the scalar chain (fp16: v_fma_mix_f32 converts
+// inside the FMA, and the pairs would cost a conversion each: c5's forward 2.99 -> 3.77 ms when they were packed too)
+template <int VEC, bool kPacked>
 __device__ __forceinline__ void blend4(float (&acc)[VEC], const float (&w)[4], const float (&v0)[VEC], const float (&v1)[VEC],
                                        const float (&v2)[VEC], const float (&v3)[VEC])
 {
-    if constexpr ((VEC % 2) == 0) {
+    if constexpr (kPacked && (VEC % 2) == 0) {
 #pragma unroll
         for (int i = 0; i < VEC; i += 2) {
             f32x2 a = {acc[i], acc[i + 1]};
@@ -98,7 +100,7 @@ __device__ __forceinline__ void blend4(float (&acc)[VEC], const float (&w)[4], c
         }
     }
 }
-template <int VEC>
+template <int VEC, bool kPacked>
 __device__ __forceinline__ void blend4(double (&acc)[VEC], const double (&w)[4], const double (&v0)[VEC], const double (&v1)[VEC],
                                        const double (&v2)[VEC], const double (&v3)[VEC])
 {

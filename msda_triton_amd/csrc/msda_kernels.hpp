@@ -518,7 +518,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                         load_row<TV, VEC>(rs, o.y + lane_off, v1);
                         load_row<TV, VEC>(rs, o.z + lane_off, v2);
                         load_row<TV, VEC>(rs, o.w + lane_off, v3);
-                        blend4<VEC>(acc, w.v, v0, v1, v2, v3);
+                        blend4<VEC, sizeof(TV) == sizeof(A)>(acc, w.v, v0, v1, v2, v3);
                     }
 #ifdef MSDA_DEV
                     if (p.debug & 2048) asm volatile("" ::"v"(acc[0]));  // (the clock must see the gathered rows consumed)
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                             lds_row<TV, VEC>(o.y + lane_off, v1);
                             lds_row<TV, VEC>(o.z + lane_off, v2);
                             lds_row<TV, VEC>(o.w + lane_off, v3);
-                            blend4<VEC>(acc, w.v, v0, v1, v2, v3);
+                            blend4<VEC, sizeof(TV) == sizeof(A)>(acc, w.v, v0, v1, v2, v3);
                         }
                     }
                     }
@@ -600,12 +600,14 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
-    static_assert(!LDSL || (!PAIR && !FUSED && VEC != 1 && sizeof(A) == 4 && (G == 4 || G == 8)), "LDS-served levels: plain reduce-scatter units");
+    static_assert(!LDSL || (!PAIR && !FUSED && VEC != 1 && sizeof(A) == 4 && !TR::kDot2 && (G == 4 || G == 8)), "LDS-served levels: plain reduce-scatter units");
     constexpr int NU = BLK / G;
     constexpr int UPW = kWave / G;
     constexpr int GH = PAIR ? G / 2 : G;  // lanes across one row's channels
     // units of 4 / 8 lanes hand every sample's dot products to ONE owner lane (reduce-scatter) instead of all-reducing
-    constexpr bool kScatter = !PAIR && sizeof(A) == 4 && (G == 4 || G == 8);
+    // (16-bit operators keep the all-reduce: with v_dot2c rows the two cost the same instructions, and the all-reduce
+    // measured 5-6 % faster at c3 / c5)
+    constexpr bool kScatter = !PAIR && sizeof(A) == 4 && !TR::kDot2 && (G == 4 || G == 8);
 
     const int slots = (p.nqc + p.qw - 1) / p.qw;
     int pair, slot;
@@ -954,7 +956,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                                                 d_lo = TR::dot2(gq.p[i], vq.p[i], d_lo);
                                                 if (i + 1 < VEC / 2) d_hi = TR::dot2(gq.p[i + 1], vq.p[i + 1], d_hi);
                                             }
-                                        } else if constexpr ((VEC % 2) == 0) {
+                                        } else if constexpr ((VEC % 2) == 0 && sizeof(TV) == sizeof(A)) {
                                             f32x2 a2 = {0.0f, 0.0f};
 #pragma unroll
                                             for (int i = 0; i < VEC; i += 2)
@@ -962,6 +964,14 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                                                                                f32x2{Traits<TV>::to_acc(v[u][k].v[i]), Traits<TV>::to_acc(v[u][k].v[i + 1])}, a2);
                                             d_lo = a2.x;
                                             d_hi = a2.y;
+                                        } else if constexpr ((VEC % 2) == 0) {
+                                            // (rows widened from 16 bits next to fp32 everything else: the same two chains, so
+                                            // that the result is bit-identical to the fp32 kernel's on the rounded rows)
+#pragma unroll
+                                            for (int i = 0; i < VEC; i += 2) {
+                                                d_lo = fma_t(g[i], Traits<TV>::to_acc(v[u][k].v[i]), d_lo);
+                                                d_hi = fma_t(g[i + 1], Traits<TV>::to_acc(v[u][k].v[i + 1]), d_hi);
+                                            }
                                         } else {
 #pragma unroll
                                             for (int i = 0; i < VEC; ++i) d_lo = fma_t(g[i], Traits<TV>::to_acc(v[u][k].v[i]), d_lo);

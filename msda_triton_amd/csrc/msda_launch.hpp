@@ -186,6 +186,10 @@ template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(c
     LdsLevelsPlan pl{};
     size_t rec_lds;
     plan_gather(NU, p.LP, sizeof(A), pl.sc, rec_lds, aux, kRecordLdsBudgetLds);
+    if (pl.sc < p.LP && pl.sc > G) {  // several trips: whole exchange batches of the sample-gradient kernel per trip
+        pl.sc = pl.sc / G * G;
+        rec_lds = kGatherLdsFixed + (size_t)NU * (pl.sc + 1) * (16 + 4 * sizeof(A));
+    }
     const size_t lev_base = (rec_lds + 127) / 128 * 128, row = (size_t)p.D * sizeof(TV);
     const long long room = (long long)kMaxDynLds - (long long)lev_base - (long long)((row + 15) / 16 * 16);
     pl.nqc = (p.Q + NU - 1) / NU;
@@ -240,7 +244,9 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, bool PAIR = fal
     using A = typename Traits<T>::acc;
     constexpr int NU = kBlock / G;
     // (the sample-gradient kernel has the variant for its reduce-scatter units: float accumulation, 4 or 8 lanes)
-    if constexpr (!PAIR && VEC * sizeof(T) == 16 && ((MODE == 0 && G <= 16) || (MODE == 1 && sizeof(A) == 4 && (G == 4 || G == 8)))) {
+    // fp32 operators only: measured at c3 (bf16, 64-byte rows: forward 88 against 86 us) and c5 (fp16, D = 64, L * P = 40 in
+    // three trips: 3.17 against 2.93 ms) the 16-bit operators do not gain
+    if constexpr (!PAIR && sizeof(T) == 4 && sizeof(TV) == 4 && VEC == 4 && ((MODE == 0 && G <= 16) || (MODE == 1 && (G == 4 || G == 8)))) {
         const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, false);
         if (pl.use) return launch_gather_lds<T, VEC, G, MODE, TV>(p, pl, stream);
     }
