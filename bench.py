@@ -458,6 +458,92 @@ def strong_scaling_leg(wl_name, dev, world, rank, use_dist, chunks=None, steps=5
     return out
 
 
+def shard_compute_leg(dev, strong_name, weak_name, ns=(2, 4, 8), steps=5, warmup=2):
+    """The COMPUTE half of the multi-GPU scaling model, measured on one GPU: for N in `ns`, rank 0's
+    rows of the strong-scaling problem (the stress shape: its B*Q rows split N ways) and of the weak-scaling problem
+    (the headline shape: Q x N queries per batch element, B*Q rows per rank) run through the row-sharded operator with
+    every exchange left out (``compute_only_as=(N, 0)``): forward / forward+backward ms and ``t(1) / t_shard(N)`` —
+    the speed-up ceiling before any byte crosses xGMI (strong: ideal N; weak: ideal 1) — next to the bytes of grad_value
+    the rank would take into a sum with its peers."""
+    import dataclasses
+
+    import torch
+    from msda_triton_amd import synth
+    from msda_triton_amd.distributed import (default_overlap_chunks, owners_sum_bytes, row_shard_bounds,
+                                             row_sharded_multiscale_deformable_attention)
+
+    on_gpu = torch.device(dev).type == "cuda"
+
+    def time_shard(wl, world, rank=0, chunks=None):
+        dt = getattr(torch, wl.dtype) if on_gpu else torch.float32
+        rows = wl.B * wl.Q
+        r0, r1 = row_shard_bounds(rows, world, rank)
+        n = r1 - r0
+        g = torch.Generator(device=dev).manual_seed(4321)
+        value = torch.randn(wl.B, wl.I, wl.H, wl.D, device=dev, generator=g).to(dt).requires_grad_(True)
+        pts = torch.rand(n, wl.H, wl.L, wl.P, 2, device=dev, generator=g).to(dt).requires_grad_(True)
+        att = torch.softmax(torch.randn(n, wl.H, wl.L * wl.P, device=dev, generator=g), -1)
+        att = att.reshape(n, wl.H, wl.L, wl.P).to(dt).requires_grad_(True)
+        shapes = torch.tensor(wl.levels, device=dev)
+
+        def fwd():
+            return row_sharded_multiscale_deformable_attention(value, shapes, pts, att, wl.padding_mode, wl.align_corners,
+                                                               inputs_are_sharded=True, num_queries=wl.Q,
+                                                               compute_only_as=(world, rank), overlap_chunks=chunks)
+
+        def step():
+            out = fwd()
+            # (the gradient of this rank's rows only, as the backward slices it: rand_like of the whole result would
+            #  charge the shard for N times its own rows)
+            out.backward(out.detach())
+            value.grad = pts.grad = att.grad = None
+
+        def sync():
+            if on_gpu:
+                torch.cuda.synchronize()
+
+        def timed(fn):
+            for _ in range(warmup):
+                fn()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            sync()
+            return (time.perf_counter() - t0) * 1e3 / steps
+
+        with torch.no_grad():
+            t_f = timed(fwd)
+        t_fb = timed(step)
+        plane = wl.I * wl.H * wl.D * (torch.finfo(dt).bits // 8)
+        return {"rows": n, "fwd_ms": round(t_f, 4), "fwd_bwd_ms": round(t_fb, 4),
+                "owners_sum_bytes": owners_sum_bytes(wl.B, wl.Q, world, rank, plane)}
+
+    out = {"what": "rank 0 of an N-rank row-sharded job on ONE GPU, exchanges left out (compute_only_as): the speed-up "
+                   "ceiling of the compute alone; speedup_ceiling = fwd_bwd t(1) / t_shard(N)"}
+    strong = synth.WORKLOADS[strong_name]
+    weak = synth.WORKLOADS[weak_name]
+    for key, base, scale in (("strong_" + strong_name, strong, False), ("weak_" + weak_name, weak, True)):
+        leg = {}
+        one = time_shard(base, 1)
+        leg["1"] = one
+        for nn in ns:
+            wl = dataclasses.replace(base, Q=base.Q * nn) if scale else base
+            r = time_shard(wl, nn)  # the forward in the pieces the overlapped exchange uses (default_overlap_chunks)
+            r["speedup_ceiling"] = round(one["fwd_bwd_ms"] / r["fwd_bwd_ms"], 3)
+            r["fwd_speedup_ceiling"] = round(one["fwd_ms"] / r["fwd_ms"], 3)
+            r["ideal"] = 1 if scale else nn
+            r["pieces"] = default_overlap_chunks(wl.B * wl.Q, nn)
+            r1 = time_shard(wl, nn, chunks=1)  # ... and as ONE piece (what the single in-place all-gather runs)
+            r["one_piece"] = {"fwd_ms": r1["fwd_ms"], "fwd_bwd_ms": r1["fwd_bwd_ms"],
+                              "speedup_ceiling": round(one["fwd_bwd_ms"] / r1["fwd_bwd_ms"], 3)}
+            leg[str(nn)] = r
+            if on_gpu:
+                torch.cuda.empty_cache()
+        out[key] = leg
+    return out
+
+
 class _StallGuard:
     """N>1 only.  A step that exchanges over RCCL is armed with a deadline; if it stalls, rank 0 prints the result
     measured so far (with config.stalled naming the step) and every rank leaves the process, so a wedged exchange
@@ -503,6 +589,8 @@ def main():
                     help="initialise the process group and use the sharded code path even with one rank (self-test)")
     ap.add_argument("--no-strong-c5", action="store_true", help="skip the strong-scaling leg")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (N=1 only)")
+    ap.add_argument("--no-shard-compute", action="store_true",
+                    help="skip the shard_compute_bound leg (rank 0's compute of an N = 2 / 4 / 8 job on one GPU)")
     ap.add_argument("--no-do-bench", action="store_true", help="skip the do_bench (cold / warm quantiles) leg (N=1 only)")
     ap.add_argument("--no-triton", action="store_true",
                     help="skip the Triton comparator leg (scripts/triton_comparator.py; N=1 only)")
@@ -811,6 +899,11 @@ def main():
         optional("strong_scaling_c5",
                  lambda: strong_scaling_leg(strong_wl, dev, world, rank, use_dist, exchange["chunks"]), True)
         guard.disarm()
+        if on_gpu:
+            torch.cuda.empty_cache()
+    if world == 1 and rank == 0 and not args.no_shard_compute and args.workload in ("c2_q10k", "dryrun"):
+        optional("shard_compute_bound",
+                 lambda: shard_compute_leg(dev, "c5_stress" if on_gpu else "dryrun_strong", args.workload), False)
         if on_gpu:
             torch.cuda.empty_cache()
     if world == 1 and on_gpu and rank == 0 and not args.no_configs and args.workload == "c2_q10k":

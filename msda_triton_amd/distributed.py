@@ -225,12 +225,13 @@ def _owner_groups(B: int, Q: int, group):
 def default_overlap_chunks(rows: int, world: int) -> int:
     """Pieces a rank's rows are computed and exchanged in (the same number on every rank: it follows the nominal shard
     size).  Piece k's exchange runs while piece k + 1 computes, so only the LAST piece's exchange is exposed: more
-    pieces hide more of it, as long as a piece stays worth a message (>= 4 096 rows: 4 MB per peer at c2's 1 KB rows).
-    c2 weak scaling (40 000 rows per rank): 8 pieces (round 3: at most 4); c5 strong scaling over 8 ranks (50 000 rows
-    per rank, 51 MB per peer): 8 pieces, 1/8 of the exchange exposed instead of 1/4."""
+    pieces hide more of it — as long as a piece stays worth a kernel launch: measured on one GPU (bench.py
+    ``shard_compute_bound``, round 5) c2's 40 000 rows per rank in 8 pieces of 5 000 rows take 0.15 ms of forward
+    against 0.07 ms in one piece (small launches, and the gather kernels' LDS-served levels need a larger grid), so a
+    piece has >= 8 192 rows: c2 weak scaling 4 pieces, c5 strong scaling over 8 ranks (50 000 rows per rank) 6."""
     if world <= 1:
         return 1
-    return max(1, min(8, -(-rows // world) // 4096))
+    return max(1, min(8, -(-rows // world) // 8192))
 
 
 def _chunk_bounds(n: int, chunks: int, k: int) -> Tuple[int, int]:
@@ -271,8 +272,11 @@ class _RowShardedMSDA(Function):
 
     @staticmethod
     def forward(ctx, img, img_shapes, pts_rows, att_rows, padding_mode, align_corners, num_queries, group,
-                grad_value_sync, grad_sync, owner_groups, chunks):
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
+                grad_value_sync, grad_sync, owner_groups, chunks, compute_only_as=None):
+        # compute_only_as = (world, rank): this process plays ONE rank of a larger job with every exchange left out
+        # (row_sharded_multiscale_deformable_attention: the compute half of the scaling model on one GPU)
+        emulated = compute_only_as is not None
+        world, rank = compute_only_as if emulated else (dist.get_world_size(group), dist.get_rank(group))
         B, _, H, D = img.shape
         Q = int(num_queries)
         rows = B * Q
@@ -301,7 +305,7 @@ class _RowShardedMSDA(Function):
                                                                   align_corners))
 
             _run_pieces(piece, Q, r0 + c0, r0 + c1)
-            if world == 1:
+            if world == 1 or emulated:
                 continue
             if chunks == 1 and equal:
                 per = r1 - r0
@@ -324,6 +328,7 @@ class _RowShardedMSDA(Function):
             req.wait()
         ctx.save_for_backward(img, img_shapes, pts_rows, att_rows)
         ctx.meta = (padding_mode, align_corners, Q, group, grad_value_sync, grad_sync, owner_groups, world, rank, r0, r1)
+        ctx.emulated = emulated
         return full.view(B, Q, H, D)
 
     @staticmethod
@@ -334,6 +339,8 @@ class _RowShardedMSDA(Function):
         rows = B * Q
         need_img, _, need_pts, need_att = ctx.needs_input_grad[:4]
         g_rows = grad_full.reshape(rows, H, D)
+        if ctx.emulated:
+            grad_value_sync, grad_sync = "none", "slice"
         if grad_sync == "reduce_scatter" and world > 1:
             per = -(-rows // world)
             padded = g_rows if rows == world * per else torch.nn.functional.pad(g_rows, (0, 0, 0, 0, 0, world * per - rows))
@@ -392,7 +399,7 @@ class _RowShardedMSDA(Function):
                 for b, (ranks, pg) in enumerate(owner_groups):  # ascending b on every rank: no cyclic waits
                     if pg is not None and rank in ranks:
                         dist.all_reduce(g_img[b], op=dist.ReduceOp.SUM, group=pg)
-        return (g_img, None, g_pts, g_att) + (None,) * 8
+        return (g_img, None, g_pts, g_att) + (None,) * 9
 
 
 def row_sharded_multiscale_deformable_attention(
@@ -408,8 +415,14 @@ def row_sharded_multiscale_deformable_attention(
     grad_value_sync: Literal["all_reduce", "owners", "none"] = "all_reduce",
     grad_sync: Literal["slice", "reduce_scatter"] = "slice",
     overlap_chunks: Optional[int] = None,
+    compute_only_as: Optional[Tuple[int, int]] = None,
 ) -> torch.Tensor:
     """Row-sharded operator; returns the full ``[B, Q, H, D]`` output on every rank.
+
+    ``compute_only_as=(world, rank)`` (measurement aid, no process group needed): run exactly what rank ``rank`` of a
+    ``world``-rank job computes — its rows, in the same pieces, through the same kernels — and leave every exchange
+    out.  Only that rank's rows of the result (and its share of the gradients) are meaningful.  ``bench.py``'s
+    ``shard_compute_bound`` leg times it on one GPU: the speed-up ceiling before any byte crosses xGMI.
 
     ``overlap_chunks``: pieces the local rows are computed and exchanged in (piece k's exchange overlaps piece k+1's
     kernels); None picks 1 .. 4 by shard size.
@@ -420,11 +433,18 @@ def row_sharded_multiscale_deformable_attention(
     ``inputs_are_sharded=True``: they hold only this rank's rows, flattened: ``[rows, H, L, P, 2]`` /
     ``[rows, H, L, P]`` (``num_queries`` = Q per batch element is then required).
     """
-    if not (dist.is_available() and dist.is_initialized()):
+    if compute_only_as is not None:
+        world, rank = (int(v) for v in compute_only_as)
+        if not 0 <= rank < world:
+            raise ValueError(f"compute_only_as={compute_only_as!r}: need 0 <= rank < world")
+        compute_only_as = (world, rank)
+        grad_value_sync = "none"
+    elif not (dist.is_available() and dist.is_initialized()):
         raise RuntimeError("torch.distributed is not initialised; call init_process_group first")
     if grad_value_sync not in ("all_reduce", "owners", "none"):
         raise ValueError(f"unknown grad_value_sync {grad_value_sync!r}")
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if compute_only_as is None:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
     B = img.shape[0]
     if inputs_are_sharded:
         if num_queries is None:
@@ -452,4 +472,15 @@ def row_sharded_multiscale_deformable_attention(
     if overlap_chunks is None:
         overlap_chunks = default_overlap_chunks(rows, world)
     return _RowShardedMSDA.apply(img, img_shapes, pts_rows, att_rows, padding_mode, bool(align_corners), Q, group,
-                                 grad_value_sync, grad_sync, owners, overlap_chunks)
+                                 grad_value_sync, grad_sync, owners, overlap_chunks, compute_only_as)
+
+
+def owners_sum_bytes(B: int, Q: int, world: int, rank: int, plane_bytes: int) -> int:
+    """Bytes of grad_value that ``rank`` of a ``world``-rank row-sharded job takes into a sum with other ranks
+    (``grad_value_sync="owners"``): one ``[I, H, D]`` gradient per batch element whose rows it shares with a peer."""
+    r0, r1 = row_shard_bounds(B * Q, world, rank)
+    shared = 0
+    for b, q0, q1 in row_segments(Q, r0, r1):
+        if q1 - q0 < Q:
+            shared += 1
+    return shared * int(plane_bytes)

@@ -316,7 +316,63 @@ def test_piece_exchange_is_issued_before_the_next_piece_computes():
 def test_default_overlap_chunks():
     from msda_triton_amd.distributed import default_overlap_chunks
     assert default_overlap_chunks(40000, 1) == 1
-    assert default_overlap_chunks(4 * 10000 * 8, 8) == 8      # c2 weak scaling at 8 ranks: 40 000 rows per rank
-    assert default_overlap_chunks(400000, 8) == 8             # c5 strong scaling: 50 000 rows per rank
+    assert default_overlap_chunks(4 * 10000 * 8, 8) == 4      # c2 weak scaling at 8 ranks: 40 000 rows per rank
+    assert default_overlap_chunks(400000, 8) == 6             # c5 strong scaling: 50 000 rows per rank
     assert default_overlap_chunks(7200, 8) == 1               # c4: 900 rows per rank, one all-gather
     assert default_overlap_chunks(400000, 2) == 8
+
+
+# ------------------------------------------------------------------------------------------
+# the compute half of the scaling model on ONE process: compute_only_as=(world, rank) runs what that
+# rank of a world-rank job computes, no process group, no exchange
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world,rank", [(2, 0), (2, 1), (3, 1), (8, 0), (8, 7)])
+def test_compute_only_as_equals_that_ranks_rows_of_the_unsharded_operator(world, rank):
+    from msda_triton_amd import multiscale_deformable_attention, synth
+    from msda_triton_amd.distributed import owners_sum_bytes, row_shard_bounds, row_sharded_multiscale_deformable_attention
+    wl = synth.WORKLOADS["dryrun_strong"]
+    d = synth.make_inputs_torch(wl, "cpu", seed=5, dtype=torch.float64)
+    v = d["value"].clone().requires_grad_(True)
+    ref = multiscale_deformable_attention(v, d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
+    r0, r1 = row_shard_bounds(wl.B * wl.Q, world, rank)
+    go = torch.zeros_like(ref).reshape(wl.B * wl.Q, wl.H, wl.D)
+    go[r0:r1] = d["grad_out"].reshape(wl.B * wl.Q, wl.H, wl.D)[r0:r1]
+    ref.backward(go.view_as(ref))
+    v2 = d["value"].clone().requires_grad_(True)
+    pts = d["loc"].reshape(wl.B * wl.Q, *d["loc"].shape[2:])[r0:r1].clone().requires_grad_(True)
+    att = d["attn"].reshape(wl.B * wl.Q, *d["attn"].shape[2:])[r0:r1].clone().requires_grad_(True)
+    out = row_sharded_multiscale_deformable_attention(v2, d["shapes"], pts, att, wl.padding_mode, wl.align_corners,
+                                                      inputs_are_sharded=True, num_queries=wl.Q,
+                                                      compute_only_as=(world, rank))
+    rows = out.reshape(wl.B * wl.Q, wl.H, wl.D)
+    torch.testing.assert_close(rows[r0:r1], ref.detach().reshape(wl.B * wl.Q, wl.H, wl.D)[r0:r1], atol=1e-12, rtol=1e-12)
+    out.backward(d["grad_out"])  # (only this rank's rows of it are read)
+    torch.testing.assert_close(v2.grad, v.grad, atol=1e-12, rtol=1e-12)
+    assert pts.grad.shape == pts.shape and att.grad.shape == att.shape
+    plane = wl.I * wl.H * wl.D * 8
+    shared = owners_sum_bytes(wl.B, wl.Q, world, rank, plane)
+    assert shared % plane == 0 and 0 <= shared <= wl.B * plane
+    if world == 2:  # two ranks divide B = 2: nothing is shared
+        assert shared == 0
+
+
+def test_bench_dry_run_world1_carries_the_shard_compute_leg():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--backend", "gloo", "--device", "cpu",
+           "--workload", "dryrun"]
+    res = subprocess.run(cmd, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="2"), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    r = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    leg = r["shard_compute_bound"]
+    for key in ("strong_dryrun_strong", "weak_dryrun"):
+        assert set(leg[key]) == {"1", "2", "4", "8"}
+        for n in ("2", "4", "8"):
+            e = leg[key][n]
+            assert e["fwd_ms"] > 0 and e["fwd_bwd_ms"] > 0 and e["speedup_ceiling"] > 0 and e["owners_sum_bytes"] >= 0
+        assert leg[key]["2"]["ideal"] == (2 if key.startswith("strong") else 1)
+    assert leg["strong_dryrun_strong"]["8"]["rows"] * 8 == leg["strong_dryrun_strong"]["1"]["rows"]
+    assert leg["weak_dryrun"]["8"]["rows"] == leg["weak_dryrun"]["1"]["rows"]

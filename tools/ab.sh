@@ -8,7 +8,7 @@ W=${3:-c2_q10k}
 cp msda_triton_amd/libmsda_hip.so /tmp/libmsda_hip_keep.so
 run() {
   cp msda_triton_amd/libmsda_hip_$1.so msda_triton_amd/libmsda_hip.so
-  for i in 1 2 3; do timeout -k 10 200 python bench.py --workload $W --no-configs --no-do-bench --no-triton --no-cpu-baseline --no-strong-c5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('  %-10s fwd %.4f step %.4f' % ('$1', d['fwd_ms'], d['ms_per_step']), {k: v['avg_us'] for k, v in d['kernels'].items()})"; done
+  for i in 1 2 3; do timeout -k 10 200 python bench.py --workload $W --no-configs --no-do-bench --no-triton --no-cpu-baseline --no-strong-c5 --no-shard-compute 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('  %-10s fwd %.4f step %.4f' % ('$1', d['fwd_ms'], d['ms_per_step']), {k: v['avg_us'] for k, v in d['kernels'].items()})"; done
 }
 run $1; run $2; run $1; run $2
 cp /tmp/libmsda_hip_keep.so msda_triton_amd/libmsda_hip.so

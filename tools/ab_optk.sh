@@ -15,6 +15,6 @@ fi
 for rep in 1 2; do
   for o in "$@"; do
     args=""; [ "$o" != "-" ] && for kv in ${o//,/ }; do args="$args --opt $kv"; done
-    for i in $(seq $REPS); do timeout -k 10 200 python bench.py --workload $W --no-configs --no-do-bench --no-triton --no-cpu-baseline --no-strong-c5 $args 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('  %-16s fwd %.4f step %.4f' % ('$o', d['fwd_ms'], d['ms_per_step']), {k.replace('msda_','').replace('_kernel',''): round(v['avg_us'],1) for k, v in d['single_kernels'].items() if 'fwd' in k or 'bwd_sample' in k or '$ALLK'})"; done
+    for i in $(seq $REPS); do timeout -k 10 200 python bench.py --workload $W --no-configs --no-do-bench --no-triton --no-cpu-baseline --no-strong-c5 --no-shard-compute $args 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('  %-16s fwd %.4f step %.4f' % ('$o', d['fwd_ms'], d['ms_per_step']), {k.replace('msda_','').replace('_kernel',''): round(v['avg_us'],1) for k, v in d['single_kernels'].items() if 'fwd' in k or 'bwd_sample' in k or '$ALLK'})"; done
   done
 done

@@ -19,7 +19,7 @@ SETS=(
 n=0
 for g in "${SETS[@]}"; do
   rm -rf gpurun_out/${TAG}_pmc_$n
-  timeout -k 10 300 rocprofv3 --pmc $g --output-format csv -d gpurun_out/${TAG}_pmc_$n -- python bench.py --workload $W $EXTRA --steps 3 --warmup 2 --no-cpu-baseline --no-strong-c5 --no-configs --no-do-bench --no-triton > gpurun_out/${TAG}_pmc_$n.log 2>&1 || echo "group $n ($g) failed: see gpurun_out/${TAG}_pmc_$n.log"
+  timeout -k 10 300 rocprofv3 --pmc $g --output-format csv -d gpurun_out/${TAG}_pmc_$n -- python bench.py --workload $W $EXTRA --steps 3 --warmup 2 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton > gpurun_out/${TAG}_pmc_$n.log 2>&1 || echo "group $n ($g) failed: see gpurun_out/${TAG}_pmc_$n.log"
   n=$((n+1))
 done
 ls gpurun_out/${TAG}_pmc_*/*/ 2>/dev/null | head -40

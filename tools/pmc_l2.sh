@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for o in 0 1; do
 rm -rf gpurun_out/pl2_$o
-timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d gpurun_out/pl2_$o -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-strong-c5 --no-configs --no-do-bench --no-triton --opt lds_levels=$o > gpurun_out/pl2_$o.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d gpurun_out/pl2_$o -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton --opt lds_levels=$o > gpurun_out/pl2_$o.log 2>&1
 python3 - <<PY
 import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -13,7 +13,7 @@ SETS=(
 n=0
 for g in "${SETS[@]}"; do
   rm -rf gpurun_out/pq_$n
-  timeout -k 10 200 rocprofv3 --pmc $g --output-format csv -d gpurun_out/pq_$n -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-strong-c5 --no-configs --no-do-bench --no-triton $args > gpurun_out/pq_$n.log 2>&1 || echo "set $n failed"
+  timeout -k 10 200 rocprofv3 --pmc $g --output-format csv -d gpurun_out/pq_$n -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton $args > gpurun_out/pq_$n.log 2>&1 || echo "set $n failed"
   n=$((n+1))
 done
 python3 - <<'PY'

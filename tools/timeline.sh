@@ -6,7 +6,7 @@ for o in "$@"; do
   args=""
   for kv in ${o//,/ }; do args="$args --opt $kv"; done
   rm -rf gpurun_out/prof_tl
-  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_tl -- python bench.py --workload $W --steps 4 --warmup 2 --no-cpu-baseline --no-strong-c5 --no-configs --no-do-bench --no-triton $args > gpurun_out/prof_tl.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_tl -- python bench.py --workload $W --steps 4 --warmup 2 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton $args > gpurun_out/prof_tl.log 2>&1
   echo "== $W $o: $(grep -o '"fwd_bwd_ms": [0-9.]*' gpurun_out/prof_tl.log | head -1)"
   python3 - <<'PY'
 import csv,glob
