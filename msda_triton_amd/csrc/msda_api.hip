@@ -33,6 +33,7 @@ static std::atomic<int> g_profile{0};
 static std::atomic<int> g_records_in_grads{1};
 static std::atomic<int> g_lds_levels{1};
 static std::atomic<int> g_lds_budget{-1};
+static std::atomic<int> g_unit_fwd{1};
 static std::atomic<int> g_lds_stagger{0};  // (measured 0 / 4 / 12 / 24 at c2 @ 10k: 0 is fastest — the work counter desynchronises the waves by itself)
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
@@ -121,6 +122,7 @@ int option_profile() { return g_profile.load(std::memory_order_relaxed); }
 int option_records_in_grads() { return g_records_in_grads.load(std::memory_order_relaxed); }
 int option_lds_levels() { return g_lds_levels.load(std::memory_order_relaxed); }
 int option_lds_stagger() { return g_lds_stagger.load(std::memory_order_relaxed); }
+int option_unit_fwd() { return g_unit_fwd.load(std::memory_order_relaxed); }
 int option_lds_budget() { return g_lds_budget.load(std::memory_order_relaxed); }  // dev knob: cap on the level bytes (-1: none)
 // CUs of the current device, asked once per device (the LDS-level gather variants size their grid by it)
 int device_cu_count()
@@ -354,6 +356,10 @@ extern "C" int msda_set_option(const char *key, int value)
         msda::g_lds_stagger.store(value, std::memory_order_relaxed);
         return 0;
     }
+    if (key && strcmp(key, "unit_fwd") == 0) {
+        msda::g_unit_fwd.store(value == 2 ? 2 : value ? 1 : 0, std::memory_order_relaxed);
+        return 0;
+    }
     if (key && strcmp(key, "lds_budget") == 0) {
         msda::g_lds_budget.store(value, std::memory_order_relaxed);
         return 0;
@@ -393,6 +399,7 @@ extern "C" int msda_get_option(const char *key)
     if (key && strcmp(key, "records_in_grads") == 0) return msda::option_records_in_grads();
     if (key && strcmp(key, "lds_levels") == 0) return msda::option_lds_levels();
     if (key && strcmp(key, "lds_budget") == 0) return msda::option_lds_budget();
+    if (key && strcmp(key, "unit_fwd") == 0) return msda::option_unit_fwd();
     if (key && strcmp(key, "lds_stagger") == 0) return msda::option_lds_stagger();
     msda::set_error("unknown option '%s'", key ? key : "(null)");
     return MSDA_ERR_BAD_ARG;

@@ -203,18 +203,50 @@ struct LevelTab {
 
 __device__ __forceinline__ void load_level_table(LevelTab *tab, const int64_t *shapes, int L)
 {
+    // ONE round trip to memory: lane l of the first wave fetches level l's (h, w) — vector loads, all in flight
+    // together — and the exclusive sums come from a shuffle scan over those lanes.  (Until round 5 thread t looped
+    // over the levels below it: the compiler made that a waterfall of scalar loads, one dependent miss per level and
+    // a vector load of the thread's own level behind them — on a cold cache four round trips in front of the first
+    // sample, which is most of a decoder-sized launch: DESIGN.md 9, small-Q forward.)
     const int t = threadIdx.x;
-    if (t < L) {
-        int start = 0, cstart = 0;
-        for (int l = 0; l < t; ++l) {
-            const int lh = (int)shapes[2 * l], lw = (int)shapes[2 * l + 1];
-            start += lh * lw;
-            cstart += (lh + 1) * (lw + 1);
+    if (t < kWave) {
+        int lh = 0, lw = 0;
+        if (t < L) {
+            lh = (int)shapes[2 * t];
+            lw = (int)shapes[2 * t + 1];
         }
-        tab->h[t] = (int)shapes[2 * t];
-        tab->w[t] = (int)shapes[2 * t + 1];
-        tab->start[t] = start;
-        tab->cstart[t] = cstart;
+        const int n = lh * lw, c = (lh + 1) * (lw + 1);
+        int sn = n, sc = c;
+        if (L <= 16) {  // inclusive scan inside a DPP row: row_shr fills with zeros, no LDS crossbar trip
+            sn += __builtin_amdgcn_update_dpp(0, sn, 0x111, 0xF, 0xF, true);  // row_shr:1
+            sc += __builtin_amdgcn_update_dpp(0, sc, 0x111, 0xF, 0xF, true);
+            if (L > 2) {
+                sn += __builtin_amdgcn_update_dpp(0, sn, 0x112, 0xF, 0xF, true);  // row_shr:2
+                sc += __builtin_amdgcn_update_dpp(0, sc, 0x112, 0xF, 0xF, true);
+            }
+            if (L > 4) {
+                sn += __builtin_amdgcn_update_dpp(0, sn, 0x114, 0xF, 0xF, true);  // row_shr:4
+                sc += __builtin_amdgcn_update_dpp(0, sc, 0x114, 0xF, 0xF, true);
+            }
+            if (L > 8) {
+                sn += __builtin_amdgcn_update_dpp(0, sn, 0x118, 0xF, 0xF, true);  // row_shr:8
+                sc += __builtin_amdgcn_update_dpp(0, sc, 0x118, 0xF, 0xF, true);
+            }
+        } else {
+            for (int d = 1; d < L; d <<= 1) {  // inclusive scan over the lanes 0 .. L-1 (L <= kMaxLevels <= 64)
+                const int a = __shfl_up(sn, d, kWave), b = __shfl_up(sc, d, kWave);
+                if (t >= d) {
+                    sn += a;
+                    sc += b;
+                }
+            }
+        }
+        if (t < L) {
+            tab->h[t] = lh;
+            tab->w[t] = lw;
+            tab->start[t] = sn - n;
+            tab->cstart[t] = sc - c;
+        }
     }
 }
 

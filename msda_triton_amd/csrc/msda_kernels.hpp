@@ -228,6 +228,17 @@ template <typename T, int VEC> __device__ __forceinline__ void lds_row(uint32_t 
     for (int i = 0; i < VEC; ++i) dst[i] = Traits<T>::to_acc(pk.v[i]);
 }
 
+// The gather kernels' arguments, requested in ONE batch of scalar loads at the top of the kernel: left to itself the
+// compiler loads each field next to its first use, which put a second kernel-argument miss (~1 us on a cold cache)
+// behind the first one on the way to the first sample — a tenth of a decoder-sized forward.
+__device__ __forceinline__ void request_all_arguments(const Params &p)
+{
+    asm volatile("" ::"s"(p.value), "s"(p.shapes), "s"(p.loc), "s"(p.attn), "s"(p.out), "s"(p.grad_out), "s"(p.grad_loc), "s"(p.grad_attn));
+    asm volatile("" ::"s"(p.B), "s"(p.I), "s"(p.H), "s"(p.D), "s"(p.Q), "s"(p.L), "s"(p.P), "s"(p.LP), "s"(p.nqc), "s"(p.qw), "s"(p.sc),
+                 "s"(p.zeros), "s"(p.align), "s"(p.xcd_map), "s"(p.grid3d), "s"(p.div_h.magic), "s"(p.div_h.shift), "s"(p.ref),
+                 "s"(p.ref_dim), "s"(p.lds_lev_bytes));
+}
+
 // ==========================================================================================
 // forward.  After the one-time staging barrier every wave runs on its own: it parks the records of
 // ITS 64/G units, gathers, stores, and moves to its next query chunk without any block barrier.
@@ -243,6 +254,10 @@ template <typename T, int VEC> __device__ __forceinline__ void lds_row(uint32_t 
 // The gather is bound by the vector-memory path (64 B/clk/CU); an LDS row read costs a quarter of that,
 // on another pipe.  One large workgroup per CU, so that 16 waves share ONE copy (round 2 tried it with 256-thread
 // workgroups: the copies ate the occupancy).  Same arithmetic in the same order: results are bit-identical.
+// (Measured and dropped in round 5: variants with 8 / 16 samples' rows in flight per lane for small grids.  On a cold
+//  cache a batch of 16 loads per lane takes ~2 500 cycles, four of them per unit — but 64 loads at once took 2.5x as
+//  long as the four batches together (in-kernel clock, Q = 10 / 100).  What small grids want is more WAVES with few
+//  loads each: msda_fwd_unit_kernel below.)
 template <typename T, int VEC, int G, bool FUSED, typename TV = T, bool PAIR = false, int BLK = kBlock, bool LDSL = false>
 __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlock ? 5 : 4))) void msda_fwd_kernel(const Params p)
 {
@@ -250,6 +265,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     using TR = Traits<T>;
     static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
     static_assert(!(LDSL && (PAIR || VEC == 1)), "the LDS-served levels use the plain 16-byte vector path");
+    request_all_arguments(p);
     constexpr int NU = BLK / G;        // units per workgroup and query chunk
     constexpr int UPW = kWave / G;     // units per wave
     constexpr int GH = PAIR ? G / 2 : G;  // lanes across one row's channels
@@ -587,6 +603,116 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
 }
 
 // ==========================================================================================
+// forward for SMALL problems (decoder calls: a few hundred queries): one WAVE per unit (b, q, h).  The lanes are
+// R = 64 / GL groups of GL lanes (GL * VEC = D channels); a load instruction fetches R different (sample, corner) rows
+// of the unit, so its 4 * L * P rows take 4 * L * P / R instructions (8 for L * P = 16, 128-byte rows), all in flight at
+// once — where msda_fwd_kernel's wave serves eight units in four batches of sixteen loads, one memory round trip per
+// batch.  On a nearly empty chip the kernel IS its chain of round trips (arguments, points + level sizes, rows): cold
+// cache, Q = 100: 13.2 us against the Triton comparator's 9.0 (profiles/r04_query_sweep_*; VERDICT r04 missing #3).
+// Phase 1: lanes < L * P compute one sample's taps each and leave {offset, weight} per (sample, corner) in the wave's
+// LDS slice; phase 2: lane (r, j) blends the pairs r, r + R, ...; the R partial rows meet through lane shuffles.
+// ==========================================================================================
+template <typename T, int VEC, typename TV = T>
+__global__ __launch_bounds__(kBlock) void msda_fwd_unit_kernel(const Params p)
+{
+    using A = typename Traits<T>::acc;
+    using TR = Traits<T>;
+    static_assert(sizeof(A) == 4, "float accumulation (the shuffles below move 32-bit values)");
+    request_all_arguments(p);
+    constexpr int WPB = kBlock / kWave;  // units per workgroup
+    const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
+    const int GL = p.D / VEC;            // lanes across a row (the host checks: a power of two, <= 64, D % VEC == 0)
+    const int R = kWave / GL;            // rows per load instruction
+    const int r = lane / GL, j = lane - r * GL;
+    const int unit = (int)blockIdx.x * WPB + wave;  // (b * Q + q) * H + h
+    const int units = p.B * p.Q * p.H;
+    LevelTab *tab = reinterpret_cast<LevelTab *>(msda_smem);
+    // per wave: [4 * LP] offsets, [4 * LP] weights
+    uint32_t *w_off = reinterpret_cast<uint32_t *>(msda_smem + kGatherLdsFixed) + (size_t)wave * 8 * p.LP;
+    A *w_wgt = reinterpret_cast<A *>(w_off + 4 * p.LP);
+    const bool live = unit < units;
+    const int bq = live ? (int)fast_div((uint32_t)unit, p.div_h) : 0, h = unit - bq * p.H;
+    const int b = live ? bq / p.Q : 0;
+    // the unit's samples: requested before the level table is waited for
+    const size_t s_base = (size_t)(live ? unit : 0) * p.LP;
+    Pack<T, 2> xy;
+    T at;
+    xy.v[0] = xy.v[1] = at = TR::from_acc((A)0);
+    const bool has = live && lane < p.LP;
+    if (has) {
+        xy = *reinterpret_cast<const Pack<T, 2> *>(static_cast<const T *>(p.loc) + 2 * (s_base + lane));
+        at = static_cast<const T *>(p.attn)[s_base + lane];
+    }
+    load_level_table(tab, p.shapes, p.L);
+    __syncthreads();
+    if (!live) return;  // (wave-uniform; no barrier below)
+    const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TV);
+    const TV *plane = static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
+    const rsrc_t rs = make_rsrc(plane, (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV)));
+    for (int s0 = 0; s0 < p.LP; s0 += kWave) {  // (L * P <= 64: one trip)
+        const int sl = s0 + lane;
+        if (s0 > 0) {
+            wave_lds_sync();
+            if (sl < p.LP) {
+                xy = *reinterpret_cast<const Pack<T, 2> *>(static_cast<const T *>(p.loc) + 2 * (s_base + sl));
+                at = static_cast<const T *>(p.attn)[s_base + sl];
+            }
+        }
+        if (sl < p.LP) {
+            const int l = div_small(sl, p.P, 1.0f / (float)p.P);
+            Taps<A> t;
+            make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], tab->start[l], p.zeros, p.align, row_bytes, t);
+            const A a = TR::to_acc(at), wy0 = (A)1 - t.dy, wx0 = (A)1 - t.dx;
+            *reinterpret_cast<uint4 *>(w_off + 4 * sl) = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
+            Rec4<A> w;
+            w.v[0] = a * (wy0 * wx0);
+            w.v[1] = a * (wy0 * t.dx);
+            w.v[2] = a * (t.dy * wx0);
+            w.v[3] = a * (t.dy * t.dx);
+            *reinterpret_cast<Rec4<A> *>(w_wgt + 4 * sl) = w;
+        }
+    }
+    wave_lds_sync();
+    // phase 2: pair index = 4 * sample + corner; lane group r takes the pairs r, r + R, ... — in ascending order, so every
+    // group's partial sum is a fixed sub-sequence of the reference's sample order
+    const int npairs = 4 * p.LP;
+    const uint32_t lane_off = (uint32_t)j * VEC * (uint32_t)sizeof(TV);
+    A acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = (A)0;
+    using RLV = RawLoad<sizeof(TV) * VEC>;
+    constexpr int kFly = 8;  // load instructions in flight together
+    for (int p0 = r; p0 < npairs; p0 += kFly * R) {
+        Pack<TV, VEC> v[kFly];
+        A wv[kFly];
+#pragma unroll
+        for (int u = 0; u < kFly; ++u) {
+            const int pi = p0 + u * R;
+            const bool on = pi < npairs;
+            const uint32_t o = on ? w_off[pi] : kMaskedOffset;  // (beyond the last pair: an out-of-range offset, zeros, weight 0)
+            wv[u] = on ? w_wgt[pi] : (A)0;
+            v[u] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, o == kMaskedOffset ? o : o + lane_off));
+        }
+#pragma unroll
+        for (int u = 0; u < kFly; ++u) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fma_t(wv[u], Traits<TV>::to_acc(v[u].v[i]), acc[i]);
+        }
+    }
+    // the R partial rows of the unit: lanes j, j + GL, j + 2 GL, ... hold the same channels
+    for (int m = GL; m < kWave; m <<= 1) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], m, kWave);
+    }
+    if (r == 0) {
+        Pack<T, VEC> o;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) o.v[i] = TR::from_acc(acc[i]);
+        store_stream(static_cast<T *>(p.out) + (size_t)unit * p.D + j * VEC, o);
+    }
+}
+
+// ==========================================================================================
 // backward, part 1: grad_loc and grad_attn.  Same decomposition as the forward; every sample's
 // three results are reduced over the unit's G lanes with DPP moves and written exactly once.
 // ==========================================================================================
@@ -601,6 +727,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     using TR = Traits<T>;
     static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
     static_assert(!LDSL || (!PAIR && !FUSED && VEC != 1 && sizeof(A) == 4 && !TR::kDot2 && (G == 4 || G == 8)), "LDS-served levels: plain reduce-scatter units");
+    request_all_arguments(p);
     constexpr int NU = BLK / G;
     constexpr int UPW = kWave / G;
     constexpr int GH = PAIR ? G / 2 : G;  // lanes across one row's channels

@@ -168,6 +168,10 @@ inline void plan_gather(int NU, int LP, size_t acc_bytes, int &sc, size_t &lds, 
 // ---- the gather kernels with the coarsest levels in LDS (msda_kernels.hpp, LDSL): ONE 1024-thread workgroup per CU,
 // every (b, h) plane cut into as many runs of query chunks as fill the chip once ----
 int option_lds_levels();  // 0: never, 1: where lds_levels_plan says so, 2: wherever the kernels exist
+int option_unit_fwd();  // 1 (default): small problems take the one-wave-per-unit forward; 2: every problem it can; 0: never
+// (b, q, h) units up to which the one-wave-per-unit forward is taken: cold-cache forward at B = 4, H = 8 (round 5, in-process
+// A/B): Q = 10 10.3 -> 7.5 us, 100 12.8 -> 9.4, 300 ~15 -> 13.2; from Q ~ 500 the general kernel is faster (900: 18-23 against 23.7)
+constexpr long long kUnitFwdMaxUnits = 12288;
 int option_lds_budget();  // dev knob: cap on the bytes of LDS-resident levels (-1: none)
 int option_lds_stagger();  // dev knob: start-up stagger of an LDSL workgroup's waves, in units of 64 cycles per wave
 int device_cu_count();    // CUs of the current device (cached; msda_api.hip)
@@ -246,6 +250,21 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, bool PAIR = fal
     // (the sample-gradient kernel has the variant for its reduce-scatter units: float accumulation, 4 or 8 lanes)
     // fp32 operators only: measured at c3 (bf16, 64-byte rows: forward 88 against 86 us) and c5 (fp16, D = 64, L * P = 40 in
     // three trips: 3.17 against 2.93 ms) the 16-bit operators do not gain
+    // small problems (decoder calls): the forward with one wave per unit (msda_fwd_unit_kernel)
+    if constexpr (MODE == 0 && !PAIR && VEC * sizeof(T) == 16 && sizeof(A) == 4) {
+        const long long units = (long long)p.B * p.Q * p.H;
+        const int gl = p.D / VEC;
+        if (option_unit_fwd() != 0 && (p.D % VEC) == 0 && gl >= 1 && gl <= kWave && (gl & (gl - 1)) == 0 && p.LP <= 1024 &&
+            units <= (option_unit_fwd() == 2 ? (1ll << 30) : kUnitFwdMaxUnits) && (units + 3) / 4 < (1ll << 31)) {
+            const size_t ulds = kGatherLdsFixed + (size_t)(kBlock / kWave) * 8 * p.LP * 4;
+            const ProfileScope prof("msda_fwd_unit_kernel", stream);
+            auto kernel = msda_fwd_unit_kernel<T, VEC, TV>;
+            static std::atomic<uint64_t> big_lds_unit{0};
+            allow_big_lds(kernel, big_lds_unit);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)((units + 3) / 4)), dim3(kBlock), ulds, stream, p);
+            return (int)hipGetLastError();
+        }
+    }
     if constexpr (!PAIR && sizeof(T) == 4 && sizeof(TV) == 4 && VEC == 4 && ((MODE == 0 && G <= 16) || (MODE == 1 && (G == 4 || G == 8)))) {
         const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, false);
         if (pl.use) return launch_gather_lds<T, VEC, G, MODE, TV>(p, pl, stream);

@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-plots", action="store_true")
     ap.add_argument("--no-triton", action="store_true", help="leave out the Triton comparator (scripts/triton_comparator.py)")
     ap.add_argument("--out", default="outputs/benchmark_results")
+    ap.add_argument("--fwd-only", action="store_true", help="forward timings only (development: the small-Q latency work)")
     args = ap.parse_args()
     providers = {"hip": multiscale_deformable_attention}
     if not args.no_native:
@@ -99,6 +100,9 @@ def main():
                     op(img, shapes, pts, att, "border", True)
 
             f = do_bench(fwd)
+            if args.fwd_only:
+                print(dict(num_queries=N, provider=name, fwd_ms=round(f[0], 5), p20=round(f[1], 5), p80=round(f[2], 5)), flush=True)
+                continue
             img, shapes, pts, att = make_inputs(N, True)
 
             def fwdbwd():
@@ -123,6 +127,8 @@ def main():
             rows.append(dict(num_queries=N, provider=name, fwd_ms=f[0], fwd_ms_p20=f[1], fwd_ms_p80=f[2],
                              fwdbwd_ms=fb[0], fwdbwd_ms_p20=fb[1], fwdbwd_ms_p80=fb[2], peak_mem_MB=mem))
             print(rows[-1], flush=True)
+    if args.fwd_only:
+        return
     path = os.path.join(args.out, "msda_sweep.csv")
     with open(path, "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=list(rows[0]))

@@ -12,6 +12,16 @@ from test_gpu_parity import BWD_TOL, DEV, FWD_TOL, rand_case
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _no_unit_forward():
+    """these shapes are small: without this they would all take the one-wave-per-unit forward (test_gpu_unit_fwd.py)"""
+    from msda_triton_amd import _lib
+    old = _lib.get_option("unit_fwd")
+    _lib.set_option("unit_fwd", 0)
+    yield
+    _lib.set_option("unit_fwd", old)
+
 # name: (B, Q, H, D, levels, P, dtype)
 CASES = {
     "c2_like_f32": (2, 700, 4, 32, [(16, 16), (8, 8), (4, 4), (2, 2)], 4, torch.float32),

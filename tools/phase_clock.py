@@ -1,6 +1,7 @@
 """dev tool (needs a library built with -DMSDA_DEV, e.g. msda_triton_amd/libmsda_hip_dev.so copied over the shipped one):
 per-phase cycles of the forward kernel's waves from the in-kernel s_memtime stamps (msda_set_option("debug", 2048)).
     python tools/phase_clock.py [workload] [k=v ...]"""
+import os
 import sys
 
 import numpy as np
@@ -10,7 +11,10 @@ sys.path.insert(0, ".")
 from msda_triton_amd import _lib, synth  # noqa: E402
 from msda_triton_amd.functional import msda_hip_fwd  # noqa: E402
 
+import dataclasses
 wl = synth.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 and "=" not in sys.argv[1] else "c2_q10k"]
+if os.environ.get("Q"):
+    wl = dataclasses.replace(wl, Q=int(os.environ["Q"]))  # (e.g. the decoder-sized calls of the query sweep)
 for kv in sys.argv[1:]:
     if "=" in kv:
         k, v = kv.split("=")
@@ -20,7 +24,6 @@ if d is None:
     h = synth.make_inputs_numpy(wl, seed=0)
     dt = getattr(torch, wl.dtype)
     d = {k: torch.from_numpy(v).to("cuda:0") if k == "shapes" else torch.from_numpy(v).to("cuda:0", dt) for k, v in h.items()}
-import os
 shift = int(os.environ.get("SHIFT", "0"))  # floats: move `value` (and with SHIFT_ALL=1 every tensor) off its allocation's start
 def shifted(t):
     if not shift or t.dtype == torch.int64:
@@ -36,9 +39,14 @@ print("value ptr % 1024 =", d["value"].data_ptr() % 1024, " loc ptr % 1024 =", d
 for _ in range(3):
     out = msda_hip_fwd(d["value"], d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
 _lib.set_option("debug", 2048 | _lib.get_option("debug"))
+if os.environ.get("COLD"):  # the reference benchmark's cold-cache recipe: L2 + Infinity Cache flushed before the launch
+    for _ in range(3):
+        out = msda_hip_fwd(d["value"], d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
+    torch.empty(256 << 20, dtype=torch.int8, device="cuda").zero_()
 out = msda_hip_fwd(d["value"], d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
 torch.cuda.synchronize()
-r = out.float().reshape(-1)[: 8 * 65536 * 4].reshape(-1, 8).cpu().numpy()
+n8 = out.numel() // 8 * 8
+r = out.float().reshape(-1)[: min(n8, 8 * 65536 * 4)].reshape(-1, 8).cpu().numpy()
 r = r[r[:, 7] == 12345.0]
 print("waves", len(r), "slices per wave", r[:, 4].mean())
 names = ["phase1(+wait for points)", "memory gather", "LDS gather"]

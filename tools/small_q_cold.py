@@ -1,0 +1,61 @@
+"""dev tool: cold-cache forward latency at small Q (the reference benchmark's recipe, scripts/benchmark_sweep.py do_bench)
+for option strings alternated INSIDE one process (boxes and even runs differ by more than the effects looked for):
+    python tools/small_q_cold.py [--triton] Q [Q ...] -- opt=val[,opt=val] [opt=val ...]      ("-" = defaults)"""
+import importlib.util
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from msda_triton_amd import _lib, multiscale_deformable_attention  # noqa: E402
+
+spec = importlib.util.spec_from_file_location("sweep", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts", "benchmark_sweep.py"))
+sweep = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(sweep)
+
+args = sys.argv[1:]
+want_triton = "--triton" in args
+if "--warm" in args:  # back-to-back instead of the flushed cache
+    torch.Tensor.zero_ = lambda self: self
+args = [a for a in args if a not in ("--triton", "--warm")]
+split = args.index("--") if "--" in args else len(args)
+qs = [int(a) for a in args[:split]] or [10, 100, 300, 900, 1000]
+opts = args[split + 1:] or ["-"]
+tc = None
+if want_triton:
+    s2 = importlib.util.spec_from_file_location("tc", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts", "triton_comparator.py"))
+    tc = importlib.util.module_from_spec(s2)
+    s2.loader.exec_module(tc)
+
+
+def apply(o, defaults):
+    for k, v in defaults.items():
+        _lib.set_option(k, v)
+    if o != "-":
+        for kv in o.split(","):
+            k, v = kv.split("=")
+            _lib.set_option(k, int(v))
+
+
+keys = sorted({kv.split("=")[0] for o in opts if o != "-" for kv in o.split(",")})
+defaults = {k: _lib.get_option(k) for k in keys}
+for N in qs:
+    img, shapes, pts, att = sweep.make_inputs(N, False)
+
+    def fwd():
+        with torch.no_grad():
+            multiscale_deformable_attention(img, shapes, pts, att, "border", True)
+
+    line = {}
+    for rep in range(2):
+        for o in opts:
+            apply(o, defaults)
+            line.setdefault(o, []).append(sweep.do_bench(fwd, warmup_ms=30.0, rep_ms=300.0)[0] * 1e3)
+    apply("-", defaults)
+    if tc is not None and tc.HAVE_TRITON:
+        def tfwd():
+            with torch.no_grad():
+                tc.triton_comparator_msda(img, shapes, pts, att, "border", True)
+        line["triton"] = [sweep.do_bench(tfwd, warmup_ms=30.0, rep_ms=300.0)[0] * 1e3 for _ in range(2)]
+    print("Q=%5d " % N + "  ".join("%s: %s us" % (k, "/".join("%.2f" % x for x in v)) for k, v in line.items()), flush=True)
