@@ -1,8 +1,8 @@
-"""dev tool: share of a Deformable-DETR training step spent inside multi-scale deformable attention, with
-transformers' own pure-PyTorch module and with this package's kernels (replace_hf_msda).  Random-init model from a
-config (no download), COCO-like 800 x 1066 input, fp32 and bf16 autocast.  Writes profiles/r03_hf_model_msda_share.json.
+"""dev tool: share of a Deformable-DETR / Grounding-DINO training step spent inside multi-scale deformable attention,
+with transformers' own pure-PyTorch module and with this package's kernels (replace_hf_msda).  Random-init model from a
+config (no download), COCO-like 800 x 1066 input, fp32 and bf16 autocast.
 
-    python tools/hf_model_share.py [out.json]
+    python tools/hf_model_share.py [--model deformable_detr|grounding_dino] [out.json]
 """
 import json
 import os
@@ -17,6 +17,26 @@ from transformers import DeformableDetrConfig, DeformableDetrModel, ResNetConfig
 from msda_triton_amd.hf_adapter import replace_hf_msda  # noqa: E402
 
 dev = "cuda:0"
+
+
+def build_gdino():
+    """Grounding-DINO-T shaped: Swin-T backbone, BERT-base-sized text encoder cut to 2 layers (random init, the text side
+    is not what is measured), d_model 256, 6 + 6 layers, 900 queries"""
+    from transformers import BertConfig, GroundingDinoConfig, GroundingDinoModel, SwinConfig
+    bb = SwinConfig(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7,
+                    out_features=["stage2", "stage3", "stage4"], drop_path_rate=0.0, hidden_dropout_prob=0.0,
+                    attention_probs_dropout_prob=0.0)
+    txt = BertConfig(num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg = GroundingDinoConfig(backbone_config=bb, use_timm_backbone=False, use_pretrained_backbone=False, backbone=None,
+                              text_config=txt, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+                              fusion_dropout=0.0, fusion_droppath=0.0)
+    torch.manual_seed(0)
+    m = GroundingDinoModel(cfg).to(dev).train()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("sampling_offsets.weight"):
+                p.normal_(0, 0.02)
+    return m
 
 
 def build():
@@ -65,11 +85,11 @@ def wrap(model):
     return len(targets)
 
 
-def measure(model, x, mask, autocast, steps=5):
+def measure(model, x, mask, autocast, steps=5, extra=None):
     def step():
         model.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
-            out = model(pixel_values=x, pixel_mask=mask)
+            out = model(pixel_values=x, pixel_mask=mask, **(extra or {}))
         (out.last_hidden_state.float() ** 2).mean().backward()
     for _ in range(2):
         step()
@@ -85,20 +105,34 @@ def measure(model, x, mask, autocast, steps=5):
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_hf_model_msda_share.json")
+    args = sys.argv[1:]
+    which = "deformable_detr"
+    if "--model" in args:
+        i = args.index("--model")
+        which = args[i + 1]
+        del args[i:i + 2]
+    out_path = args[0] if args else os.path.join(ROOT, "profiles", "hf_model_msda_share_%s.json" % which)
     torch.manual_seed(1)
     x = torch.randn(2, 3, 800, 1066, device=dev)
     mask = torch.ones(2, 800, 1066, dtype=torch.long, device=dev)
-    res = {"model": "DeformableDetrModel (transformers %s), random init, ResNet-50-shaped backbone, d_model 256, 6 + 6 layers, "
-                    "300 queries, 4 levels x 4 points, input 2 x 3 x 800 x 1066, fwd + bwd" % __import__("transformers").__version__,
+    extra = None
+    if which == "grounding_dino":
+        ids = torch.randint(1000, 20000, (2, 12), device=dev)
+        extra = dict(input_ids=ids, attention_mask=torch.ones_like(ids), token_type_ids=torch.zeros_like(ids))
+        what = ("GroundingDinoModel (transformers %s), random init, Swin-T-shaped backbone, 2-layer BERT text encoder, d_model 256, "
+                "6 + 6 layers, 900 queries, 4 levels x 4 points, input 2 x 3 x 800 x 1066 + 12 text tokens, fwd + bwd")
+    else:
+        what = ("DeformableDetrModel (transformers %s), random init, ResNet-50-shaped backbone, d_model 256, 6 + 6 layers, "
+                "300 queries, 4 levels x 4 points, input 2 x 3 x 800 x 1066, fwd + bwd")
+    res = {"model": what % __import__("transformers").__version__,
            "timing": "msda_ms: device time between events around the attention core's forward and (autograd hooks) its backward, "
                      "summed over the 12 layers; step_ms: wall time of a training step (no optimizer)"}
     for impl in ("transformers", "msda_triton_amd"):
-        model = build()
+        model = build_gdino() if which == "grounding_dino" else build()
         if impl == "msda_triton_amd":
             assert replace_hf_msda(model) == 12
         wrap(model)
-        res[impl] = {"fp32": measure(model, x, mask, False), "bf16_autocast": measure(model, x, mask, True)}
+        res[impl] = {"fp32": measure(model, x, mask, False, extra=extra), "bf16_autocast": measure(model, x, mask, True, extra=extra)}
         del model
         torch.cuda.empty_cache()
     with open(out_path, "w") as f:
