@@ -726,7 +726,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
-    static_assert(!LDSL || (!PAIR && !FUSED && VEC != 1 && sizeof(A) == 4 && !TR::kDot2 && (G == 4 || G == 8)), "LDS-served levels: plain reduce-scatter units");
+    static_assert(!LDSL || (!PAIR && VEC != 1 && sizeof(A) == 4 && !TR::kDot2 && (G == 4 || G == 8)), "LDS-served levels: reduce-scatter units");
     request_all_arguments(p);
     constexpr int NU = BLK / G;
     constexpr int UPW = kWave / G;
@@ -795,7 +795,8 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     __syncthreads();
     CoarseStage cs{p.L, 0, 0, (uint32_t)p.D * (uint32_t)sizeof(TV)};
     if constexpr (LDSL)
-        cs = stage_coarse_levels<TV, VEC, BLK>(tab, p, rs, row_bytes, kGatherLdsFixed + (size_t)NU * scp * (sizeof(uint4) + sizeof(Rec4<A>)));
+        cs = stage_coarse_levels<TV, VEC, BLK>(tab, p, rs, row_bytes,
+                                               kGatherLdsFixed + (size_t)NU * scp * (sizeof(uint4) + sizeof(Rec4<A>) + (FUSED ? 3 * sizeof(A) : 0)));
     // levels [fl, L) are SERVED from LDS: the first staged level whose first sample starts an exchange batch of G samples
     // in every trip (P = 4 / 8: every level; a staged level in front of it is simply not used)
     int fl = cs.first;

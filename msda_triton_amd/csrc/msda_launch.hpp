@@ -175,7 +175,7 @@ constexpr long long kUnitFwdMaxUnits = 12288;
 int option_lds_budget();  // dev knob: cap on the bytes of LDS-resident levels (-1: none)
 int option_lds_stagger();  // dev knob: start-up stagger of an LDSL workgroup's waves, in units of 64 cycles per wave
 int device_cu_count();    // CUs of the current device (cached; msda_api.hip)
-constexpr size_t kRecordLdsBudgetLds = 72 * 1024;  // the records of 16 waves
+constexpr size_t kRecordLdsBudgetLds = 72 * 1024;  // the records of 16 waves (the fused backward's larger records: 100 KB)
 
 struct LdsLevelsPlan {
     bool use;
@@ -189,10 +189,10 @@ template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(c
     constexpr int NU = kBlockLds / G;
     LdsLevelsPlan pl{};
     size_t rec_lds;
-    plan_gather(NU, p.LP, sizeof(A), pl.sc, rec_lds, aux, kRecordLdsBudgetLds);
+    plan_gather(NU, p.LP, sizeof(A), pl.sc, rec_lds, aux, aux ? (size_t)100 * 1024 : kRecordLdsBudgetLds);
     if (pl.sc < p.LP && pl.sc > G) {  // several trips: whole exchange batches of the sample-gradient kernel per trip
         pl.sc = pl.sc / G * G;
-        rec_lds = kGatherLdsFixed + (size_t)NU * (pl.sc + 1) * (16 + 4 * sizeof(A));
+        rec_lds = kGatherLdsFixed + (size_t)NU * (pl.sc + 1) * (16 + (aux ? 7 : 4) * sizeof(A));
     }
     const size_t lev_base = (rec_lds + 127) / 128 * 128, row = (size_t)p.D * sizeof(TV);
     const long long room = (long long)kMaxDynLds - (long long)lev_base - (long long)((row + 15) / 16 * 16);
@@ -218,7 +218,7 @@ template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(c
 
 template <typename T, int VEC, int G, int MODE, typename TV> inline int launch_gather_lds(Params &p, const LdsLevelsPlan &pl, hipStream_t stream)
 {
-    static_assert(MODE == 0 || MODE == 1, "LDS-served levels: the plain operator's forward and sample-gradient kernels");
+    // MODE as in launch_gather: the forward and sample-gradient kernels, plain (0, 1) and with the module prologue (2, 3)
     p.sc = pl.sc;
     p.nqc = pl.nqc;
     p.qw = pl.qw;
@@ -230,13 +230,13 @@ template <typename T, int VEC, int G, int MODE, typename TV> inline int launch_g
         return MSDA_ERR_TOO_LARGE;
     }
     static std::atomic<uint64_t> big_lds_done{0};
-    const ProfileScope prof(MODE == 0 ? "msda_fwd_kernel" : "msda_bwd_sample_kernel", stream);
-    if constexpr (MODE == 0) {
-        auto kernel = msda_fwd_kernel<T, VEC, G, false, TV, false, kBlockLds, true>;
+    const ProfileScope prof(MODE == 0 || MODE == 2 ? "msda_fwd_kernel" : "msda_bwd_sample_kernel", stream);
+    if constexpr (MODE == 0 || MODE == 2) {
+        auto kernel = msda_fwd_kernel<T, VEC, G, MODE == 2, TV, false, kBlockLds, true>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlockLds), pl.lds, stream, p);
     } else {
-        auto kernel = msda_bwd_sample_kernel<T, VEC, G, false, TV, false, kBlockLds, true>;
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, MODE == 3, TV, false, kBlockLds, true>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlockLds), pl.lds, stream, p);
     }
@@ -265,9 +265,12 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, bool PAIR = fal
             return (int)hipGetLastError();
         }
     }
-    if constexpr (!PAIR && sizeof(T) == 4 && sizeof(TV) == 4 && VEC == 4 && ((MODE == 0 && G <= 16) || (MODE == 1 && (G == 4 || G == 8)))) {
-        const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, false);
-        if (pl.use) return launch_gather_lds<T, VEC, G, MODE, TV>(p, pl, stream);
+    // ... and the module's kernels (fused prologue).  fp32 rows only there too: over a bf16 pyramid (64-byte rows) the
+    // module's step at the c2 shape went 1.09 -> 1.31 ms with the levels in LDS
+    if constexpr (!PAIR && sizeof(T) == 4 && VEC == 4 && sizeof(TV) == 4 &&
+                  (((MODE == 0 || MODE == 2) && G <= 16) || ((MODE == 1 || MODE == 3) && (G == 4 || G == 8)))) {
+        const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, MODE == 3);
+        if (pl.use && (MODE < 2 || pl.sc == p.LP)) return launch_gather_lds<T, VEC, G, MODE, TV>(p, pl, stream);
     }
     size_t lds;
     plan_gather(NU, p.LP, sizeof(A), p.sc, lds, MODE == 3);
