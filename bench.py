@@ -296,7 +296,7 @@ def bench_config(name, dev, steps=20, warmup=5):
 def real_pyramid_leg(dev, steps=50, warmup=10):
     """Not a BASELINE config: the c4 decoder call (B=8, Q=900) over the pyramid of an 800 x 1066 image (c3's levels)
     instead of 64 x 64 ... 8 x 8 — what a Grounding-DINO / Deformable-DETR decoder layer sees at COCO size — without
-    and with the level sizes given as host numbers (`level_shapes=`, include/msda_hip.h msda_hint_level_cells)."""
+    and with the level sizes given as host numbers (`level_shapes=`, include/msda_hip.h max_level_cells)."""
     import torch
     from msda_triton_amd import synth
     from msda_triton_amd.functional import multiscale_deformable_attention

@@ -74,7 +74,7 @@
 extern "C" {
 #endif
 
-#define MSDA_ABI_VERSION 9
+#define MSDA_ABI_VERSION 10
 
 #if defined(__GNUC__)
 #define MSDA_API __attribute__((visibility("default")))
@@ -93,6 +93,17 @@ extern "C" {
 #define MSDA_ERR_MISALIGNED (-4)   /* a buffer is not aligned to its element size */
 #define MSDA_ERR_UNSUPPORTED (-5)  /* valid arguments this entry point cannot serve (use the unfused call) */
 
+/*
+ * ONE forward and ONE backward entry point per storage type (ABI 10; ABI 9 carried three generations of them).
+ *
+ * max_level_cells (backward): what the caller knows about the level sizes ON THE HOST.  `shapes` lives on the device, so
+ * the library sizes the single-launch grad_value kernel's LDS cell table for the worst level `I` pixels can form,
+ * (2 I + 2 L) cells — which rules that kernel out for the pyramids of real images (a 100 x 134 ... 13 x 17 pyramid:
+ * 35.6 k cells by the bound, 13.6 k in its largest level) and sends decoder-sized calls on them to the sorted pipeline,
+ * 1.4x slower there.  A caller that knows the level sizes (Hugging Face models carry `spatial_shapes_list`) passes the
+ * bilinear cells of the largest level, max_l (h_l + 1) * (w_l + 1); 0 = unknown.  The workspace query takes the same
+ * number.  A level larger than stated cannot be reported from the kernel: its grad_value rows come back NaN.
+ */
 #define MSDA_DECLARE(SUF)                                                                          \
     MSDA_API int msda_fwd_##SUF(const void *value, const int64_t *shapes, const void *loc,                  \
                        const void *attn, void *out, int64_t B, int64_t I, int64_t H, int64_t D,    \
@@ -105,13 +116,15 @@ extern "C" {
     MSDA_API int msda_bwd_##SUF(const void *grad_out, const void *value, const int64_t *shapes,             \
                        const void *loc, const void *attn, void *grad_value, void *grad_loc,        \
                        void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,     \
-                       int64_t L, int64_t P, int padding_mode, int align_corners, void *workspace, \
-                       int64_t workspace_bytes, void *stream);                                     \
+                       int64_t L, int64_t P, int padding_mode, int align_corners,                  \
+                       int64_t max_level_cells, void *workspace, int64_t workspace_bytes,          \
+                       void *stream);                                                              \
     MSDA_API int msda_bwd_fused_##SUF(const void *grad_out, const void *value, const int64_t *shapes, \
                        const void *proj, const void *ref, void *grad_value, void *grad_proj,       \
                        void *grad_ref_partial, int64_t B, int64_t I, int64_t H, int64_t D,          \
                        int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,              \
-                       int align_corners, void *workspace, int64_t workspace_bytes, void *stream);
+                       int align_corners, int64_t max_level_cells, void *workspace,                 \
+                       int64_t workspace_bytes, void *stream);
 
 MSDA_DECLARE(f32)
 MSDA_DECLARE(f16)
@@ -121,86 +134,30 @@ MSDA_DECLARE(f64)
  * projection, reference points, out, grad_out and the other gradients) is fp32.  For modules that keep the value
  * pyramid in 16 bits (the value projection written straight in the kernel's layout and dtype) without
  * giving up fp32 sampling coordinates; arithmetic is fp32 as everywhere.  Same signatures; workspace sizes are those
- * of elem_size 4. */
+ * of elem_size 4, value_elem_size 2. */
 MSDA_DECLARE(f32_vbf16)
 MSDA_DECLARE(f32_vf16)
 #undef MSDA_DECLARE
 
 /*
- * The backward entry points with the caller's knowledge of the level sizes AS AN ARGUMENT (ABI 9).  `shapes` lives on the
- * device, so the library sizes the single-launch grad_value kernel's LDS cell table for the worst level `I` pixels can
- * form, (2 I + 2 L) cells — which rules that kernel out for the pyramids of real images (a 100 x 134 ... 13 x 17
- * pyramid: 35.6 k cells by the bound, 13.6 k in its largest level) and sends decoder-sized calls on them to the sorted
- * pipeline, 1.4x slower there.  A caller that knows the level sizes on the host (Hugging Face models carry
- * `spatial_shapes_list`) passes max_level_cells = the bilinear cells of the largest level, max_l (h_l + 1) * (w_l + 1);
- * 0 = unknown (then these are msda_bwd_<dtype> / msda_bwd_fused_<dtype>).  The workspace query takes the same number.
- * A level larger than stated cannot be reported from the kernel: its grad_value rows come back NaN.
- */
-#define MSDA_DECLARE_EX(SUF)                                                                                  \
-    MSDA_API int msda_bwd_ex_##SUF(const void *grad_out, const void *value, const int64_t *shapes,            \
-                       const void *loc, const void *attn, void *grad_value, void *grad_loc,                   \
-                       void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,                \
-                       int64_t L, int64_t P, int padding_mode, int align_corners, int64_t max_level_cells,    \
-                       void *workspace, int64_t workspace_bytes, void *stream);                               \
-    MSDA_API int msda_bwd_fused_ex_##SUF(const void *grad_out, const void *value, const int64_t *shapes,      \
-                       const void *proj, const void *ref, void *grad_value, void *grad_proj,                  \
-                       void *grad_ref_partial, int64_t B, int64_t I, int64_t H, int64_t D,                    \
-                       int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,                        \
-                       int align_corners, int64_t max_level_cells, void *workspace,                           \
-                       int64_t workspace_bytes, void *stream);
-MSDA_DECLARE_EX(f32)
-MSDA_DECLARE_EX(f16)
-MSDA_DECLARE_EX(bf16)
-MSDA_DECLARE_EX(f64)
-MSDA_DECLARE_EX(f32_vbf16)
-MSDA_DECLARE_EX(f32_vf16)
-#undef MSDA_DECLARE_EX
-/* elem_size: of everything but `value`; value_elem_size: of `value` / `grad_value` (0: the same — 2 next to elem_size 4
- * for the mixed-storage entry points) */
-/* flags: MSDA_WS_RECORDS_IN_GRADS — the call will ALSO ask for grad_loc / grad_attn (all three gradient buffers
+ * Bytes of device workspace msda_bwd_<dtype> wants for these sizes.  elem_size: of everything but `value`;
+ * value_elem_size: of `value` / `grad_value` (0: the same — 2 next to elem_size 4 for the mixed-storage entry points);
+ * max_level_cells: as for the call (0: unknown).
+ * flags: MSDA_WS_RECORDS_IN_GRADS — the call will ALSO ask for grad_loc / grad_attn (all three gradient buffers
  * non-NULL and 16-byte aligned): the sorted sample records are dead once the gather has run, grad_loc / grad_attn are
  * written last and grad_value only by the finish kernel behind the gather, so the records of as many (batch, head)
  * planes as fit are kept in those buffers and the workspace shrinks (c2 @ 10k: 180 -> 98 MB).  A call with such a
  * workspace but without grad_loc / grad_attn (or misaligned buffers) is rejected (MSDA_ERR_BAD_ARG); a larger workspace
- * is fine. */
-#define MSDA_WS_RECORDS_IN_GRADS 1
-MSDA_API int64_t msda_bwd_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                             int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells,
-                                             int flags);
-MSDA_API int64_t msda_bwd_fused_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                                   int64_t P, int elem_size, int value_elem_size,
-                                                   int64_t max_level_cells);
-
-/*
- * Forward entry points with an OPTIONAL workspace (ABI 9).  When a row of `value` has exactly 64 bytes (D = 32 in
- * bf16 / fp16, D = 16 in fp32) two rows share one 128-byte cache line, and the four corner rows of a bilinear footprint
- * are four half-used lines.  Given msda_fwd_workspace_bytes(...) of workspace (256-byte aligned) the library first
- * builds an x-pair table there — entry p = the rows of pixels p and p + 1 of one head, one line — and gathers from
- * it: both x-corners of a footprint row come from one line (the gather alone: 15.5 -> 8.1 ps per sample,
- * profiles/r04_row_pair_bench.txt).  An internal layout: the tensors' conventions do not change, results agree with
- * the plain entry points to rounding.  workspace == NULL (or too small, or another row size: the query returns 0) is
- * exactly msda_fwd_<dtype> / msda_fwd_fused_<dtype>.  The backward takes its table from the workspace it already has
- * (msda_bwd_workspace_bytes includes the room).  The layout is OFF unless msda_set_option("pairs", 1): measured at c3
- * it does not pay yet (see the option's note below); with it off the query returns 0 and these are the plain calls.
+ * is fine.
  */
-#define MSDA_DECLARE_FWD_EX(SUF)                                                                              \
-    MSDA_API int msda_fwd_ex_##SUF(const void *value, const int64_t *shapes, const void *loc,                 \
-                       const void *attn, void *out, int64_t B, int64_t I, int64_t H, int64_t D,               \
-                       int64_t Q, int64_t L, int64_t P, int padding_mode, int align_corners,                  \
-                       void *workspace, int64_t workspace_bytes, void *stream);                               \
-    MSDA_API int msda_fwd_fused_ex_##SUF(const void *value, const int64_t *shapes, const void *proj,          \
-                       const void *ref, void *out, int64_t B, int64_t I, int64_t H, int64_t D,                \
-                       int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,                        \
-                       int align_corners, void *workspace, int64_t workspace_bytes, void *stream);
-MSDA_DECLARE_FWD_EX(f32)
-MSDA_DECLARE_FWD_EX(f16)
-MSDA_DECLARE_FWD_EX(bf16)
-MSDA_DECLARE_FWD_EX(f64)
-MSDA_DECLARE_FWD_EX(f32_vbf16)
-MSDA_DECLARE_FWD_EX(f32_vf16)
-#undef MSDA_DECLARE_FWD_EX
-/* value_elem_size = sizeof of the value pyramid's storage type */
-MSDA_API int64_t msda_fwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int value_elem_size);
+#define MSDA_WS_RECORDS_IN_GRADS 1
+MSDA_API int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
+                                          int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells,
+                                          int flags);
+/* ... and msda_bwd_fused_<dtype> (grad_value != NULL). */
+MSDA_API int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
+                                                int64_t P, int elem_size, int value_elem_size,
+                                                int64_t max_level_cells);
 
 /*
  * 1 when msda_bwd_<dtype> can produce grad_value for these sizes, 0 when it would return MSDA_ERR_UNSUPPORTED (a plane
@@ -211,26 +168,9 @@ MSDA_API int64_t msda_fwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64
 MSDA_API int msda_bwd_supported(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P,
                                 int elem_size);
 
-/* Bytes of device workspace msda_bwd_<dtype> wants for these sizes; elem_size = sizeof(dtype). */
-MSDA_API int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                          int64_t P, int elem_size);
-
-/* Bytes of device workspace msda_bwd_fused_<dtype> wants (grad_value != NULL) for these sizes. */
-MSDA_API int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                                int64_t P, int elem_size);
-
 /* Largest L*P the fused entry points accept for head dimension D and this element size (beyond it they return
  * MSDA_ERR_UNSUPPORTED and the caller composes the prologue around msda_fwd_/msda_bwd_<dtype>). */
 MSDA_API int64_t msda_fused_lp_limit(int64_t D, int elem_size);
-
-/*
- * Superseded by the max_level_cells argument of msda_bwd_ex_<dtype> / msda_bwd_workspace_bytes_ex (above); kept for one
- * ABI version.  The same bound as a per-THREAD side channel: "no level of the calls that follow on this thread has more
- * than `max_level_cells` bilinear cells"; 0 withdraws it.  msda_bwd_workspace_bytes and msda_bwd_<dtype> must see the
- * same promise (autograd runs the backward on its own thread: set it there).  msda_set_option("level_cells", n) is the
- * same promise process-wide (a thread's own wins; an argument of an _ex call wins over both).
- */
-MSDA_API void msda_hint_level_cells(int64_t max_level_cells);
 
 /* ABI version of the loaded library (== MSDA_ABI_VERSION it was built with). */
 MSDA_API int msda_abi_version(void);
@@ -239,34 +179,44 @@ MSDA_API int msda_abi_version(void);
 MSDA_API const char *msda_last_error(void);
 
 /*
- * Kernel-variant switches for A/B measurements (bench.py, profiling).  Not needed for
- * normal use: the defaults are the fastest measured variants.  Unknown keys return
- * MSDA_ERR_BAD_ARG.  Keys:
+ * Kernel-variant switches for A/B measurements (bench.py, profiling, the option-variant test runs).  Not needed for
+ * normal use: the defaults are the fastest measured variants.  Unknown keys return MSDA_ERR_BAD_ARG.  Keys:
  *   "xcd_map"    1 (default): blockIdx -> (batch, head) mapping keeps each (b,h) plane on one XCD's L2
- *                0: plain linear mapping
+ *                0: plain linear mapping   2: as 1 with the planes of an XCD rotated through the heads
+ *   "lds_levels" 1 (default): fp32 problems large enough to amortise it run the forward / sample-gradient kernels with
+ *                   the coarsest pyramid levels served from LDS (1024-thread workgroups, one per CU: c2 @ 10k forward
+ *                   99 -> 75 us);  0: never;  2: wherever the variant exists (tests)
+ *   "unit_fwd"   1 (default): forwards of at most 12 288 (b, q, h) units take the one-wave-per-unit kernel (decoder
+ *                   calls: cold-cache forward at Q = 100 12.8 -> 9.3 us);  0: never;  2: wherever it exists (tests)
  *   "value_path" 0 (default): grad_value by the single-launch LDS kernel when a (plane, level) fits one workgroup
  *                   (small problems; no workspace needed), else by the sorted gather in the caller's workspace
  *                2: the sorted gather always   3: the single-launch kernel whenever it fits
- *   "overlap"    -1 (default) / 0: the backward's kernels run one after the other on the caller's stream (since ABI 9:
- *                   with the level-major place pass a fork no longer pays at any measured size, and the records kept in
- *                   the gradient buffers want the sample-gradient kernel last);  1: grad_loc / grad_attn run on a forked
- *                   side stream next to grad_value (fork / join with events inside the call, graph-capturable; costs
- *                   ~14 us of host time and ~19 us of latency)
- *   "deterministic" accepted and stored, without effect since ABI 9: grad_value is bitwise reproducible ALWAYS (for
- *                   P <= 1024 points per level) — the place pass of the sorted pipeline and the single-launch kernel of
- *                   the small problems both let their waves take the list-cursor atomics in turns, so a cell's records
- *                   are in the same order in every run (cost: 1.5 us of 46 in the place pass, 2.2 us of 48 in the
- *                   single-launch kernel at the Grounding-DINO decoder shape).  out, grad_loc and grad_attn always were.
- *                   (ABI 8: 1 routed every problem through a one-wave place pass, 2.9x the fwd+bwd time.)
- *   "place_path" 0 (default) / 2: the level-major place pass;  1: the plane-major one where it is faster (pyramids much
- *                   larger than the sample count: 14 us against 21) — its record order follows LDS atomics, grad_value
- *                   may then differ in the last bit from run to run (measurement only)
+ *   "small_ns"   0 (default): workgroups per (plane, level) of the single-launch kernel chosen by the plane count; 1..16
+ *   "q_round"    0 (default): queries per round of the sorted pipeline chosen by size; n: that many (tests)
+ *   "overlap"    -1 (default) / 0: the backward's kernels run one after the other on the caller's stream;  1: grad_loc /
+ *                   grad_attn run on a forked side stream next to grad_value (fork / join with events inside the call,
+ *                   graph-capturable; costs ~14 us of host time and ~19 us of latency; does not pay since round 4)
+ *   "place_path" 0 (default) / 2: the level-major place pass;  1: the plane-major one;  3: the level-major pass with
+ *                   256-thread workgroups everywhere (measurement only)
+ *   "strict"     0 (default);  1: a backward whose grad_value would NOT be bitwise reproducible is refused with
+ *                   MSDA_ERR_UNSUPPORTED instead of run — see "Reproducibility" below
  *   "records_in_grads" 1 (default): msda_bwd_<dtype> with all three gradients keeps sorted records in the grad_loc /
  *                   grad_attn buffers until the sample-gradient kernel overwrites them;  0: never
  *   "profile"    0 (default);  1: event pairs around every kernel launch, read with msda_profile_read (measurement only)
- *   "level_cells" 0 (default): unknown;  n: process-wide form of msda_hint_level_cells(n)
- *   "cell_slices", "small_ns", "gather_win", "wg_target", "debug": experiment knobs, see
- *                msda_triton_amd/csrc/msda_launch.hpp and msda_value_sorted.hpp
+ *   "level_cells" 0 (default): unknown;  n: process-wide form of the max_level_cells argument (an argument wins)
+ * Builds with -DMSDA_DEV (development only; the shipped library rejects these keys) add the experiment knobs
+ * "cell_slices", "gather_win", "wg_target", "lds_budget", "lds_stagger" and the ablation / phase-clock mask "debug":
+ * see msda_triton_amd/csrc/msda_launch.hpp, msda_value_sorted.hpp and tools/phase_clock.py.
+ *
+ * Reproducibility.  out, grad_loc and grad_attn are bitwise reproducible by construction (no atomics, fixed summation
+ * orders).  grad_value is bitwise reproducible for P <= 1024 points per level: the gather sums a cell's records in list
+ * order, and the place pass of the sorted pipeline and the single-launch kernel both let their waves take the
+ * list-cursor atomics in TURNS (acquire / release on the turn word), so the list order is the same in every run.  This
+ * rests on OBSERVED, not architected, behaviour of gfx950: lanes of ONE wave instruction that hit the same LDS word
+ * with ds_add_rtn_u32 are served in a fixed order.  It holds in every run of the test suite (three dedicated tests,
+ * all storage types, option variants) and of the fuzzers, and it is what the tests pin; a future part may differ.
+ * P > 1024 points per level (and "place_path" 1) take the plane-major place pass, whose order follows free-running
+ * atomics: grad_value may then differ in the last bit from run to run — or, with "strict" 1, the call is refused.
  */
 MSDA_API int msda_set_option(const char *key, int value);
 /* Measurement only.  With msda_set_option("profile", 1) every kernel the library launches is bracketed by a HIP event

@@ -15,20 +15,17 @@ LIB_NAME = "libmsda_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PADDING_MODES = {"border": 0, "zeros": 1}
-WS_RECORDS_IN_GRADS = 1  # msda_bwd_workspace_bytes_ex flag (include/msda_hip.h)
+WS_RECORDS_IN_GRADS = 1  # msda_bwd_workspace_bytes flag (include/msda_hip.h)
 # one storage type for every tensor, then the mixed ones: value / grad_value in 16 bits, everything else fp32
 DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64", "f32_vbf16", "f32_vf16")
 
 # every symbol include/msda_hip.h declares
 EXPORTED_SYMBOLS = tuple(
-    [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused", "bwd_fused", "fwd_ex", "fwd_fused_ex", "bwd_ex", "bwd_fused_ex")
-     for s in DTYPE_SUFFIXES]
+    [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused", "bwd_fused") for s in DTYPE_SUFFIXES]
     + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option", "msda_bwd_workspace_bytes",
-       "msda_bwd_fused_workspace_bytes", "msda_bwd_workspace_bytes_ex", "msda_bwd_fused_workspace_bytes_ex",
-       "msda_fwd_workspace_bytes", "msda_bwd_supported", "msda_fused_lp_limit", "msda_hint_level_cells",
-       "msda_profile_read"]
+       "msda_bwd_fused_workspace_bytes", "msda_bwd_supported", "msda_fused_lp_limit", "msda_profile_read"]
 )
 
 _lib = None
@@ -76,44 +73,23 @@ def load():
             ff = getattr(lib, f"msda_fwd_fused_{suf}")
             ff.restype = ci
             ff.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, ci, vp]
+            # the backward: the level-size bound (max_level_cells, 0: unknown) is an argument
             g = getattr(lib, f"msda_bwd_{suf}")
             g.restype = ci
-            g.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, vp, i64, vp]
+            g.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, i64, vp, i64, vp]
             gf = getattr(lib, f"msda_bwd_fused_{suf}")
             gf.restype = ci
-            gf.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, vp, i64, vp]
-            # ... with an optional workspace (x-pair table of a pyramid with 64-byte rows)
-            fx = getattr(lib, f"msda_fwd_ex_{suf}")
-            fx.restype = ci
-            fx.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, vp, i64, vp]
-            ffx = getattr(lib, f"msda_fwd_fused_ex_{suf}")
-            ffx.restype = ci
-            ffx.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, ci, vp, i64, vp]
-            # ... with the level-size bound as an argument (max_level_cells, 0: unknown)
-            gx = getattr(lib, f"msda_bwd_ex_{suf}")
-            gx.restype = ci
-            gx.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, i64, vp, i64, vp]
-            gfx = getattr(lib, f"msda_bwd_fused_ex_{suf}")
-            gfx.restype = ci
-            gfx.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, i64, vp, i64, vp]
+            gf.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, i64, vp, i64, vp]
         lib.msda_bwd_workspace_bytes.restype = i64
-        lib.msda_bwd_workspace_bytes.argtypes = [i64] * 7 + [ci]
+        lib.msda_bwd_workspace_bytes.argtypes = [i64] * 7 + [ci, ci, i64, ci]
         lib.msda_bwd_fused_workspace_bytes.restype = i64
-        lib.msda_bwd_fused_workspace_bytes.argtypes = [i64] * 7 + [ci]
-        lib.msda_bwd_workspace_bytes_ex.restype = i64
-        lib.msda_bwd_workspace_bytes_ex.argtypes = [i64] * 7 + [ci, ci, i64, ci]
-        lib.msda_bwd_fused_workspace_bytes_ex.restype = i64
-        lib.msda_bwd_fused_workspace_bytes_ex.argtypes = [i64] * 7 + [ci, ci, i64]
-        lib.msda_fwd_workspace_bytes.restype = i64
-        lib.msda_fwd_workspace_bytes.argtypes = [i64] * 4 + [ci]
+        lib.msda_bwd_fused_workspace_bytes.argtypes = [i64] * 7 + [ci, ci, i64]
         lib.msda_bwd_supported.restype = ci
         lib.msda_bwd_supported.argtypes = [i64] * 7 + [ci]
         lib.msda_profile_read.restype = ci
         lib.msda_profile_read.argtypes = [ctypes.c_char_p, ci]
         lib.msda_fused_lp_limit.restype = i64
         lib.msda_fused_lp_limit.argtypes = [i64, ci]
-        lib.msda_hint_level_cells.restype = None
-        lib.msda_hint_level_cells.argtypes = [i64]
         lib.msda_abi_version.restype = ci
         lib.msda_last_error.restype = ctypes.c_char_p
         lib.msda_set_option.restype = ci

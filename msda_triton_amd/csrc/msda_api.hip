@@ -26,11 +26,10 @@ static std::atomic<int> g_q_round{0};
 static std::atomic<int> g_level_cells{0};
 static std::atomic<int> g_overlap{-1};
 static std::atomic<int> g_gather_win{0};
-static std::atomic<int> g_deterministic{0};
 static std::atomic<int> g_place_path{0};
-static std::atomic<int> g_pairs{0};
 static std::atomic<int> g_profile{0};
 static std::atomic<int> g_records_in_grads{1};
+static std::atomic<int> g_strict{0};
 static std::atomic<int> g_lds_levels{1};
 static std::atomic<int> g_lds_budget{-1};
 static std::atomic<int> g_unit_fwd{1};
@@ -104,22 +103,13 @@ int option_cell_slices() { return g_cell_slices.load(std::memory_order_relaxed);
 int option_debug() { return g_debug.load(std::memory_order_relaxed); }
 int option_small_ns() { return g_small_ns.load(std::memory_order_relaxed); }
 int option_q_round() { return g_q_round.load(std::memory_order_relaxed); }
-static thread_local int64_t t_level_cells = 0;  // msda_hint_level_cells: this thread's promise for the calls that follow
-int option_level_cells()
-{
-    const int64_t t = t_level_cells;
-    if (t > 0) return t > 0x7fffffff ? 0x7fffffff : (int)t;
-    return g_level_cells.load(std::memory_order_relaxed);
-}
-void set_thread_level_cells(int64_t n) { t_level_cells = n > 0 ? n : 0; }
-int64_t get_thread_level_cells() { return t_level_cells; }
+int option_level_cells() { return g_level_cells.load(std::memory_order_relaxed); }  // process-wide promise (0: unknown)
 int option_overlap() { return g_overlap.load(std::memory_order_relaxed); }
 int option_gather_win() { return g_gather_win.load(std::memory_order_relaxed); }
-int option_deterministic() { return g_deterministic.load(std::memory_order_relaxed); }  // (stored, without effect)
 int option_place_path() { return g_place_path.load(std::memory_order_relaxed); }
-int option_pairs() { return g_pairs.load(std::memory_order_relaxed); }
 int option_profile() { return g_profile.load(std::memory_order_relaxed); }
 int option_records_in_grads() { return g_records_in_grads.load(std::memory_order_relaxed); }
+int option_strict() { return g_strict.load(std::memory_order_relaxed); }
 int option_lds_levels() { return g_lds_levels.load(std::memory_order_relaxed); }
 int option_lds_stagger() { return g_lds_stagger.load(std::memory_order_relaxed); }
 int option_unit_fwd() { return g_unit_fwd.load(std::memory_order_relaxed); }
@@ -181,76 +171,27 @@ void set_error(const char *fmt, ...)
 
 extern "C" int msda_abi_version(void) { return MSDA_ABI_VERSION; }
 
-extern "C" void msda_hint_level_cells(int64_t max_level_cells) { msda::set_thread_level_cells(max_level_cells); }
-
 // the layout lives in a device header (msda_value_sorted.hpp); msda_f32.hip exposes its size formula
-extern "C" int64_t msda_bwd_workspace_bytes_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int);
-
-// room for the x-pair table (rows of exactly 64 bytes of the value storage type; msda_launch.hpp pair_table_bytes)
-static int64_t pair_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int value_elem_size)
-{
-    if (msda::option_pairs() == 0 || value_elem_size <= 0 || D * value_elem_size != 64 || B > 65535) return 0;
-    return (B * H * I * 128 + 255) / 256 * 256;
-}
-
-extern "C" int64_t msda_fwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int value_elem_size)
-{
-    if (B < 0 || I < 0 || H < 0 || D < 0) return 0;
-    return pair_bytes(B, I, H, D, value_elem_size);
-}
+extern "C" int64_t msda_bwd_workspace_bytes_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, int64_t);
 
 extern "C" int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                            int64_t P, int elem_size)
+                                            int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells,
+                                            int flags)
 {
     if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0) return 0;
-    return pair_bytes(B, I, H, D, elem_size) + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0, 0);
+    return msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, (flags & MSDA_WS_RECORDS_IN_GRADS) ? 1 : 0,
+                                         value_elem_size > 0 ? value_elem_size : elem_size, max_level_cells);
 }
 
 extern "C" int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                                  int64_t P, int elem_size)
+                                                  int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells)
 {
     if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0 || elem_size <= 0) return 0;
     // the derived sampling points + attention weights (3 elements per sample, rounded up to 256 bytes), then
     // the sorted pipeline's own workspace (msda_launch.hpp: fused_mat_bytes)
+    (void)value_elem_size;
     const int64_t mat = (B * Q * H * L * P * 3 * (int64_t)elem_size + 255) / 256 * 256;
-    return pair_bytes(B, I, H, D, elem_size) + mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0, 0);
-}
-
-// the level-size bound as an argument: it becomes the thread's promise for the duration of the call
-namespace msda {
-struct LevelCellsScope {
-    int64_t saved;
-    bool on;
-    explicit LevelCellsScope(int64_t n) : saved(get_thread_level_cells()), on(n > 0)
-    {
-        if (on) set_thread_level_cells(n);
-    }
-    ~LevelCellsScope()
-    {
-        if (on) set_thread_level_cells(saved);
-    }
-};
-}  // namespace msda
-
-extern "C" int64_t msda_bwd_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                               int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells,
-                                               int flags)
-{
-    if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0) return 0;
-    const msda::LevelCellsScope scope(max_level_cells);
-    return pair_bytes(B, I, H, D, value_elem_size > 0 ? value_elem_size : elem_size) +
-           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, (flags & MSDA_WS_RECORDS_IN_GRADS) ? 1 : 0,
-                                         value_elem_size > 0 ? value_elem_size : elem_size);
-}
-
-extern "C" int64_t msda_bwd_fused_workspace_bytes_ex(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                                     int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells)
-{
-    if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0 || elem_size <= 0) return 0;
-    const msda::LevelCellsScope scope(max_level_cells);
-    const int64_t mat = (B * Q * H * L * P * 3 * (int64_t)elem_size + 255) / 256 * 256;
-    return pair_bytes(B, I, H, D, value_elem_size > 0 ? value_elem_size : elem_size) + mat +
-           msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0, 0);
+    return mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0, 0, max_level_cells);
 }
 
 extern "C" int msda_bwd_supported_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
@@ -298,109 +239,70 @@ extern "C" int msda_profile_read(char *buf, int cap)
     return n;
 }
 
+// One table for set and get.  dev: an experiment knob, reachable only in builds with -DMSDA_DEV (include/msda_hip.h).
+namespace msda {
+struct OptionEntry {
+    const char *key;
+    std::atomic<int> *slot;
+    int lo, hi;  // accepted range (values outside are clamped to `fallback` when clamp, rejected otherwise)
+    bool dev;
+};
+static const OptionEntry kOptions[] = {
+    {"xcd_map", &g_xcd_map, 0, 2, false},
+    {"value_path", &g_value_path, 0, 3, false},
+    {"level_cells", &g_level_cells, 0, 0x7fffffff, false},
+    {"q_round", &g_q_round, 0, 0x7fffffff, false},
+    {"small_ns", &g_small_ns, 0, 16, false},
+    {"overlap", &g_overlap, -1, 1, false},
+    {"place_path", &g_place_path, 0, 3, false},
+    {"strict", &g_strict, 0, 1, false},
+    {"records_in_grads", &g_records_in_grads, 0, 1, false},
+    {"profile", &g_profile, 0, 1, false},
+    {"lds_levels", &g_lds_levels, 0, 2, false},
+    {"unit_fwd", &g_unit_fwd, 0, 2, false},
+    {"debug", &g_debug, (int)0x80000000, 0x7fffffff, true},
+    {"gather_win", &g_gather_win, 0, 4096, true},
+    {"cell_slices", &g_cell_slices, 0, 64, true},
+    {"wg_target", &g_wg_target, 1, 0x7fffffff, true},
+    {"lds_budget", &g_lds_budget, -1, 0x7fffffff, true},
+    {"lds_stagger", &g_lds_stagger, 0, 4096, true},
+};
+static const OptionEntry *find_option(const char *key)
+{
+    if (key == nullptr) return nullptr;
+    for (const OptionEntry &o : kOptions) {
+        if (strcmp(key, o.key) != 0) continue;
+#ifndef MSDA_DEV
+        if (o.dev) return nullptr;
+#endif
+        return &o;
+    }
+    return nullptr;
+}
+}  // namespace msda
+
 extern "C" int msda_set_option(const char *key, int value)
 {
-    if (key && strcmp(key, "xcd_map") == 0) {
-        msda::g_xcd_map.store(value == 2 ? 2 : value ? 1 : 0, std::memory_order_relaxed);
-        return 0;
+    const msda::OptionEntry *o = msda::find_option(key);
+    if (o == nullptr) {
+        msda::set_error("unknown option '%s'", key ? key : "(null)");
+        return MSDA_ERR_BAD_ARG;
     }
-    if (key && strcmp(key, "value_path") == 0) {
-        msda::g_value_path.store(value == 2 || value == 3 ? value : 0, std::memory_order_relaxed);
-        return 0;
+    if (value < o->lo || value > o->hi || (o->slot == &msda::g_value_path && value == 1) ||
+        (o->slot == &msda::g_gather_win && value != 0 && value < 8)) {
+        msda::set_error("option '%s': value %d out of range [%d, %d]", key, value, o->lo, o->hi);
+        return MSDA_ERR_BAD_ARG;
     }
-    if (key && strcmp(key, "debug") == 0) {
-        msda::g_debug.store(value, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "level_cells") == 0 && value >= 0) {
-        msda::g_level_cells.store(value, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "q_round") == 0 && value >= 0) {
-        msda::g_q_round.store(value, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "small_ns") == 0 && value >= 0 && value <= 16) {
-        msda::g_small_ns.store(value, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "overlap") == 0) {
-        msda::g_overlap.store(value < 0 ? -1 : value ? 1 : 0, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "gather_win") == 0 && value >= 0 && value <= 4096 && (value == 0 || value >= 8)) {
-        msda::g_gather_win.store(value, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "deterministic") == 0) {
-        msda::g_deterministic.store(value ? 1 : 0, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "place_path") == 0) {
-        msda::g_place_path.store(value >= 1 && value <= 3 ? value : 0, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "pairs") == 0) {
-        msda::g_pairs.store(value ? 1 : 0, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "records_in_grads") == 0) {
-        msda::g_records_in_grads.store(value ? 1 : 0, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "profile") == 0) {
-        msda::g_profile.store(value ? 1 : 0, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "lds_stagger") == 0 && value >= 0 && value <= 4096) {
-        msda::g_lds_stagger.store(value, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "unit_fwd") == 0) {
-        msda::g_unit_fwd.store(value == 2 ? 2 : value ? 1 : 0, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "lds_budget") == 0) {
-        msda::g_lds_budget.store(value, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "lds_levels") == 0 && value >= 0 && value <= 2) {
-        msda::g_lds_levels.store(value, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "cell_slices") == 0 && value >= 0 && value <= 64) {
-        msda::g_cell_slices.store(value, std::memory_order_relaxed);
-        return 0;
-    }
-    if (key && strcmp(key, "wg_target") == 0 && value >= 1) {
-        msda::g_wg_target.store(value, std::memory_order_relaxed);
-        return 0;
-    }
-    msda::set_error("unknown option '%s'", key ? key : "(null)");
-    return MSDA_ERR_BAD_ARG;
+    o->slot->store(value, std::memory_order_relaxed);
+    return 0;
 }
 
 extern "C" int msda_get_option(const char *key)
 {
-    if (key && strcmp(key, "xcd_map") == 0) return msda::option_xcd_map();
-    if (key && strcmp(key, "value_path") == 0) return msda::option_value_path();
-    if (key && strcmp(key, "wg_target") == 0) return msda::option_wg_target();
-    if (key && strcmp(key, "cell_slices") == 0) return msda::option_cell_slices();
-    if (key && strcmp(key, "debug") == 0) return msda::option_debug();
-    if (key && strcmp(key, "small_ns") == 0) return msda::option_small_ns();
-    if (key && strcmp(key, "q_round") == 0) return msda::option_q_round();
-    if (key && strcmp(key, "level_cells") == 0) return msda::option_level_cells();
-    if (key && strcmp(key, "overlap") == 0) return msda::option_overlap();
-    if (key && strcmp(key, "gather_win") == 0) return msda::option_gather_win();
-    if (key && strcmp(key, "deterministic") == 0) return msda::option_deterministic();
-    if (key && strcmp(key, "place_path") == 0) return msda::option_place_path();
-    if (key && strcmp(key, "pairs") == 0) return msda::option_pairs();
-    if (key && strcmp(key, "profile") == 0) return msda::option_profile();
-    if (key && strcmp(key, "records_in_grads") == 0) return msda::option_records_in_grads();
-    if (key && strcmp(key, "lds_levels") == 0) return msda::option_lds_levels();
-    if (key && strcmp(key, "lds_budget") == 0) return msda::option_lds_budget();
-    if (key && strcmp(key, "unit_fwd") == 0) return msda::option_unit_fwd();
-    if (key && strcmp(key, "lds_stagger") == 0) return msda::option_lds_stagger();
-    msda::set_error("unknown option '%s'", key ? key : "(null)");
-    return MSDA_ERR_BAD_ARG;
+    const msda::OptionEntry *o = msda::find_option(key);
+    if (o == nullptr) {
+        msda::set_error("unknown option '%s'", key ? key : "(null)");
+        return MSDA_ERR_BAD_ARG;
+    }
+    return o->slot->load(std::memory_order_relaxed);
 }

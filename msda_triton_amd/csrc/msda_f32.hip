@@ -6,10 +6,10 @@ MSDA_DEFINE_ENTRY_POINTS(f32, float)
 // size of the backward workspace (shared by every dtype: the accumulate type decides the record sizes)
 extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_bytes_impl(
     int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int elem_size, int records_in_grads,
-    int value_elem_size)
+    int value_elem_size, int64_t max_level_cells)
 {
     // problems the single-launch kernel takes need no workspace at all
-    const msda::Dims d{B, I, H, D, Q, L, P};
+    const msda::Dims d{B, I, H, D, Q, L, P, max_level_cells > 0 ? max_level_cells : 0};
     const bool small = elem_size == 8 ? msda::small_path_chosen<double>(d) : msda::small_path_chosen<float>(d);
     const size_t acc = elem_size == 8 ? 8 : 4;
     if (small) return 0;

@@ -73,9 +73,6 @@ struct Params {
     // 1 first round (-> accumulator), 2 middle round (accumulator +=), 3 last round (accumulator + this -> grad_value)
     int q_begin, q_end, ent_cap, finish_mode;
     void *ws_accum;     // [pairs][I][D] acc-typed running sums between rounds (nullptr: a single round)
-    // x-pair table of the value pyramid (PAIR kernels): [B][H][I][2][D], entry p = the rows of pixels p and p + 1 of one
-    // head, one 128-byte line when a row has 64 bytes — a bilinear footprint's two x-corners then come from ONE line
-    const void *pairs;
     int lds_lev_bytes;  // LDSL gather kernels: LDS bytes set aside for the rows of the coarsest levels
     int lds_stagger;    // ... wave w starts w * lds_stagger * 64 cycles late
     int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
@@ -119,16 +116,6 @@ template <typename A> struct GatherLds {
     }
 };
 constexpr size_t kGatherLdsFixed = kGatherLdsFixedBytes;
-
-// PAIR: the four corner offsets in pair-table addressing.  make_taps was given the table's entry stride, so every
-// offset points at its pixel's OWN entry (left half); an x1 corner that is the x0 corner's right-hand neighbour
-// (x1 = x0 + 1 in the same image row: all but clamped / masked corners) is read from the right half of x0's entry
-// instead — same line as the x0 corner.
-__device__ __forceinline__ void pair_offsets(uint32_t (&off)[4], uint32_t entry_bytes)
-{
-    if (off[1] == off[0] + entry_bytes) off[1] = off[0] + entry_bytes / 2;
-    if (off[3] == off[2] + entry_bytes) off[3] = off[2] + entry_bytes / 2;
-}
 
 #ifdef MSDA_DEV
 // dev builds: a phase clock for the forward kernel (msda_set_option("debug", 2048)): every wave sums the cycles between
@@ -245,10 +232,9 @@ __device__ __forceinline__ void request_all_arguments(const Params &p)
 // ==========================================================================================
 // TV: storage type of the value rows (T unless the caller keeps value in 16 bits next to fp32 coordinates / weights /
 // output: the "mixed" entry points, msda_mixed.hip)
-// PAIR: the value rows come from the x-pair table (Params::pairs): a unit's G lanes are two halves of G / 2 lanes, the
-// left half gathers the rows of the x0 corners, the right half those of the x1 corners — for x1 = x0 + 1 both sit in
-// the line of pixel x0, so a footprint costs two 128-byte lines instead of four half-used ones (64-byte rows: 15.5 ->
-// 8.1 ps per sample in the gather alone, profiles/r04_row_pair_bench.txt).  The halves' sums meet once per unit.
+// (Round 4's x-pair table for 64-byte rows — every row stored twice so that a footprint's two x-corners come from ONE
+//  128-byte line: 15.5 -> 8.1 ps per sample in the gather alone, profiles/r04_row_pair_bench.txt — was removed in
+//  round 5: inside the kernels it netted -3 us forward / +7 us backward at c3 and stayed off)
 // LDSL (BLK = kBlockLds threads): the coarsest levels of the plane — the longest SUFFIX of the level list whose rows fit
 // Params::lds_lev_bytes — are copied into LDS once per workgroup and their samples read from there (coarse_levels()).
 // The gather is bound by the vector-memory path (64 B/clk/CU); an LDS row read costs a quarter of that,
@@ -258,17 +244,16 @@ __device__ __forceinline__ void request_all_arguments(const Params &p)
 //  cache a batch of 16 loads per lane takes ~2 500 cycles, four of them per unit — but 64 loads at once took 2.5x as
 //  long as the four batches together (in-kernel clock, Q = 10 / 100).  What small grids want is more WAVES with few
 //  loads each: msda_fwd_unit_kernel below.)
-template <typename T, int VEC, int G, bool FUSED, typename TV = T, bool PAIR = false, int BLK = kBlock, bool LDSL = false>
+template <typename T, int VEC, int G, bool FUSED, typename TV = T, int BLK = kBlock, bool LDSL = false>
 __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlock ? 5 : 4))) void msda_fwd_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
-    static_assert(!(LDSL && (PAIR || VEC == 1)), "the LDS-served levels use the plain 16-byte vector path");
+    static_assert(!(LDSL && VEC == 1), "the LDS-served levels use the 16-byte vector path");
     request_all_arguments(p);
     constexpr int NU = BLK / G;        // units per workgroup and query chunk
     constexpr int UPW = kWave / G;     // units per wave
-    constexpr int GH = PAIR ? G / 2 : G;  // lanes across one row's channels
 
     const int slots = (p.nqc + p.qw - 1) / p.qw;
     int pair, slot;
@@ -279,19 +264,15 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     const GatherLds<A> lds(NU, scp);
     LevelTab *tab = lds.tab;
 
-    // row stride and plane: the pyramid itself (rows of one head H*D apart), or the pair table (one entry of 2*D per pixel)
-    const uint32_t row_bytes = PAIR ? 2u * (uint32_t)p.D * (uint32_t)sizeof(TV) : (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TV);
-    const TV *plane = PAIR ? static_cast<const TV *>(p.pairs) + ((size_t)b * p.H + h) * p.I * 2 * p.D
-                           : static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
-    const uint32_t plane_bytes = PAIR ? (uint32_t)((size_t)p.I * 2 * p.D * sizeof(TV))
-                                      : (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV));
+    // row stride and plane: the rows of one head are H*D elements apart
+    const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TV);
+    const TV *plane = static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
+    const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV));
     const rsrc_t rs = make_rsrc(plane, plane_bytes);
 
     const int tid = threadIdx.x;
     const int wave = tid / kWave, lane = tid % kWave;
-    const int wunit = lane / G, jl = lane % G;  // unit inside the wave, lane inside the unit
-    const int half = PAIR ? jl / GH : 0;        // PAIR: 0 = the x0 corners, 1 = the x1 corners
-    const int j = PAIR ? jl % GH : jl;          // lane across the row's channels
+    const int wunit = lane / G, j = lane % G;  // unit inside the wave, lane inside the unit (across the row's channels)
     uint4 *w_off = lds.s_off + wave * UPW * scp;
     Rec4<A> *w_rec = lds.s_rec + wave * UPW * scp;
     // per-plane bases (64-bit, uniform) + 32-bit per-sample indices (the host checks Q*H*L*P*3 < 2^31)
@@ -301,7 +282,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     const T *refp = FUSED ? static_cast<const T *>(p.ref) + (size_t)b * p.Q * p.ref_dim : nullptr;
     const int HLP = p.H * p.LP;
     const float inv_P = 1.0f / (float)p.P;
-    const int nchan_chunks = (p.D + GH * VEC - 1) / (GH * VEC);  // (PAIR: 1, the host checks)
+    const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
     const int qc_end = min(p.nqc, (slot + 1) * p.qw);
 
     // The workgroup's FIRST chunk of samples is requested before the level table is waited for (the addresses do not
@@ -381,7 +362,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
         const bool unit_ok = q < (LDSL ? q_hi : p.Q);
         const bool use_pre = pre && (LDSL || it == 0);
         for (int cc = 0; cc < nchan_chunks; ++cc) {
-            const int c0 = (cc * GH + j) * VEC;
+            const int c0 = (cc * G + j) * VEC;
             const bool lane_ok = unit_ok && (c0 < p.D);
             const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(TV);
             A acc[VEC];
@@ -424,12 +405,12 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                     wave_lds_sync();
                     if (unit_ok) {
                         A mx = -__builtin_huge_val();
-                        for (int sl = jl; sl < sc; sl += G) mx = fmax_t(mx, w_rec[imul24(wunit, scp) + sl].v[0]);
+                        for (int sl = j; sl < sc; sl += G) mx = fmax_t(mx, w_rec[imul24(wunit, scp) + sl].v[0]);
                         mx = group_max<G>(mx);
                         A sum = (A)0;
-                        for (int sl = jl; sl < sc; sl += G) sum += exp_t(w_rec[imul24(wunit, scp) + sl].v[0] - mx);
+                        for (int sl = j; sl < sc; sl += G) sum += exp_t(w_rec[imul24(wunit, scp) + sl].v[0] - mx);
                         sum = group_sum<G>(sum);
-                        if (jl == 0) {
+                        if (j == 0) {
                             w_rec[imul24(wunit, scp) + sc].v[0] = mx;
                             w_rec[imul24(wunit, scp) + sc].v[1] = (A)1 / sum;
                         }
@@ -474,7 +455,6 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                         w.v[1] = a * (wy0 * t.dx);
                         w.v[2] = a * (t.dy * wx0);
                         w.v[3] = a * (t.dy * t.dx);
-                        if constexpr (PAIR) pair_offsets(t.off, row_bytes);
                         const int rslot = imul24(fu, scp) + (sl - s0);
                         w_off[rslot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
                         w_rec[rslot] = w;
@@ -498,24 +478,6 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                 if (lane_ok) {
                     const uint4 *uo = w_off + imul24(wunit, scp);
                     const Rec4<A> *uw = w_rec + imul24(wunit, scp);
-                    if constexpr (PAIR) {
-                        // this half's two rows (y0, y1 of its x-corner): half the loads per lane, whole lines per pair
-#pragma unroll 8
-                        for (int s = 0; s < sc; ++s) {
-                            const uint4 o = uo[s];
-                            const Rec4<A> w = uw[s];
-                            const uint32_t oa = half ? o.y : o.x, ob = half ? o.w : o.z;
-                            const A wa = half ? w.v[1] : w.v[0], wb = half ? w.v[3] : w.v[2];
-                            A v0[VEC], v1[VEC];
-                            load_row<TV, VEC>(rs, oa + lane_off, v0);
-                            load_row<TV, VEC>(rs, ob + lane_off, v1);
-#pragma unroll
-                            for (int i = 0; i < VEC; ++i) {
-                                acc[i] = fma_t(wa, v0[i], acc[i]);
-                                acc[i] = fma_t(wb, v1[i], acc[i]);
-                            }
-                        }
-                    } else {
                     // samples [0, s_lds) of this trip gather from memory, [s_lds, sc) from the LDS-resident levels
                     const int s_lds = LDSL ? min(max(imul24(fl, p.P) - s0, 0), sc) : sc;
 #ifdef MSDA_DEV  // ablations (msda_set_option("debug", mask)): 256 no memory gather, 512 no LDS gather
@@ -553,16 +515,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                             blend4<VEC, sizeof(TV) == sizeof(A)>(acc, w.v, v0, v1, v2, v3);
                         }
                     }
-                    }
                 }
             }
-            if constexpr (PAIR) {  // x0 corners + x1 corners (a live unit's halves are both here)
-                if (unit_ok) {
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], GH, kWave);
-                }
-            }
-            if (lane_ok && half == 0) {
+            if (lane_ok) {
                 Pack<T, VEC> o;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) o.v[i] = TR::from_acc(acc[i]);
@@ -716,25 +671,21 @@ __global__ __launch_bounds__(kBlock) void msda_fwd_unit_kernel(const Params p)
 // backward, part 1: grad_loc and grad_attn.  Same decomposition as the forward; every sample's
 // three results are reduced over the unit's G lanes with DPP moves and written exactly once.
 // ==========================================================================================
-// PAIR: as in the forward — the value rows come from the x-pair table, the unit's left half of lanes takes the x0
-// corners, the right half the x1 corners; the three results are linear in the four dot products, so each half forms
-// its share and the usual reduction over the unit's lanes adds them up.
 // LDSL (BLK = kBlockLds): the coarsest levels served from LDS, as in the forward (reduce-scatter units only).
-template <typename T, int VEC, int G, bool FUSED, typename TV = T, bool PAIR = false, int BLK = kBlock, bool LDSL = false>
+template <typename T, int VEC, int G, bool FUSED, typename TV = T, int BLK = kBlock, bool LDSL = false>
 __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
-    static_assert(!LDSL || (!PAIR && VEC != 1 && sizeof(A) == 4 && !TR::kDot2 && (G == 4 || G == 8)), "LDS-served levels: reduce-scatter units");
+    static_assert(!LDSL || (VEC != 1 && sizeof(A) == 4 && !TR::kDot2 && (G == 4 || G == 8)), "LDS-served levels: reduce-scatter units");
     request_all_arguments(p);
     constexpr int NU = BLK / G;
     constexpr int UPW = kWave / G;
-    constexpr int GH = PAIR ? G / 2 : G;  // lanes across one row's channels
     // units of 4 / 8 lanes hand every sample's dot products to ONE owner lane (reduce-scatter) instead of all-reducing
     // (16-bit operators keep the all-reduce: with v_dot2c rows the two cost the same instructions, and the all-reduce
     // measured 5-6 % faster at c3 / c5)
-    constexpr bool kScatter = !PAIR && sizeof(A) == 4 && !TR::kDot2 && (G == 4 || G == 8);
+    constexpr bool kScatter = sizeof(A) == 4 && !TR::kDot2 && (G == 4 || G == 8);
 
     const int slots = (p.nqc + p.qw - 1) / p.qw;
     int pair, slot;
@@ -746,16 +697,14 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     const GatherLds<A> lds(NU, scp, FUSED);
     LevelTab *tab = lds.tab;
 
-    const uint32_t row_bytes = PAIR ? 2u * (uint32_t)p.D * (uint32_t)sizeof(TV) : (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TV);
-    const TV *plane = PAIR ? static_cast<const TV *>(p.pairs) + ((size_t)b * p.H + h) * p.I * 2 * p.D
-                           : static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
-    const uint32_t plane_bytes = PAIR ? (uint32_t)((size_t)p.I * 2 * p.D * sizeof(TV))
-                                      : (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV));
+    const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TV);
+    const TV *plane = static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
+    const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV));
     const rsrc_t rs = make_rsrc(plane, plane_bytes);
 
     const int tid = threadIdx.x;
     const int wave = tid / kWave, lane = tid % kWave;
-    const int wunit = lane / G, j = lane % G;  // (PAIR: j / GH = which x-corner, j % GH = lane across the row's channels)
+    const int wunit = lane / G, j = lane % G;  // unit inside the wave, lane across the row's channels
     uint4 *w_off = lds.s_off + wave * UPW * scp;
     Rec4<A> *w_rec = lds.s_rec + wave * UPW * scp;
     // per-plane bases (64-bit, uniform) + 32-bit per-sample indices (the host checks Q*H*L*P*2 < 2^31)
@@ -768,7 +717,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     const A half_inv_P = (A)1 / (A)(2 * p.P);
     const int HLP = p.H * p.LP;
     const float inv_P = 1.0f / (float)p.P;
-    const int nchan_chunks = (p.D + GH * VEC - 1) / (GH * VEC);  // (PAIR: 1, the host checks)
+    const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
     const int qc_end = min(p.nqc, (slot + 1) * p.qw);
 
     // the workgroup's first chunk of samples requested before the level table is waited for, as in the forward
@@ -914,7 +863,6 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                     r.v[1] = t.dy;
                     r.v[2] = t.gx_on ? a * sx : (A)0;
                     r.v[3] = t.gy_on ? a * sy : (A)0;
-                    if constexpr (PAIR) pair_offsets(t.off, row_bytes);
                     const int rslot = imul24(fu, scp) + (sl - s0);
                     w_off[rslot] = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
                     w_rec[rslot] = r;
@@ -955,73 +903,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                         up[s] = res;
                     }
                 };
-                if constexpr (PAIR) {
-                    // this lane's x-corner: rows y0 and y1 of UB samples in flight (2 * UB loads), two dot products per
-                    // sample.  With t = (1-dy) da + dy db:  gA = c t,  gX = +-t,  gY = c (db - da),  c = dx (x1 half) or
-                    // 1 - dx (x0 half); the reduction over the unit's lanes adds the halves.
-                    constexpr int UB = 8;
-                    const int hx = j / GH, c0 = (j % GH) * VEC;
-                    const bool lane_in = c0 < p.D;
-                    const uint32_t lane_off = (uint32_t)(lane_in ? c0 : 0) * (uint32_t)sizeof(TV);
-                    Pack<T, VEC> gp;
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) gp.v[i] = TR::from_acc((A)0);
-                    if (lane_in) gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
-                    A g[VEC];
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) g[i] = TR::to_acc(gp.v[i]);
-                    using RLV = RawLoad<sizeof(TV) * VEC>;
-                    for (int sb = 0; sb < sc; sb += UB) {
-                        Pack<TV, VEC> va[UB], vb[UB];  // (kept packed until they are consumed)
-#pragma unroll
-                        for (int u = 0; u < UB; ++u) {
-                            const uint4 o = uo[min(sb + u, sc - 1)];  // tail: recompute the last sample, its store is skipped
-                            va[u] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, (hx ? o.y : o.x) + lane_off));
-                            vb[u] = __builtin_bit_cast(Pack<TV, VEC>, RLV::load(rs, (hx ? o.w : o.z) + lane_off));
-                        }
-#pragma unroll
-                        for (int u = 0; u < UB; ++u) {
-                            const Rec4<A> ru = up[min(sb + u, sc - 1)];
-                            A da = 0, db = 0;
-                            if constexpr (TR::kDot2 && (VEC % 2) == 0 && sizeof(TV) == sizeof(T)) {
-                                using P2 = typename TR::pair_t;
-                                struct Pairs {
-                                    P2 p[VEC / 2];
-                                };
-                                const Pairs gq = __builtin_bit_cast(Pairs, gp), qa = __builtin_bit_cast(Pairs, va[u]),
-                                            qb = __builtin_bit_cast(Pairs, vb[u]);
-#pragma unroll
-                                for (int i = 0; i < VEC / 2; ++i) {
-                                    da = TR::dot2(gq.p[i], qa.p[i], da);
-                                    db = TR::dot2(gq.p[i], qb.p[i], db);
-                                }
-                            } else {
-#pragma unroll
-                                for (int i = 0; i < VEC; ++i) {
-                                    da = fma_t(g[i], Traits<TV>::to_acc(va[u].v[i]), da);
-                                    db = fma_t(g[i], Traits<TV>::to_acc(vb[u].v[i]), db);
-                                }
-                            }
-                            if (sb + u < sc) {  // uniform
-                                const A dx = ru.v[0], dy = ru.v[1];
-                                const A cx = hx ? dx : (A)1 - dx;
-                                const A t = fma_t(dy, db, ((A)1 - dy) * da);
-                                A gA = cx * t, gX = hx ? t : -t, gY = cx * (db - da);
-                                gA = group_sum<G>(gA);
-                                gX = group_sum<G>(gX);
-                                gY = group_sum<G>(gY);
-                                if (j == 0) {
-                                    Rec4<A> res;
-                                    res.v[0] = gA;
-                                    res.v[1] = ru.v[2] * gX;
-                                    res.v[2] = ru.v[3] * gY;
-                                    res.v[3] = (A)0;
-                                    up[sb + u] = res;
-                                }
-                            }
-                        }
-                    }
-                } else if (kScatter && nchan_chunks == 1) {
+                if (kScatter && nchan_chunks == 1) {
                     // fast path, units of 4 or 8 lanes: the partial dot products of G samples are reduce-SCATTERED over
                     // the unit (quad_steps / half_step, msda_common.hpp) — lane j ends up with the four complete dot
                     // products of sample sb + j, combines them ONCE and parks the result itself.  (Until round 5 every
@@ -1342,28 +1224,6 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
             }
         }
     }
-}
-
-// ==========================================================================================
-// x-pair table: pairs[b][h][p] = {row (b, p, h), row (b, p + 1, h)} of the value pyramid, 2 * row_bytes per entry.
-// One thread per 16-byte piece of the pyramid, in the pyramid's own order (coalesced reads); the piece is stored twice:
-// left half of entry p, right half of entry p - 1.  (The right half of a plane's last entry is never read: an x1
-// corner uses it only when pixel x0 + 1 exists.)  Rows of 16 * row16 bytes.
-// ==========================================================================================
-template <int kUnused = 0>  // (a template so that every translation unit may carry a copy)
-__global__ __launch_bounds__(kBlock) void msda_pairs_build_kernel(const uint4 *value, uint4 *pairs, int I, int H, int row16)
-{
-    const int per_pixel = H * row16;
-    const long long n = (long long)I * per_pixel;  // pieces of one batch element
-    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= n) return;
-    const int b = (int)blockIdx.y;
-    const int pix = (int)(gid / per_pixel), rem = (int)(gid - (long long)pix * per_pixel);
-    const int h = rem / row16, q = rem - h * row16;
-    const uint4 v = value[(size_t)b * n + gid];
-    uint4 *plane = pairs + ((size_t)b * H + h) * (size_t)I * 2 * row16;
-    plane[(size_t)pix * 2 * row16 + q] = v;
-    if (pix > 0) plane[(size_t)(pix - 1) * 2 * row16 + row16 + q] = v;
 }
 
 }  // namespace msda

@@ -22,6 +22,7 @@ int option_q_round();       // queries per round of the sorted grad_value path (
 int option_debug();         // dev-only ablation mask
 int option_place_path();    // 0: level-major place pass with LDS-staged runs (msda_value_place.hpp); 1: the plane-major place pass
 int option_records_in_grads();  // 1 (default): the sorted records may live in the caller's grad_loc / grad_attn buffers
+int option_strict();        // 1: refuse a backward whose grad_value would not be bitwise reproducible
 int option_overlap();       // 1: grad_loc/grad_attn and grad_value run concurrently on a forked side stream; 0: never; -1: automatic
 // fork-join helpers around a lazily created per-device side stream (msda_api.hip)
 hipStream_t side_stream_fork(hipStream_t user);   // side stream that waits for everything queued on `user`
@@ -36,22 +37,6 @@ struct ProfileScope {
     ProfileScope(const char *name, hipStream_t s) : token(profile_begin(name, s)), stream(s) {}
     ~ProfileScope() { profile_end(token, stream); }
 };
-void set_thread_level_cells(int64_t n);   // this thread's promise about the level sizes (msda_hint_level_cells)
-int64_t get_thread_level_cells();
-// max_level_cells argument of the _ex entry points: the thread's promise for the duration of one call
-struct LevelCellsArg {
-    int64_t saved;
-    bool on;
-    explicit LevelCellsArg(int64_t n) : saved(get_thread_level_cells()), on(n > 0)
-    {
-        if (on) set_thread_level_cells(n);
-    }
-    ~LevelCellsArg()
-    {
-        if (on) set_thread_level_cells(saved);
-    }
-};
-
 constexpr int kRecordLdsBudget = 48 * 1024;                // per workgroup, parked sample records
 constexpr int kMaxDynLds = 160 * 1024 - 2048;  // leaves room for small static __shared__ objects
 
@@ -74,7 +59,10 @@ template <typename K> inline void allow_big_lds(K kernel, std::atomic<uint64_t> 
 
 struct Dims {
     int64_t B, I, H, D, Q, L, P;
+    int64_t cells = 0;  // the caller's max_level_cells argument: no level has more bilinear cells (0: unknown)
 };
+// ... or the process-wide promise (msda_set_option("level_cells", n)); 0: unknown
+inline int64_t level_cells_bound(const Dims &d) { return d.cells > 0 ? d.cells : (int64_t)option_level_cells(); }
 
 template <typename T>
 inline int check_common(const Dims &d, int padding_mode, const void *const *ptrs, int nptrs)
@@ -164,7 +152,6 @@ inline void plan_gather(int NU, int LP, size_t acc_bytes, int &sc, size_t &lds, 
 }
 
 // MODE 0: forward, 1: grad_loc/grad_attn, 2: fused forward, 3: fused backward (sample half)
-// PAIR: value rows from the x-pair table (p.pairs); G then counts both halves of a unit's lanes
 // ---- the gather kernels with the coarsest levels in LDS (msda_kernels.hpp, LDSL): ONE 1024-thread workgroup per CU,
 // every (b, h) plane cut into as many runs of query chunks as fill the chip once ----
 int option_lds_levels();  // 0: never, 1: where lds_levels_plan says so, 2: wherever the kernels exist
@@ -232,18 +219,18 @@ template <typename T, int VEC, int G, int MODE, typename TV> inline int launch_g
     static std::atomic<uint64_t> big_lds_done{0};
     const ProfileScope prof(MODE == 0 || MODE == 2 ? "msda_fwd_kernel" : "msda_bwd_sample_kernel", stream);
     if constexpr (MODE == 0 || MODE == 2) {
-        auto kernel = msda_fwd_kernel<T, VEC, G, MODE == 2, TV, false, kBlockLds, true>;
+        auto kernel = msda_fwd_kernel<T, VEC, G, MODE == 2, TV, kBlockLds, true>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlockLds), pl.lds, stream, p);
     } else {
-        auto kernel = msda_bwd_sample_kernel<T, VEC, G, MODE == 3, TV, false, kBlockLds, true>;
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, MODE == 3, TV, kBlockLds, true>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlockLds), pl.lds, stream, p);
     }
     return (int)hipGetLastError();
 }
 
-template <typename T, int VEC, int G, int MODE, typename TV = T, bool PAIR = false> inline int launch_gather(Params &p, hipStream_t stream)
+template <typename T, int VEC, int G, int MODE, typename TV = T> inline int launch_gather(Params &p, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
     constexpr int NU = kBlock / G;
@@ -251,7 +238,7 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, bool PAIR = fal
     // fp32 operators only: measured at c3 (bf16, 64-byte rows: forward 88 against 86 us) and c5 (fp16, D = 64, L * P = 40 in
     // three trips: 3.17 against 2.93 ms) the 16-bit operators do not gain
     // small problems (decoder calls): the forward with one wave per unit (msda_fwd_unit_kernel)
-    if constexpr (MODE == 0 && !PAIR && VEC * sizeof(T) == 16 && sizeof(A) == 4) {
+    if constexpr (MODE == 0 && VEC * sizeof(T) == 16 && sizeof(A) == 4) {
         const long long units = (long long)p.B * p.Q * p.H;
         const int gl = p.D / VEC;
         if (option_unit_fwd() != 0 && (p.D % VEC) == 0 && gl >= 1 && gl <= kWave && (gl & (gl - 1)) == 0 && p.LP <= 1024 &&
@@ -267,7 +254,7 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, bool PAIR = fal
     }
     // ... and the module's kernels (fused prologue).  fp32 rows only there too: over a bf16 pyramid (64-byte rows) the
     // module's step at the c2 shape went 1.09 -> 1.31 ms with the levels in LDS
-    if constexpr (!PAIR && sizeof(T) == 4 && VEC == 4 && sizeof(TV) == 4 &&
+    if constexpr (sizeof(T) == 4 && VEC == 4 && sizeof(TV) == 4 &&
                   (((MODE == 0 || MODE == 2) && G <= 16) || ((MODE == 1 || MODE == 3) && (G == 4 || G == 8)))) {
         const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, MODE == 3);
         if (pl.use && (MODE < 2 || pl.sc == p.LP)) return launch_gather_lds<T, VEC, G, MODE, TV>(p, pl, stream);
@@ -292,19 +279,19 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, bool PAIR = fal
     static std::atomic<uint64_t> big_lds_done{0};  // one per template instantiation
     const ProfileScope prof(MODE == 0 || MODE == 2 ? "msda_fwd_kernel" : "msda_bwd_sample_kernel", stream);
     if constexpr (MODE == 3) {
-        auto kernel = msda_bwd_sample_kernel<T, VEC, G, true, TV, PAIR>;
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, true, TV>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else if constexpr (MODE == 1) {
-        auto kernel = msda_bwd_sample_kernel<T, VEC, G, false, TV, PAIR>;
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, false, TV>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else if constexpr (MODE == 2) {
-        auto kernel = msda_fwd_kernel<T, VEC, G, true, TV, PAIR>;
+        auto kernel = msda_fwd_kernel<T, VEC, G, true, TV>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else {
-        auto kernel = msda_fwd_kernel<T, VEC, G, false, TV, PAIR>;
+        auto kernel = msda_fwd_kernel<T, VEC, G, false, TV>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     }
@@ -328,48 +315,6 @@ template <typename T, int MODE, typename TV = T> inline int dispatch_gather(Para
     constexpr int VECF = 16 / sizeof(T);  // channels per lane (mixed storage: the 16-bit value rows load as 8-byte pieces)
     if (vec_ok && (p.D % VECF) == 0) return dispatch_group<T, VECF, MODE, TV>(p, stream);
     return dispatch_group<T, 1, MODE, TV>(p, stream);
-}
-
-// ---- x-pair table of the value pyramid (msda_kernels.hpp, PAIR): for rows of exactly 64 bytes ----
-int option_pairs();  // 0: never; else where the shape qualifies and the caller gave workspace (msda_api.hip)
-
-// does the pair layout apply to this value storage type and head dimension?
-template <typename TV> inline bool pair_shape_ok(int64_t D) { return D * (int64_t)sizeof(TV) == 64; }
-inline size_t pair_table_bytes(int64_t B, int64_t I, int64_t H) { return align_up((size_t)(B * H * I) * 128, 256); }
-
-// lanes of a PAIR unit: two halves of (64 bytes / bytes per lane)
-template <typename T, typename TV> constexpr int pair_group()
-{
-    constexpr int VECF = 16 / (int)sizeof(T);            // channels per lane
-    return 2 * (64 / (VECF * (int)sizeof(TV)));           // T = TV 16 bit: 8;  fp32 next to a 16-bit pyramid: 16;  fp32 / fp64 rows of 64 bytes: 8
-}
-
-template <typename TV> inline int build_pairs(const void *value, void *pairs, const Dims &d, hipStream_t stream)
-{
-    const int row16 = (int)(d.D * (int64_t)sizeof(TV) / 16);
-    const long long n = (long long)d.I * d.H * row16;
-    if (d.B > 65535 || n >= ((long long)1 << 31) * kBlock) return MSDA_ERR_TOO_LARGE;
-    const ProfileScope prof("msda_pairs_build_kernel", stream);
-    hipLaunchKernelGGL(msda_pairs_build_kernel<0>, dim3((unsigned)((n + kBlock - 1) / kBlock), (unsigned)d.B), dim3(kBlock), 0, stream,
-                       static_cast<const uint4 *>(value), static_cast<uint4 *>(pairs), (int)d.I, (int)d.H, row16);
-    return (int)hipGetLastError();
-}
-
-// the gather kernels on the pair table: MODE as in launch_gather
-template <typename T, int MODE, typename TV> inline int dispatch_gather_pairs(Params &p, hipStream_t stream)
-{
-    constexpr int VECF = 16 / sizeof(T);
-    return launch_gather<T, VECF, pair_group<T, TV>(), MODE, TV, true>(p, stream);
-}
-
-// can this call take the pair kernels?  (16-byte vector path, rows of 64 bytes, enough aligned workspace for the table)
-template <typename T, typename TV>
-inline bool pairs_ok(const Params &p, const Dims &d, bool vec_ok, const void *workspace, int64_t workspace_bytes)
-{
-    constexpr int VECF = 16 / sizeof(T);
-    return option_pairs() != 0 && vec_ok && pair_shape_ok<TV>(d.D) && (d.D % VECF) == 0 && d.B <= 65535 &&
-           workspace != nullptr && aligned_to(workspace, 256) && (uint64_t)workspace_bytes >= pair_table_bytes(d.B, d.I, d.H) &&
-           (size_t)d.I * 128 < ((size_t)1 << 31);
 }
 
 // ---- sorted (gather-formulated) grad_value: K1..K5 of msda_value_sorted.hpp ----
@@ -488,6 +433,11 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
     // and one rule — grad_value is bitwise reproducible — is worth more than 3 % on that shape.  place_path = 1 keeps
     // the plane-major pass reachable for measurements.
     const bool place_lm = d.P >= 1 && d.P <= kPlaceBlock && option_place_path() != 1;
+    if (!place_lm && option_strict() != 0) {  // (no silent fall-back to an order that follows free-running atomics)
+        set_error("strict: grad_value would take the plane-major place pass (P = %lld > %d points per level, or place_path = 1), "
+                  "whose record order — and so grad_value's last bit — is not reproducible", (long long)d.P, kPlaceBlock);
+        return MSDA_ERR_UNSUPPORTED;
+    }
     // ... with 256-thread workgroups when one round of them covers a slice's queries (decoder-sized calls: few samples
     // per (level, slice)): the waves' turns are a chain of 4 hand-overs instead of 16, and more workgroups are in flight
     const int64_t q_slice = (w.q_round + p.nsplit - 1) / p.nsplit;
@@ -501,7 +451,7 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
     int place_cells;
     {
         int64_t bound = w.nc_cap;
-        const int64_t hint = option_level_cells();
+        const int64_t hint = level_cells_bound(d);
         if (hint > 0 && hint < bound) bound = hint;
         place_cells = place_cell_cap(bound, (size_t)kMaxDynLds);
         if (place_cells > kPlaceCellsTwoPerCu) place_cells = kPlaceCellsTwoPerCu;
@@ -575,11 +525,10 @@ inline void fill_params(Params &p, const Dims &d, int padding_mode, int align_co
     p.div_h = make_fast_div((uint32_t)d.H);
 }
 
-// workspace (optional, msda_fwd_workspace_bytes): room for the x-pair table of a pyramid with 64-byte rows
 template <typename T, typename TV = T>
 int run_fwd(const void *value, const int64_t *shapes, const void *loc, const void *attn, void *out, int64_t B,
             int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int padding_mode, int align_corners,
-            void *stream_, void *workspace = nullptr, int64_t workspace_bytes = 0)
+            void *stream_)
 {
     const Dims d{B, I, H, D, Q, L, P};
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -607,13 +556,7 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
     p.out = out;
     fill_params(p, d, padding_mode, align_corners);
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
-    if (pairs_ok<T, TV>(p, d, vec_ok, workspace, workspace_bytes)) {
-        rc = build_pairs<TV>(value, workspace, d, stream);
-        p.pairs = workspace;
-        if (rc == 0) rc = dispatch_gather_pairs<T, 0, TV>(p, stream);
-    } else {
-        rc = dispatch_gather<T, 0, TV>(p, vec_ok, stream);
-    }
+    rc = dispatch_gather<T, 0, TV>(p, vec_ok, stream);
     if (rc > 0) set_error("forward launch failed: %s", hipGetErrorString((hipError_t)rc));  // negative: message already set
     return rc;
 }
@@ -623,7 +566,7 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
 template <typename T, typename TV = T>
 int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, const void *ref, void *out, int64_t B,
                   int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,
-                  int align_corners, void *stream_, void *workspace = nullptr, int64_t workspace_bytes = 0)
+                  int align_corners, void *stream_)
 {
     const Dims d{B, I, H, D, Q, L, P};
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -659,16 +602,7 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
     p.ref = ref;
     p.ref_dim = ref_dim;
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
-    size_t lds_unused;
-    int sc_all;
-    plan_gather(kBlock / pair_group<T, TV>(), (int)(L * P), sizeof(typename Traits<T>::acc), sc_all, lds_unused);
-    if (pairs_ok<T, TV>(p, d, vec_ok, workspace, workspace_bytes) && sc_all == (int)(L * P)) {
-        rc = build_pairs<TV>(value, workspace, d, stream);
-        p.pairs = workspace;
-        if (rc == 0) rc = dispatch_gather_pairs<T, 2, TV>(p, stream);
-    } else {
-        rc = dispatch_gather<T, 2, TV>(p, vec_ok, stream);
-    }
+    rc = dispatch_gather<T, 2, TV>(p, vec_ok, stream);
     if (rc > 0) set_error("fused forward launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }
@@ -678,7 +612,7 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
 // without a promise from the caller the bound is what I pixels can make of one level: 2 I + 2 L.
 inline int64_t small_cell_cap(const Dims &d)
 {
-    const int64_t bound = 2 * d.I + 2 * d.L, hint = option_level_cells();
+    const int64_t bound = 2 * d.I + 2 * d.L, hint = level_cells_bound(d);
     return hint > 0 && hint < bound ? hint : bound;
 }
 template <typename T> inline size_t small_need_bytes(const Dims &d, bool vec)
@@ -802,10 +736,10 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
 template <typename T, typename TV = T>
 int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, const void *loc, const void *attn,
             void *grad_value, void *grad_loc, void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,
-            int64_t L, int64_t P, int padding_mode, int align_corners, void *workspace, int64_t workspace_bytes,
-            void *stream_)
+            int64_t L, int64_t P, int padding_mode, int align_corners, int64_t max_level_cells, void *workspace,
+            int64_t workspace_bytes, void *stream_)
 {
-    const Dims d{B, I, H, D, Q, L, P};
+    const Dims d{B, I, H, D, Q, L, P, max_level_cells > 0 ? max_level_cells : 0};
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = check_common<T>(d, padding_mode, nullptr, 0);
     if (rc) return rc;
@@ -856,20 +790,7 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
         p.ent_alt1 = grad_attn;
         p.ent_alt2 = grad_value;
     }
-    // The workspace's front may carry the x-pair table for the sample-gradient kernel (64-byte value rows): only when
-    // what follows it still covers what grad_value needs.
     const bool vec_sample = aligned_to(value, 16) && aligned_to(grad_out, 16);
-    bool use_pairs = false;
-    if (want_sample && pairs_ok<T, TV>(p, d, vec_sample, workspace, workspace_bytes)) {
-        const int64_t pb = (int64_t)pair_table_bytes(B, I, H);
-        const bool value_fits = !want_value || value_ws_ok<T, TV>(p, d, static_cast<unsigned char *>(workspace) + pb, workspace_bytes - pb);
-        if (value_fits) {
-            use_pairs = true;
-            p.pairs = workspace;
-            workspace = static_cast<unsigned char *>(workspace) + pb;
-            workspace_bytes -= pb;
-        }
-    }
     // The two halves of the backward are independent: when both are wanted, grad_loc/grad_attn run on a
     // forked side stream next to the grad_value pipeline (fork/join with events: still graph-capturable).
     hipStream_t sample_stream = stream;
@@ -891,13 +812,7 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
         }
     }
     auto run_sample = [&]() -> int {
-        int r;
-        if (use_pairs) {
-            r = build_pairs<TV>(value, const_cast<void *>(p.pairs), d, sample_stream);
-            if (r == 0) r = dispatch_gather_pairs<T, 1, TV>(p, sample_stream);
-        } else {
-            r = dispatch_gather<T, 1, TV>(p, vec_sample, sample_stream);
-        }
+        const int r = dispatch_gather<T, 1, TV>(p, vec_sample, sample_stream);
         if (r > 0) set_error("backward (grad_loc/grad_attn) launch failed: %s", hipGetErrorString((hipError_t)r));
         return r;
     };
@@ -932,10 +847,10 @@ inline size_t fused_mat_bytes(int64_t B, int64_t H, int64_t Q, int64_t L, int64_
 template <typename T, typename TV = T>
 int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes, const void *proj, const void *ref,
                   void *grad_value, void *grad_proj, void *grad_ref_part, int64_t B, int64_t I, int64_t H, int64_t D,
-                  int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode, int align_corners, void *workspace,
-                  int64_t workspace_bytes, void *stream_)
+                  int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode, int align_corners,
+                  int64_t max_level_cells, void *workspace, int64_t workspace_bytes, void *stream_)
 {
-    const Dims d{B, I, H, D, Q, L, P};
+    const Dims d{B, I, H, D, Q, L, P, max_level_cells > 0 ? max_level_cells : 0};
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int rc = check_common<T>(d, padding_mode, nullptr, 0);
     if (rc) return rc;
@@ -971,31 +886,6 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
     }
     const bool want_value = grad_value != nullptr;
     const size_t mat = fused_mat_bytes(B, H, Q, L, P, sizeof(T));
-    // the x-pair table for the sample half sits in front when the rest of the workspace still serves grad_value
-    bool use_pairs = false;
-    const void *pairs_at = nullptr;
-    {
-        Params probe{};
-        probe.grad_out = grad_out;
-        probe.grad_value = grad_value;
-        fill_params(probe, d, padding_mode, align_corners);
-        size_t lds_unused;
-        int sc_all;
-        plan_gather(kBlock / pair_group<T, TV>(), (int)(L * P), sizeof(typename Traits<T>::acc), sc_all, lds_unused, true);
-        const bool vec_s = aligned_to(value, 16) && aligned_to(grad_out, 16);
-        if (pairs_ok<T, TV>(probe, d, vec_s, workspace, workspace_bytes) && sc_all == (int)(L * P)) {
-            const int64_t pb = (int64_t)pair_table_bytes(B, I, H);
-            unsigned char *rest = static_cast<unsigned char *>(workspace) + pb;
-            const bool ok = !want_value || ((uint64_t)(workspace_bytes - pb) >= mat &&
-                                            value_ws_ok<T>(probe, d, rest + mat, workspace_bytes - pb - (int64_t)mat));
-            if (ok) {
-                use_pairs = true;
-                pairs_at = workspace;
-                workspace = rest;
-                workspace_bytes -= pb;
-            }
-        }
-    }
     if (want_value && (workspace == nullptr || !aligned_to(workspace, 256) || (uint64_t)workspace_bytes < mat)) {
         set_error("the fused backward needs a 256-byte aligned workspace of at least %zu bytes for grad_value", mat);
         return MSDA_ERR_BAD_ARG;
@@ -1012,19 +902,13 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
     fill_params(p, d, padding_mode, align_corners);
     p.ref = ref;
     p.ref_dim = ref_dim;
-    p.pairs = pairs_at;
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     if (want_value) {
         p.mat_loc = ws;
         p.mat_attn = ws + ns * 2 * sizeof(T);
     }
     const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
-    if (use_pairs) {
-        rc = build_pairs<TV>(value, const_cast<void *>(p.pairs), d, stream);
-        if (rc == 0) rc = dispatch_gather_pairs<T, 3, TV>(p, stream);
-    } else {
-        rc = dispatch_gather<T, 3, TV>(p, vec_ok, stream);
-    }
+    rc = dispatch_gather<T, 3, TV>(p, vec_ok, stream);
     if (rc) {
         if (rc > 0) set_error("fused backward launch failed: %s", hipGetErrorString((hipError_t)rc));
         return rc;
@@ -1057,65 +941,27 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
         return msda::run_fwd_fused<T, TV>(value, shapes, proj, ref, out, B, I, H, D, Q, L, P, ref_dim, padding_mode, \
                                       align_corners, stream);                                                    \
     }                                                                                                            \
-    extern "C" int msda_fwd_ex_##SUF(const void *value, const int64_t *shapes, const void *loc, const void *attn, \
-                                     void *out, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, \
-                                     int64_t P, int padding_mode, int align_corners, void *workspace,            \
-                                     int64_t workspace_bytes, void *stream)                                      \
-    {                                                                                                            \
-        return msda::run_fwd<T, TV>(value, shapes, loc, attn, out, B, I, H, D, Q, L, P, padding_mode,               \
-                                align_corners, stream, workspace, workspace_bytes);                              \
-    }                                                                                                            \
-    extern "C" int msda_fwd_fused_ex_##SUF(const void *value, const int64_t *shapes, const void *proj,          \
-                                           const void *ref, void *out, int64_t B, int64_t I, int64_t H,          \
-                                           int64_t D, int64_t Q, int64_t L, int64_t P, int ref_dim,              \
-                                           int padding_mode, int align_corners, void *workspace,                 \
-                                           int64_t workspace_bytes, void *stream)                                \
-    {                                                                                                            \
-        return msda::run_fwd_fused<T, TV>(value, shapes, proj, ref, out, B, I, H, D, Q, L, P, ref_dim, padding_mode, \
-                                      align_corners, stream, workspace, workspace_bytes);                        \
-    }                                                                                                            \
     extern "C" int msda_bwd_##SUF(const void *grad_out, const void *value, const int64_t *shapes,               \
                                   const void *loc, const void *attn, void *grad_value, void *grad_loc,          \
                                   void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,       \
-                                  int64_t L, int64_t P, int padding_mode, int align_corners, void *workspace,   \
-                                  int64_t workspace_bytes, void *stream)                                         \
+                                  int64_t L, int64_t P, int padding_mode, int align_corners,                    \
+                                  int64_t max_level_cells, void *workspace, int64_t workspace_bytes,            \
+                                  void *stream)                                                                  \
     {                                                                                                            \
         return msda::run_bwd<T, TV>(grad_out, value, shapes, loc, attn, grad_value, grad_loc, grad_attn, B, I, H,   \
-                                D, Q, L, P, padding_mode, align_corners, workspace, workspace_bytes, stream);    \
-    }                                                                                                            \
-    extern "C" int msda_bwd_ex_##SUF(const void *grad_out, const void *value, const int64_t *shapes,            \
-                                     const void *loc, const void *attn, void *grad_value, void *grad_loc,       \
-                                     void *grad_attn, int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q,    \
-                                     int64_t L, int64_t P, int padding_mode, int align_corners,                 \
-                                     int64_t max_level_cells, void *workspace, int64_t workspace_bytes,         \
-                                     void *stream)                                                               \
-    {                                                                                                            \
-        const msda::LevelCellsArg scope(max_level_cells);                                                        \
-        return msda::run_bwd<T, TV>(grad_out, value, shapes, loc, attn, grad_value, grad_loc, grad_attn, B, I, H,   \
-                                D, Q, L, P, padding_mode, align_corners, workspace, workspace_bytes, stream);    \
-    }                                                                                                            \
-    extern "C" int msda_bwd_fused_ex_##SUF(const void *grad_out, const void *value, const int64_t *shapes,      \
-                                           const void *proj, const void *ref, void *grad_value,                 \
-                                           void *grad_proj, void *grad_ref_partial, int64_t B, int64_t I,       \
-                                           int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int ref_dim,  \
-                                           int padding_mode, int align_corners, int64_t max_level_cells,        \
-                                           void *workspace, int64_t workspace_bytes, void *stream)              \
-    {                                                                                                            \
-        const msda::LevelCellsArg scope(max_level_cells);                                                        \
-        return msda::run_bwd_fused<T, TV>(grad_out, value, shapes, proj, ref, grad_value, grad_proj,                \
-                                      grad_ref_partial, B, I, H, D, Q, L, P, ref_dim, padding_mode,              \
-                                      align_corners, workspace, workspace_bytes, stream);                        \
+                                D, Q, L, P, padding_mode, align_corners, max_level_cells, workspace,             \
+                                workspace_bytes, stream);                                                        \
     }                                                                                                            \
     extern "C" int msda_bwd_fused_##SUF(const void *grad_out, const void *value, const int64_t *shapes,         \
                                         const void *proj, const void *ref, void *grad_value, void *grad_proj,   \
                                         void *grad_ref_partial, int64_t B, int64_t I, int64_t H, int64_t D,      \
                                         int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,          \
-                                        int align_corners, void *workspace, int64_t workspace_bytes,             \
-                                        void *stream)                                                            \
+                                        int align_corners, int64_t max_level_cells, void *workspace,             \
+                                        int64_t workspace_bytes, void *stream)                                   \
     {                                                                                                            \
         return msda::run_bwd_fused<T, TV>(grad_out, value, shapes, proj, ref, grad_value, grad_proj,                \
                                       grad_ref_partial, B, I, H, D, Q, L, P, ref_dim, padding_mode,              \
-                                      align_corners, workspace, workspace_bytes, stream);                        \
+                                      align_corners, max_level_cells, workspace, workspace_bytes, stream);       \
     }
 
 // one storage type for every tensor

@@ -16,16 +16,15 @@
 
 namespace {
 
-// (the _ex forms: optional workspace — x-pair table of a pyramid with 64-byte rows)
 using FwdFn = int (*)(const void *, const int64_t *, const void *, const void *, void *, int64_t, int64_t, int64_t,
-                      int64_t, int64_t, int64_t, int64_t, int, int, void *, int64_t, void *);
-// (the _ex forms: the level-size bound travels as an argument, include/msda_hip.h ABI 9)
+                      int64_t, int64_t, int64_t, int64_t, int, int, void *);
+// (the level-size bound travels as an argument: include/msda_hip.h, max_level_cells)
 using BwdFn = int (*)(const void *, const void *, const int64_t *, const void *, const void *, void *, void *, void *,
                       int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int64_t, void *, int64_t,
                       void *);
 
 using FwdFusedFn = int (*)(const void *, const int64_t *, const void *, const void *, void *, int64_t, int64_t, int64_t,
-                           int64_t, int64_t, int64_t, int64_t, int, int, int, void *, int64_t, void *);
+                           int64_t, int64_t, int64_t, int64_t, int, int, int, void *);
 using BwdFusedFn = int (*)(const void *, const void *, const int64_t *, const void *, const void *, void *, void *, void *,
                            int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, int64_t, void *,
                            int64_t, void *);
@@ -45,14 +44,14 @@ Fns fns_for(at::ScalarType t, at::ScalarType c)
         TORCH_CHECK_VALUE(c == at::kFloat && (t == at::kBFloat16 || t == at::kHalf),
                           "unsupported dtype combination: value ", t, " with ", c);
         if (t == at::kBFloat16)
-            return {msda_fwd_ex_f32_vbf16, msda_bwd_ex_f32_vbf16, msda_fwd_fused_ex_f32_vbf16, msda_bwd_fused_ex_f32_vbf16};
-        return {msda_fwd_ex_f32_vf16, msda_bwd_ex_f32_vf16, msda_fwd_fused_ex_f32_vf16, msda_bwd_fused_ex_f32_vf16};
+            return {msda_fwd_f32_vbf16, msda_bwd_f32_vbf16, msda_fwd_fused_f32_vbf16, msda_bwd_fused_f32_vbf16};
+        return {msda_fwd_f32_vf16, msda_bwd_f32_vf16, msda_fwd_fused_f32_vf16, msda_bwd_fused_f32_vf16};
     }
     switch (t) {
-    case at::kFloat: return {msda_fwd_ex_f32, msda_bwd_ex_f32, msda_fwd_fused_ex_f32, msda_bwd_fused_ex_f32};
-    case at::kHalf: return {msda_fwd_ex_f16, msda_bwd_ex_f16, msda_fwd_fused_ex_f16, msda_bwd_fused_ex_f16};
-    case at::kBFloat16: return {msda_fwd_ex_bf16, msda_bwd_ex_bf16, msda_fwd_fused_ex_bf16, msda_bwd_fused_ex_bf16};
-    case at::kDouble: return {msda_fwd_ex_f64, msda_bwd_ex_f64, msda_fwd_fused_ex_f64, msda_bwd_fused_ex_f64};
+    case at::kFloat: return {msda_fwd_f32, msda_bwd_f32, msda_fwd_fused_f32, msda_bwd_fused_f32};
+    case at::kHalf: return {msda_fwd_f16, msda_bwd_f16, msda_fwd_fused_f16, msda_bwd_fused_f16};
+    case at::kBFloat16: return {msda_fwd_bf16, msda_bwd_bf16, msda_fwd_fused_bf16, msda_bwd_fused_bf16};
+    case at::kDouble: return {msda_fwd_f64, msda_bwd_f64, msda_fwd_fused_f64, msda_bwd_fused_f64};
     default: TORCH_CHECK_VALUE(false, "unsupported dtype ", t);
     }
 }
@@ -82,13 +81,6 @@ torch::autograd::variable_list once_differentiable(const torch::autograd::variab
     return (*err)(std::move(outs));
 }
 
-// optional forward scratch: room for the x-pair table of a pyramid with 64-byte rows (msda_fwd_workspace_bytes; 0 otherwise)
-at::Tensor fwd_workspace(const at::Tensor &img)
-{
-    const int64_t n = msda_fwd_workspace_bytes(img.size(0), img.size(1), img.size(2), img.size(3), (int)img.element_size());
-    return n > 0 ? at::empty({n}, img.options().dtype(at::kByte)) : at::Tensor();
-}
-
 void *current_stream(const at::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
 class MSDAFunction : public torch::autograd::Function<MSDAFunction> {
@@ -103,11 +95,9 @@ public:
         const int64_t Q = pts.size(1), L = pts.size(3), P = pts.size(4);
         at::Tensor out = at::empty({B, Q, H, D}, pts.options());
         const c10::DeviceGuard guard(img.device());
-        const at::Tensor fws = fwd_workspace(img);
         check_rc(fns_for(img.scalar_type(), pts.scalar_type())
                      .fwd(img.data_ptr(), shapes.data_ptr<int64_t>(), pts.data_ptr(), att.data_ptr(), out.data_ptr(), B, I,
-                          H, D, Q, L, P, (int)padding_mode, align_corners ? 1 : 0, fws.defined() ? fws.data_ptr() : nullptr,
-                          fws.defined() ? fws.numel() : 0, current_stream(img)),
+                          H, D, Q, L, P, (int)padding_mode, align_corners ? 1 : 0, current_stream(img)),
                  "msda_fwd");
         ctx->save_for_backward({img, shapes, pts, att});
         ctx->saved_data["padding_mode"] = padding_mode;
@@ -143,12 +133,9 @@ public:
             const bool in_grads = want_sample && reinterpret_cast<uintptr_t>(g_pts.data_ptr()) % 16 == 0 &&
                                   reinterpret_cast<uintptr_t>(g_att.data_ptr()) % 16 == 0 &&
                                   reinterpret_cast<uintptr_t>(g_img.data_ptr()) % 16 == 0 && msda_get_option("overlap") != 1;
-            ws_bytes = msda_bwd_workspace_bytes_ex(B, I, H, D, Q, L, P, (int)pts.element_size(), (int)img.element_size(),
-                                                   level_cells, in_grads ? MSDA_WS_RECORDS_IN_GRADS : 0);
+            ws_bytes = msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, (int)pts.element_size(), (int)img.element_size(),
+                                                level_cells, in_grads ? MSDA_WS_RECORDS_IN_GRADS : 0);
             ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));  // scratch: no initialisation needed
-        } else {  // only the x-pair table for the sample half, if the shape takes one
-            ws = fwd_workspace(img);
-            ws_bytes = ws.defined() ? ws.numel() : 0;
         }
         if (want_value || want_sample) {
             const c10::DeviceGuard guard(img.device());
@@ -180,11 +167,9 @@ public:
         const int64_t Q = proj.size(1), L = proj.size(3), P = proj.size(4);
         at::Tensor out = at::empty({B, Q, H, D}, proj.options());
         const c10::DeviceGuard guard(img.device());
-        const at::Tensor fws = fwd_workspace(img);
         check_rc(fns_for(img.scalar_type(), proj.scalar_type())
                      .fwd_fused(img.data_ptr(), shapes.data_ptr<int64_t>(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(),
                                 B, I, H, D, Q, L, P, (int)ref.size(-1), (int)padding_mode, align_corners ? 1 : 0,
-                                fws.defined() ? fws.data_ptr() : nullptr, fws.defined() ? fws.numel() : 0,
                                 current_stream(img)),
                  "msda_fwd_fused");
         ctx->save_for_backward({img, shapes, proj, ref});
@@ -213,12 +198,9 @@ public:
         int64_t ws_bytes = 0;
         if (want_value) {
             g_img = at::empty_like(img);
-            ws_bytes = msda_bwd_fused_workspace_bytes_ex(B, I, H, D, Q, L, P, (int)proj.element_size(),
-                                                         (int)img.element_size(), level_cells);
+            ws_bytes = msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, (int)proj.element_size(),
+                                                      (int)img.element_size(), level_cells);
             ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));
-        } else {
-            ws = fwd_workspace(img);
-            ws_bytes = ws.defined() ? ws.numel() : 0;
         }
         {
             const c10::DeviceGuard guard(img.device());

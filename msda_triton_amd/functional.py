@@ -218,37 +218,22 @@ def msda_hip_fwd(img, img_shapes, sampling_points, attention_weights, padding_mo
         raise ValueError(f"`out` should be a contiguous {(B, Q, H, D)} {cdt} tensor on {img.device}, but got "
                          f"{tuple(out.shape)} {out.dtype} on {out.device} (contiguous: {out.is_contiguous()}).")
     lib = _lib.load()
-    fn = getattr(lib, f"msda_fwd_ex_{suf}")
-    ws, ws_bytes = _fwd_workspace(lib, img)
+    fn = getattr(lib, f"msda_fwd_{suf}")
 
     def call():
         return fn(img.data_ptr(), shapes.data_ptr(), sampling_points.data_ptr(), attention_weights.data_ptr(),
-                  out.data_ptr(), B, I, H, D, Q, L, P, pad, int(bool(align_corners)),
-                  ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(img.device))
+                  out.data_ptr(), B, I, H, D, Q, L, P, pad, int(bool(align_corners)), _stream_ptr(img.device))
 
     with _OnDevice(img.device):
         timer = KernelTimer.active
         rc = timer.launch("msda_fwd", img.device, call) if timer else call()
-    _lib.check(rc, f"msda_fwd_ex_{suf}")
+    _lib.check(rc, f"msda_fwd_{suf}")
     return out
-
-
-_FWD_WS_BYTES: dict = {}  # (B, I, H, D, value element size, option epoch) -> msda_fwd_workspace_bytes
-
-
-def _fwd_workspace(lib, img):
-    """Optional scratch for the forward: room for the x-pair table the library builds for a pyramid whose rows have
-    exactly 64 bytes (include/msda_hip.h, msda_fwd_ex_<dtype>); (None, 0) for every other shape."""
-    key = (*img.shape, img.element_size(), _lib.OPTION_EPOCH)
-    n = _FWD_WS_BYTES.get(key)
-    if n is None:
-        n = _FWD_WS_BYTES[key] = int(lib.msda_fwd_workspace_bytes(*key[:5]))
-    return (torch.empty(n, dtype=torch.uint8, device=img.device), n) if n > 0 else (None, 0)
 
 
 def level_cells_of(level_shapes, num_levels: Optional[int] = None, num_pixels: Optional[int] = None) -> int:
     """``level_shapes``: the pyramid's (height, width) pairs AS HOST NUMBERS (e.g. Hugging Face's
-    ``spatial_shapes_list``), or None.  Returns the bound ``msda_bwd_ex_<dtype>`` takes as ``max_level_cells`` — the bilinear cells of the
+    ``spatial_shapes_list``), or None.  Returns the bound ``msda_bwd_<dtype>`` takes as ``max_level_cells`` — the bilinear cells of the
     largest level, (h + 1) * (w + 1) — or 0 for "unknown".  With it the backward can use its single-launch grad_value
     kernel on decoder-sized calls over real-image pyramids (include/msda_hip.h); it must describe the same pyramid as
     the ``img_shapes`` tensor (a level larger than promised gets NaN gradients)."""
@@ -319,12 +304,10 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
     g_att = buf(2, (B, Q, H, L, P), want_sample, cdt)
     if want_value or want_sample:
         lib = _lib.load()
-        fn = getattr(lib, f"msda_bwd_ex_{suf}")  # (the level-size bound travels as an argument: include/msda_hip.h, ABI 9)
+        fn = getattr(lib, f"msda_bwd_{suf}")  # (the level-size bound travels as an argument: include/msda_hip.h)
         ws, ws_bytes = None, 0
         level_cells = int(level_cells)
-        if not want_value:  # only the x-pair table, if the shape takes one
-            ws, ws_bytes = _fwd_workspace(lib, img)
-        else:  # scratch: the inverted index (grad_value), in front of it the x-pair table
+        if want_value:  # scratch: the inverted index of grad_value (grad_loc / grad_attn never need any)
             # all three gradients in ONE call: the sorted records may use the gradient buffers themselves (smaller
             # workspace); the per-kernel timer issues the halves as two calls and needs the full size
             # (the library's own conditions: 16-byte aligned gradient buffers, no forced side-stream fork)
@@ -336,7 +319,7 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
                    flags)
             ws_bytes = _WS_BYTES.get(key)
             if ws_bytes is None:
-                ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes_ex(*key[:9], level_cells, flags))
+                ws_bytes = _WS_BYTES[key] = int(lib.msda_bwd_workspace_bytes(*key[:9], level_cells, flags))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
         def call(value_part: bool, sample_part: bool):
@@ -359,7 +342,7 @@ def msda_hip_bwd(out_grad, img, img_shapes, sampling_points, attention_weights, 
                     rc = timer.launch("msda_bwd_sample", img.device, lambda: call(False, True))
                 if rc == 0 and want_value:
                     rc = timer.launch("msda_bwd_value", img.device, lambda: call(True, False))
-        _lib.check(rc, f"msda_bwd_ex_{suf}")
+        _lib.check(rc, f"msda_bwd_{suf}")
     return g_img, (g_pts if needs[1] else None), (g_att if needs[2] else None)
 
 
@@ -492,20 +475,18 @@ def msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, al
     shapes = _shapes_i64(img_shapes)
     out = torch.empty((B, Q, H, D), dtype=cdt, device=img.device)
     lib = _lib.load()
-    fn = getattr(lib, f"msda_fwd_fused_ex_{suf}")
-    ws, ws_bytes = _fwd_workspace(lib, img)
+    fn = getattr(lib, f"msda_fwd_fused_{suf}")
 
     def call():
         return fn(img.data_ptr(), shapes.data_ptr(), proj.data_ptr(), reference_points.data_ptr(), out.data_ptr(),
-                  B, I, H, D, Q, L, P, ref_dim, pad, int(bool(align_corners)),
-                  ws.data_ptr() if ws is not None else None, ws_bytes, _stream_ptr(img.device))
+                  B, I, H, D, Q, L, P, ref_dim, pad, int(bool(align_corners)), _stream_ptr(img.device))
 
     with _OnDevice(img.device):
         timer = KernelTimer.active
         rc = timer.launch("msda_fwd_fused", img.device, call) if timer else call()
     if rc == -5:  # MSDA_ERR_UNSUPPORTED
         return None
-    _lib.check(rc, f"msda_fwd_fused_ex_{suf}")
+    _lib.check(rc, f"msda_fwd_fused_{suf}")
     return out
 
 
@@ -531,12 +512,12 @@ def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, paddin
     g_proj = torch.empty((B, Q, H, L, P, 3), **kw)
     g_ref_part = torch.empty((B, Q, H, ref_dim), **kw)
     lib = _lib.load()
-    fn = getattr(lib, f"msda_bwd_fused_ex_{suf}")
+    fn = getattr(lib, f"msda_bwd_fused_{suf}")
     ws, ws_bytes = None, 0
     level_cells = int(level_cells)  # the level-size bound (level_cells_of), an argument of the size query and the launch
-    if need_img or img.element_size() * D == 64:
-        ws_bytes = int(lib.msda_bwd_fused_workspace_bytes_ex(B, I, H, D, Q, L, P, proj.element_size(), img.element_size(),
-                                                             level_cells))
+    if need_img:  # (a frozen value pyramid needs no workspace at all — ADVICE r04)
+        ws_bytes = int(lib.msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, proj.element_size(), img.element_size(),
+                                                          level_cells))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
     def call():
@@ -550,7 +531,7 @@ def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, paddin
         rc = timer.launch("msda_bwd_fused", img.device, call) if timer else call()
     if rc == -5:  # MSDA_ERR_UNSUPPORTED
         return None
-    _lib.check(rc, f"msda_bwd_fused_ex_{suf}")
+    _lib.check(rc, f"msda_bwd_fused_{suf}")
     return g_img, g_proj, g_ref_part.sum(dim=2)
 
 

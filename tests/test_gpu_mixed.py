@@ -137,17 +137,8 @@ def test_mixed_storage_rejects_other_combinations():
     assert out.dtype == torch.float32
 
 
-@pytest.fixture(params=[0, 1], ids=["plain", "x_pair_table"])
-def pairs_option(request):
-    """both with and without msda_set_option("pairs", 1) (the fused kernels on the x-pair table of a 64-byte-row pyramid)"""
-    from msda_triton_amd import _lib
-    _lib.set_option("pairs", request.param)
-    yield request.param
-    _lib.set_option("pairs", 0)
-
-
 @pytest.mark.parametrize("ref_dim", [2, 4])
-def test_mixed_storage_fused_core_matches_composition(ref_dim, pairs_option):
+def test_mixed_storage_fused_core_matches_composition(ref_dim):
     """fused_module_core with a bf16 pyramid and fp32 projection == prologue in PyTorch + the mixed operator."""
     from msda_triton_amd.functional import fused_module_core, module_sampling_inputs, multiscale_deformable_attention
     torch.manual_seed(3)

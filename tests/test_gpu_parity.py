@@ -657,7 +657,7 @@ def test_grad_value_without_workspace(oracle):
     _, Q, _, L, P, _ = l.shape
     st = torch.cuda.current_stream().cuda_stream
     rc = lib.msda_bwd_f32(g.data_ptr(), v.data_ptr(), s.data_ptr(), l.data_ptr(), a.data_ptr(),
-                          gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, I, H, D, Q, L, P, 1, 0, None, 0, st)
+                          gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, I, H, D, Q, L, P, 1, 0, 0, None, 0, st)
     assert rc == 0
     torch.cuda.synchronize()
     r_gv, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
@@ -669,17 +669,17 @@ def test_grad_value_without_workspace(oracle):
     gv, gl, ga = torch.empty_like(v), torch.empty_like(l), torch.empty_like(a)
     B, I, H, D = v.shape
     _, Q, _, L, P, _ = l.shape
-    need = lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, 4)
+    need = lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, 4, 4, 0, 0)
     assert need > 0
     args = (g.data_ptr(), v.data_ptr(), s.data_ptr(), l.data_ptr(), a.data_ptr())
-    dims = (B, I, H, D, Q, L, P, 1, 0)
+    dims = (B, I, H, D, Q, L, P, 1, 0, 0)  # (..., padding_mode, align_corners, max_level_cells)
     assert lib.msda_bwd_f32(*args, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), *dims, None, 0, st) == -1
     assert str(need) in lib.msda_last_error().decode()
     small_ws = torch.empty(need // 8, dtype=torch.uint8, device=DEV)
     assert lib.msda_bwd_f32(*args, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), *dims, small_ws.data_ptr(), need // 8, st) == -1
     # with all three gradients in one call the sorted records may live in the grad_loc / grad_attn buffers: the size
-    # msda_bwd_workspace_bytes_ex reports for that (MSDA_WS_RECORDS_IN_GRADS) is smaller and suffices — for that call only
-    lean = lib.msda_bwd_workspace_bytes_ex(B, I, H, D, Q, L, P, 4, 4, 0, _lib.WS_RECORDS_IN_GRADS)
+    # msda_bwd_workspace_bytes reports for that (MSDA_WS_RECORDS_IN_GRADS) is smaller and suffices — for that call only
+    lean = lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, 4, 4, 0, _lib.WS_RECORDS_IN_GRADS)
     assert 0 < lean < need
     lean_ws = torch.empty(lean, dtype=torch.uint8, device=DEV)
     assert lib.msda_bwd_f32(*args, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), *dims, lean_ws.data_ptr(), lean, st) == 0
@@ -702,9 +702,9 @@ def test_grad_value_without_workspace(oracle):
     gvb = torch.empty(v.numel() + 4, device=DEV)
     gv, gl, ga = gvb[:v.numel()].view_as(v), torch.empty_like(l), torch.empty_like(a)
     args = (g.data_ptr(), v.data_ptr(), s.data_ptr(), l.data_ptr(), a.data_ptr())
-    dims = (B, I, H, D, Q, L, P, 1, 0)
-    full = lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, 4)
-    lean = lib.msda_bwd_workspace_bytes_ex(B, I, H, D, Q, L, P, 4, 4, 0, _lib.WS_RECORDS_IN_GRADS)
+    dims = (B, I, H, D, Q, L, P, 1, 0, 0)  # (..., padding_mode, align_corners, max_level_cells)
+    full = lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, 4, 4, 0, 0)
+    lean = lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, 4, 4, 0, _lib.WS_RECORDS_IN_GRADS)
     assert 0 < lean <= full - 2 * Q * L * P * 16  # both planes' records are gone from it
     lean_ws = torch.empty(lean, dtype=torch.uint8, device=DEV)
     assert lib.msda_bwd_f32(*args, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), *dims, lean_ws.data_ptr(), lean, st) == 0
@@ -740,7 +740,7 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     assert lib.msda_fwd_f32(p, p, p, p, p, 1, 1 << 28, 8, 64, 1, 1, 1, 0, 0, st) == -3    # plane offsets overflow
     assert lib.msda_fwd_f32(p + 2, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, st) == -4      # misaligned
     assert lib.msda_fwd_f32(None, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, st) == -1       # null buffer
-    assert lib.msda_bwd_workspace_bytes(4, 5440, 8, 32, 10000, 4, 4, 4) > 0
+    assert lib.msda_bwd_workspace_bytes(4, 5440, 8, 32, 10000, 4, 4, 4, 4, 0, 0) > 0
 
 
 def test_torch_compile_fullgraph_uses_registered_custom_op():
@@ -944,10 +944,10 @@ def test_single_launch_kernel_with_several_workgroups_per_level(oracle, small_ns
 
 def test_level_shapes_hint_opens_the_single_launch_kernel_on_image_sized_pyramids(oracle):
     """`level_shapes=` (the pyramid's sizes as host numbers, e.g. Hugging Face's spatial_shapes_list) promises the
-    library a bound on the largest level's bilinear cells (msda_hint_level_cells): a decoder-sized call over a pyramid
+    library a bound on the largest level's bilinear cells (the max_level_cells argument): a decoder-sized call over a pyramid
     whose 2 I + 2 L worst case does not fit the single-launch grad_value kernel's LDS then takes that kernel (no
-    workspace) instead of the sorted pipeline — same results, both routes (C++ binding and ctypes), and the promise is
-    withdrawn after the call."""
+    workspace) instead of the sorted pipeline — same results, both routes (C++ binding and ctypes); the bound is an
+    argument of the call and of the size query, nothing outlives it."""
     from msda_triton_amd import _lib
     from msda_triton_amd.functional import level_cells_of, msda_hip_bwd
     ops = _ops()
@@ -956,16 +956,12 @@ def test_level_shapes_hint_opens_the_single_launch_kernel_on_image_sized_pyramid
     rng = np.random.default_rng(77)
     c = rand_case(rng, B, Q, H, D, levels, P, lo=-0.05, hi=1.05)
     lib = _lib.load()
-    dims = (B, sum(h * w for h, w in levels), H, D, Q, len(levels), P, 4)
+    dims = (B, sum(h * w for h, w in levels), H, D, Q, len(levels), P, 4, 4)
     cells = level_cells_of(levels)
     assert cells == 101 * 135
-    assert lib.msda_bwd_workspace_bytes(*dims) > 0           # worst case from I: the sorted pipeline
-    lib.msda_hint_level_cells(cells)
-    try:
-        assert lib.msda_bwd_workspace_bytes(*dims) == 0      # with the promise: the single-launch kernel
-    finally:
-        lib.msda_hint_level_cells(0)
-    assert lib.msda_bwd_workspace_bytes(*dims) > 0
+    assert lib.msda_bwd_workspace_bytes(*dims, 0, 0) > 0        # worst case from I: the sorted pipeline
+    assert lib.msda_bwd_workspace_bytes(*dims, cells, 0) == 0   # with the bound: the single-launch kernel
+    assert lib.msda_bwd_workspace_bytes(*dims, 0, 0) > 0        # (an argument: nothing is remembered)
     r_gv, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
     t = {k: torch.from_numpy(v).to(DEV) for k, v in c.items()}
     # launcher API
@@ -973,7 +969,6 @@ def test_level_shapes_hint_opens_the_single_launch_kernel_on_image_sized_pyramid
                               level_cells=cells)
     np.testing.assert_allclose(gv.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
     np.testing.assert_allclose(ga.cpu().numpy(), r_ga, **BWD_TOL[torch.float32])
-    assert lib.msda_bwd_workspace_bytes(*dims) > 0           # withdrawn
     # public API (the C++ autograd node when the binding is built) and the Python Function over ctypes
     from msda_triton_amd.functional import _HipMultiscaleDeformableAttentionFunction as PyFn
     for route in ("public", "py"):
@@ -985,7 +980,6 @@ def test_level_shapes_hint_opens_the_single_launch_kernel_on_image_sized_pyramid
         out.backward(t["grad_out"])
         np.testing.assert_allclose(v.grad.cpu().numpy(), r_gv, err_msg=route, **BWD_TOL[torch.float32])
         np.testing.assert_allclose(a.grad.cpu().numpy(), r_ga, err_msg=route, **BWD_TOL[torch.float32])
-        assert lib.msda_bwd_workspace_bytes(*dims) > 0       # withdrawn again (this thread; the engine's thread set its own)
 
 
 def test_level_shapes_reach_the_backward_of_the_compiled_op(oracle):
@@ -1247,7 +1241,8 @@ def test_grad_value_is_bitwise_reproducible_everywhere(oracle):
     1 x 1 level takes a quarter of all samples), a c2-sized problem of the sorted pipeline, and a decoder call over an
     image-sized pyramid (more cells than samples: the shape the plane-major place pass used to take).  Across repeated
     calls, with other work interleaved on the device, and against a run under a different workgroup -> plane mapping;
-    the result still matches the oracle.  msda_set_option("deterministic", 1) is still accepted (and changes nothing)."""
+    the result still matches the oracle.  Under msda_set_option("strict", 1) these shapes run all the same (they ARE
+    reproducible); a shape that is not (P > 1024 points per level) is refused there — test_strict_refuses_…"""
     from msda_triton_amd import _lib, synth
     ops = _ops()
     rng = np.random.default_rng(515)
@@ -1259,11 +1254,11 @@ def test_grad_value_is_bitwise_reproducible_everywhere(oracle):
     cs = rand_case(rng, 2, 300, 2, 32, [(100, 134), (50, 67), (25, 34), (13, 17)], 4, lo=-0.05, hi=1.05)
     sparse = tuple(torch.from_numpy(cs[k]).to(DEV) for k in ("grad_out", "value", "shapes", "loc", "attn"))
     lib = _lib.load()
-    assert lib.msda_bwd_workspace_bytes(2, 17821, 2, 32, 300, 4, 4, 4) > 0  # (the sorted pipeline)
+    assert lib.msda_bwd_workspace_bytes(2, 17821, 2, 32, 300, 4, 4, 4, 4, 0, 0) > 0  # (the sorted pipeline)
     try:
         for det in (0, 1):
-            _lib.set_option("deterministic", det)
-            assert lib.msda_get_option(b"deterministic") == det
+            _lib.set_option("strict", det)
+            assert lib.msda_get_option(b"strict") == det
             for args, pm, ac in ((small, "zeros", False), (small, "border", True), (big, wl.padding_mode, wl.align_corners),
                                  (sparse, "zeros", False)):
                 runs = []
@@ -1283,8 +1278,37 @@ def test_grad_value_is_bitwise_reproducible_everywhere(oracle):
         r_gv, _, _ = oracle.backward(cs["grad_out"], cs["value"], cs["shapes"], cs["loc"], cs["attn"], "zeros", False)
         np.testing.assert_allclose(gv.cpu().numpy(), r_gv, **BWD_TOL[torch.float32])
     finally:
-        _lib.set_option("deterministic", 0)
+        _lib.set_option("strict", 0)
         _lib.set_option("xcd_map", 1)
+
+
+def test_strict_refuses_a_backward_that_would_not_be_reproducible():
+    """P > 1024 points per level takes the plane-major place pass, whose record order follows free-running atomics: with
+    msda_set_option("strict", 1) the call is refused (MSDA_ERR_UNSUPPORTED -> ValueError) instead of silently giving a
+    grad_value whose last bit may change from run to run; without it the call runs.  The same for a forced
+    place_path = 1."""
+    from msda_triton_amd import _lib
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    c = rand_case(rng, 1, 12, 2, 8, [(6, 5)], 1100)
+    many = tuple(torch.from_numpy(c[k]).to(DEV) for k in ("grad_out", "value", "shapes", "loc", "attn"))
+    c2 = rand_case(rng, 1, 3000, 2, 32, [(12, 10), (6, 5)], 4)
+    usual = tuple(torch.from_numpy(c2[k]).to(DEV) for k in ("grad_out", "value", "shapes", "loc", "attn"))
+    try:
+        _lib.set_option("value_path", 2)  # (the sorted pipeline for both)
+        ops.msda_hip_bwd(*many, "zeros", False)  # runs
+        _lib.set_option("strict", 1)
+        with pytest.raises(ValueError, match="strict"):
+            ops.msda_hip_bwd(*many, "zeros", False)
+        ops.msda_hip_bwd(*usual, "zeros", False)  # a reproducible shape is not affected
+        _lib.set_option("place_path", 1)
+        with pytest.raises(ValueError, match="strict"):
+            ops.msda_hip_bwd(*usual, "zeros", False)
+    finally:
+        _lib.set_option("place_path", 0)
+        _lib.set_option("strict", 0)
+        _lib.set_option("value_path", 0)
+    torch.cuda.synchronize()
 
 
 def test_make_graphed_callables_replays_forward_and_backward():
@@ -1393,54 +1417,3 @@ def test_seventeen_levels_beyond_the_single_launch_kernel(oracle):
         check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float32], BWD_TOL[torch.float32])
 
 
-@pytest.mark.parametrize("td,vd,D", [(torch.bfloat16, torch.bfloat16, 32), (torch.float16, torch.float16, 32),
-                                     (torch.float32, torch.bfloat16, 32), (torch.float32, torch.float32, 16),
-                                     (torch.float64, torch.float64, 8)],
-                         ids=["bf16", "fp16", "fp32_vbf16", "fp32_d16", "fp64_d8"])
-@pytest.mark.parametrize("pm,ac", [("zeros", False), ("border", True), ("border", False)], ids=["zeros_0", "border_1", "border_0"])
-def test_x_pair_table_kernels_match_the_oracle(oracle, td, vd, D, pm, ac):
-    """msda_set_option("pairs", 1): pyramids with 64-byte rows are gathered through the x-pair table (forward and
-    sample gradients, include/msda_hip.h).  Same oracle comparison as the plain kernels, points beyond the image so
-    that clamped / masked x1 corners (the entries that are NOT the x0 corner's neighbour) are exercised; the plain
-    kernels on the same inputs agree to rounding."""
-    from msda_triton_amd import _lib
-    levels = [(9, 7), (4, 5), (1, 3), (6, 1)]
-    c = rand_case(np.random.default_rng(41), 2, 45, 3, D, levels, 3, lo=-0.3, hi=1.3,
-                  dtype=np.float64 if td == torch.float64 else np.float32)
-    rounded = {k: (v if k == "shapes" else torch.from_numpy(v).to(vd if k == "value" else td).to(torch.from_numpy(v).dtype).numpy())
-               for k, v in c.items()}
-    ops = _ops()
-
-    def run():
-        v = torch.from_numpy(rounded["value"]).to(DEV, vd).requires_grad_(True)
-        l = torch.from_numpy(rounded["loc"]).to(DEV, td).requires_grad_(True)
-        a = torch.from_numpy(rounded["attn"]).to(DEV, td).requires_grad_(True)
-        out = ops.multiscale_deformable_attention(v, torch.from_numpy(rounded["shapes"]).to(DEV), l, a, pm, ac)
-        out.backward(torch.from_numpy(rounded["grad_out"]).to(DEV, td))
-        return [t.detach().double().cpu().numpy() for t in (out, v.grad, l.grad, a.grad)]
-
-    plain = run()
-    try:
-        _lib.set_option("pairs", 1)
-        assert _lib.load().msda_fwd_workspace_bytes(2, sum(h * w for h, w in levels), 3, D, torch.empty(0, dtype=vd).element_size()) > 0
-        paired = run()
-    finally:
-        _lib.set_option("pairs", 0)
-    r_out = oracle.forward(rounded["value"], rounded["shapes"], rounded["loc"], rounded["attn"], pm, ac)
-    r_gv, r_gl, r_ga = oracle.backward(rounded["grad_out"], rounded["value"], rounded["shapes"], rounded["loc"],
-                                       rounded["attn"], pm, ac)
-    atol, rtol = {torch.float64: (1e-9, 1e-9), torch.float32: (1e-4, 1e-3), torch.float16: (2e-2, 2e-2),
-                  torch.bfloat16: (4e-2, 2e-2)}[td]
-    np.testing.assert_allclose(paired[0], r_out, atol=atol, rtol=rtol, err_msg="out")
-    np.testing.assert_allclose(paired[3], r_ga, atol=atol * 4, rtol=rtol * 10, err_msg="grad_attn")
-    np.testing.assert_allclose(paired[1], r_gv, atol=atol * 4 if vd == td else 4e-2, rtol=rtol * 10, err_msg="grad_value")
-    keep = ~kink_mask(rounded["loc"], rounded["shapes"], ac, tol=2e-2 if td in (torch.float16, torch.bfloat16) else 1e-4)
-    scale = max(1.0, float(np.abs(r_gl).max()))
-    np.testing.assert_allclose(np.where(keep, paired[2], 0), np.where(keep, r_gl, 0), atol=atol * 10 * scale, rtol=rtol * 10,
-                               err_msg="grad_loc")
-    # and against the plain kernels: the same arithmetic in another order
-    eps = {torch.float64: 1e-12, torch.float32: 1e-5, torch.float16: 2e-2, torch.bfloat16: 6e-2}[td]
-    np.testing.assert_allclose(paired[0], plain[0], atol=eps * max(1.0, float(np.abs(plain[0]).max())), rtol=0)
-    np.testing.assert_allclose(paired[3], plain[3], atol=eps * max(1.0, float(np.abs(plain[3]).max())), rtol=0)
-    np.testing.assert_allclose(np.where(keep, paired[2], 0), np.where(keep, plain[2], 0),
-                               atol=eps * max(1.0, float(np.abs(plain[2]).max())), rtol=0)

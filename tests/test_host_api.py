@@ -186,7 +186,7 @@ def test_backward_workspace_sizes_stay_within_budget():
 
     def ws(name):
         wl = synth.WORKLOADS[name]
-        return int(lib.msda_bwd_workspace_bytes(wl.B, wl.I, wl.H, wl.D, wl.Q, wl.L, wl.P, wl.elem_size))
+        return int(lib.msda_bwd_workspace_bytes(wl.B, wl.I, wl.H, wl.D, wl.Q, wl.L, wl.P, wl.elem_size, wl.elem_size, 0, 0))
 
     assert ws("c2_q10k") <= 200 * 2**20          # entries 82 MB + partial rows 89 MB + cell tables
     # two rounds over the queries: records 1.02 GB + partial rows 0.72 GB + running sums; sized for the scalar
@@ -298,7 +298,7 @@ def test_host_path_and_gather_formulation_agree():
 
 
 def test_level_cells_of_host_shapes():
-    """The bound msda_hint_level_cells takes, from host numbers only (a device tensor would need a synchronisation)."""
+    """The bound msda_bwd_<dtype> takes as max_level_cells, from host numbers only (a device tensor would need a synchronisation)."""
     from msda_triton_amd.functional import level_cells_of
     assert level_cells_of(None) == 0
     assert level_cells_of([]) == 0
@@ -337,19 +337,17 @@ def test_workspace_size_queries_are_consistent():
     lib = _lib.load()
     flag = _lib.WS_RECORDS_IN_GRADS
     c2 = (4, 5440, 8, 32, 10000, 4, 4)
-    full, lean = lib.msda_bwd_workspace_bytes_ex(*c2, 4, 4, 0, 0), lib.msda_bwd_workspace_bytes_ex(*c2, 4, 4, 0, flag)
-    assert full == lib.msda_bwd_workspace_bytes(*c2, 4)
+    full, lean = lib.msda_bwd_workspace_bytes(*c2, 4, 4, 0, 0), lib.msda_bwd_workspace_bytes(*c2, 4, 4, 0, flag)
     records = 4 * 8 * 10000 * 16 * 16  # planes x samples per plane x 16 bytes
     assert 0 < lean <= full - records and lean < 110e6
     for dims, es, ves in (((4, 5440, 8, 32, 5000, 4, 4), 4, 4), ((2, 17821, 8, 32, 17821, 4, 4), 2, 2),
                           ((2, 17821, 8, 32, 17821, 4, 4), 4, 2), ((4, 21824, 8, 64, 100000, 5, 8), 2, 2)):
-        f, le = lib.msda_bwd_workspace_bytes_ex(*dims, es, ves, 0, 0), lib.msda_bwd_workspace_bytes_ex(*dims, es, ves, 0, flag)
+        f, le = lib.msda_bwd_workspace_bytes(*dims, es, ves, 0, 0), lib.msda_bwd_workspace_bytes(*dims, es, ves, 0, flag)
         assert 0 < le < f, dims
     c5 = (4, 21824, 8, 64, 100000, 5, 8)  # two rounds: grad_loc / grad_attn hold records, grad_value does not
     per_round = 4 * 8 * 50000 * 40 * 16
-    assert lib.msda_bwd_workspace_bytes_ex(*c5, 2, 2, 0, 0) - lib.msda_bwd_workspace_bytes_ex(*c5, 2, 2, 0, flag) < per_round
-    assert lib.msda_bwd_workspace_bytes_ex(2, 5440, 8, 32, 900, 4, 4, 4, 4, 0, flag) == 0          # c1: single launch
+    assert lib.msda_bwd_workspace_bytes(*c5, 2, 2, 0, 0) - lib.msda_bwd_workspace_bytes(*c5, 2, 2, 0, flag) < per_round
+    assert lib.msda_bwd_workspace_bytes(2, 5440, 8, 32, 900, 4, 4, 4, 4, 0, flag) == 0          # c1: single launch
     dec = (8, 17821, 8, 32, 900, 4, 4)
-    assert lib.msda_bwd_workspace_bytes_ex(*dec, 4, 4, 0, 0) > 0
-    assert lib.msda_bwd_workspace_bytes_ex(*dec, 4, 4, 101 * 135, 0) == 0                           # with the bound
-    assert lib.msda_fwd_workspace_bytes(2, 17821, 8, 32, 2) == 0                                     # pairs are off
+    assert lib.msda_bwd_workspace_bytes(*dec, 4, 4, 0, 0) > 0
+    assert lib.msda_bwd_workspace_bytes(*dec, 4, 4, 101 * 135, 0) == 0                           # with the bound

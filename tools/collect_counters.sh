@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (gpurun): pipeline-utilisation counters of `python bench.py`, one rocprofv3 --pmc pass per
 # counter group (no tracing options alongside), into gpurun_out/<tag>_pmc_<n>/.
 # Summarise afterwards with tools/summarise_counters.py.   WL=<workload> and EXTRA="--opt k=v ..." select another
-# workload / library options (e.g. WL=c3_ddetr_enc EXTRA="--opt pairs=1" bash tools/collect_counters.sh r04c3pairs).
+# workload / library options (e.g. WL=c3_ddetr_enc EXTRA="--opt lds_levels=0" bash tools/collect_counters.sh r05c3plain).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-r01}
 W=${WL:-c2_q10k}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev tool: per-kernel times (all msda kernels, forward included) of a workload under option strings ("k=v,k=v" or "-"):
-#   WORKLOAD=c3_ddetr_enc bash tools/prof_all.sh pairs=0 -
+#   WORKLOAD=c3_ddetr_enc bash tools/prof_all.sh lds_levels=0 -
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 W=${WORKLOAD:-c2_q10k}
 STEPS=${STEPS:-6}

@@ -24,7 +24,7 @@ def short(name):
 
 
 GROUPS = {  # launcher-level groups timed by bench.py's KernelTimer
-    "msda_fwd": ["msda_fwd_kernel"],
+    "msda_fwd": ["msda_fwd_kernel", "msda_fwd_unit_kernel"],
     "msda_bwd_sample": ["msda_bwd_sample_kernel"],
     "msda_bwd_value": ["msda_cell_pass_kernel", "msda_cell_scan_kernel", "msda_cell_place_lm_kernel", "msda_value_gather_kernel",
                        "msda_value_finish_kernel", "msda_value_small_kernel", "msda_cell_place_det_kernel"],
