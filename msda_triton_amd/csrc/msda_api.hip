@@ -134,29 +134,42 @@ int device_cu_count()
 struct ProfileRec {
     const char *name;
     hipEvent_t a, b;
+    bool ended;  // profile_end has recorded `b` (only then may msda_profile_read consume the record)
 };
-static std::vector<ProfileRec> t_profile;  // (process-wide: autograd launches the backward from its own thread)
+// (process-wide: autograd launches the backward from its own thread.  Records are heap objects and the token handed to
+// the launch is the record itself, so a read that runs between a launch's begin and end can neither redirect nor drop it;
+// every access to the list is under the mutex — ADVICE r04)
+static std::vector<ProfileRec *> t_profile;
 static std::mutex t_profile_mutex;
 
 void *profile_begin(const char *name, hipStream_t stream)
 {
-    if (!option_profile() || t_profile.size() >= 65536) return nullptr;
-    ProfileRec r{name, nullptr, nullptr};
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess || hipEventRecord(r.a, stream) != hipSuccess) {
+    if (!option_profile()) return nullptr;
+    const std::lock_guard<std::mutex> lock(t_profile_mutex);
+    if (t_profile.size() >= 65536) return nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
-    const std::lock_guard<std::mutex> lock(t_profile_mutex);
+    if (hipEventCreate(&b) != hipSuccess || hipEventRecord(a, stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipEventDestroy(a);
+        if (b != nullptr) (void)hipEventDestroy(b);
+        return nullptr;
+    }
+    ProfileRec *r = new ProfileRec{name, a, b, false};
     t_profile.push_back(r);
-    return reinterpret_cast<void *>(t_profile.size());  // 1-based index
+    return r;
 }
 
 void profile_end(void *token, hipStream_t stream)
 {
     if (token == nullptr) return;
-    const size_t i = reinterpret_cast<size_t>(token) - 1;
+    ProfileRec *r = static_cast<ProfileRec *>(token);
     const std::lock_guard<std::mutex> lock(t_profile_mutex);
-    if (i < t_profile.size()) (void)hipEventRecord(t_profile[i].b, stream);
+    (void)hipEventRecord(r->b, stream);
+    r->ended = true;
 }
 
 void set_error(const char *fmt, ...)
@@ -214,18 +227,24 @@ extern "C" int msda_profile_read(char *buf, int cap)
 {
     std::map<std::string, std::pair<int, double>> acc;
     const std::lock_guard<std::mutex> lock(msda::t_profile_mutex);
-    for (const msda::ProfileRec &r : msda::t_profile) {
+    std::vector<msda::ProfileRec *> open;  // begun, not ended yet: they stay for the next read
+    for (msda::ProfileRec *r : msda::t_profile) {
+        if (!r->ended) {
+            open.push_back(r);
+            continue;
+        }
         float ms = 0.f;
-        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-            auto &e = acc[r.name];
+        if (hipEventSynchronize(r->b) == hipSuccess && hipEventElapsedTime(&ms, r->a, r->b) == hipSuccess) {
+            auto &e = acc[r->name];
             e.first += 1;
             e.second += (double)ms * 1e3;
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        (void)hipEventDestroy(r->a);
+        (void)hipEventDestroy(r->b);
+        delete r;
     }
     (void)hipGetLastError();
-    msda::t_profile.clear();
+    msda::t_profile.swap(open);
     std::string out;
     for (const auto &kv : acc) {
         char line[160];
