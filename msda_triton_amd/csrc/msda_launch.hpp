@@ -197,8 +197,9 @@ template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(c
     pl.lds = lev_base + (size_t)pl.lev_bytes + (row + 15) / 16 * 16;
     const long long wgs = (long long)npairs * pl.slots, rounds = (wgs + ncu - 1) / ncu;
     const int opt = option_lds_levels();
-    // worth it when a workgroup amortises its copy over >= 4 chunks and the workgroups fill the CUs evenly
-    const bool pays = pl.qw >= 4 && wgs * 10 >= rounds * ncu * 8 && pl.lev_bytes >= (int)(64 * row);
+    // worth it when the workgroups fill the CUs (one 1024-thread workgroup each) evenly: c2 @ 10k 99 -> 75 us, @ 1k
+    // (one chunk per workgroup) still 15.3 -> 14.4, c4 28.5 -> 26.9; the README shape (128 workgroups: half the chip) 10.7 -> 13
+    const bool pays = wgs * 10 >= rounds * ncu * 8 && pl.lev_bytes >= (int)(64 * row);
     pl.use = opt == 2 ? pl.lev_bytes >= (int)row : opt == 1 && pays;
     return pl;
 }
