@@ -1,0 +1,96 @@
+"""The module's projections (``nn.Linear`` parameters, frontend.py:214-222) on a GPU when the row count is large.
+
+Forward and grad_input are the library GEMMs ``nn.Linear`` runs.  The WEIGHT gradient ``dW[out, in] = dY[N, out]^T
+X[N, in]`` is the problem case: N is 20 000 - 160 000 rows (every pixel of the pyramid / every query of the batch)
+while out and in are a few hundred, and the BLAS library serves it with one 64 x 64 tile per workgroup and no split
+over N — 16 to 24 workgroups on a 256-CU device (c2 module shape, bf16: 122 us per layer, a third of the module's
+whole training step; ``tools/linear_wgrad_bench.py``).  Here it is a batched product over row blocks, summed in fp32
+(58 us), and the bias gradient a two-stage column sum (16 us against 28).  Same arithmetic up to summation order.
+"""
+from __future__ import annotations
+
+import torch
+from torch.nn import functional as F
+
+ROW_SPLIT_MIN_ROWS = 8192   # below this the plain layer is used (decoder-sized calls: the library GEMM is fine)
+_BLOCK_MAX, _BLOCK_MIN = 2048, 512
+
+
+def _acc_dtype(dt: torch.dtype) -> torch.dtype:
+    return torch.float64 if dt == torch.float64 else torch.float32
+
+
+def _row_block(n: int) -> int:
+    """Largest block length in [_BLOCK_MIN, _BLOCK_MAX] (a multiple of 8) that divides n, or 0."""
+    for c in range(_BLOCK_MAX, _BLOCK_MIN - 1, -8):
+        if n % c == 0:
+            return c
+    return 0
+
+
+def row_split_weight_grad(gy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """``gy^T @ x`` for ``gy [N, out]``, ``x [N, in]`` as a batched product over row blocks; the blocks are summed in
+    fp32 (fp64 operands: fp64)."""
+    n = x.shape[0]
+    acc = _acc_dtype(x.dtype)
+    c = _row_block(n) or _BLOCK_MAX
+    s = n // c
+    main = s * c
+    if s == 0:
+        return (gy.t() @ x).to(acc)
+    parts = torch.bmm(gy[:main].view(s, c, -1).transpose(1, 2), x[:main].view(s, c, -1))
+    w = parts.sum(0, dtype=acc)
+    if main < n:
+        w = w + (gy[main:].t() @ x[main:]).to(acc)
+    return w
+
+
+def column_sum(gy: torch.Tensor) -> torch.Tensor:
+    """``gy.sum(0)`` in two stages (the one-stage column reduction keeps few workgroups busy); summed in fp32 (fp64
+    operands: fp64)."""
+    n, o = gy.shape
+    acc = _acc_dtype(gy.dtype)
+    for c in (64, 40, 32, 16, 8):
+        if n % c == 0:
+            return gy.view(n // c, c, o).sum(1, dtype=acc).sum(0)
+    return gy.sum(0, dtype=acc)
+
+
+class _RowSplitLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        # autocast: what F.linear would do to its arguments, done once so that the 16-bit copies can be saved
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            xc, wc, bc = x.to(dt), weight.to(dt), None if bias is None else bias.to(dt)
+        else:
+            xc, wc, bc = x, weight, bias
+        ctx.save_for_backward(xc, wc)
+        ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        with torch.autocast("cuda", enabled=False):
+            return F.linear(xc, wc, bc)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xc, wc = ctx.saved_tensors
+        xdt, wdt, bdt = ctx.dtypes
+        gx = gw = gb = None
+        with torch.autocast("cuda", enabled=False):
+            gy2 = gy.reshape(-1, gy.shape[-1]).to(xc.dtype)
+            if ctx.needs_input_grad[0]:
+                gx = (gy2 @ wc).view(xc.shape).to(xdt)
+            if ctx.needs_input_grad[1]:
+                gw = row_split_weight_grad(gy2, xc.reshape(-1, xc.shape[-1])).to(wdt)
+            if bdt is not None and ctx.needs_input_grad[2]:
+                gb = column_sum(gy2).to(bdt)
+        return gx, gw, gb
+
+
+def projection(layer: torch.nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """``layer(x)``; on a GPU with many rows through the row-split weight gradient above."""
+    if x.device.type == "cuda" and x.dim() >= 2 and x.numel() // x.shape[-1] >= ROW_SPLIT_MIN_ROWS and \
+            torch.is_grad_enabled() and x.is_floating_point() and not torch.compiler.is_compiling() and \
+            (layer.weight.requires_grad or x.requires_grad) and \
+            (torch.is_autocast_enabled("cuda") or x.dtype == layer.weight.dtype):
+        return _RowSplitLinear.apply(x, layer.weight, layer.bias)
+    return layer(x)

@@ -568,13 +568,15 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
 // LDS slice; phase 2: lane (r, j) blends the pairs r, r + R, ...; the R partial rows meet through lane shuffles.
 // ==========================================================================================
 template <typename T, int VEC, typename TV = T>
-__global__ __launch_bounds__(kBlock) void msda_fwd_unit_kernel(const Params p)
+__global__ __launch_bounds__(kWave) void msda_fwd_unit_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     static_assert(sizeof(A) == 4, "float accumulation (the shuffles below move 32-bit values)");
     request_all_arguments(p);
-    constexpr int WPB = kBlock / kWave;  // units per workgroup
+    // one unit per 64-thread workgroup: a few hundred one-wave workgroups land on different CUs, each with the CU's
+    // texture path to itself (four-wave workgroups: +0.5 ... 0.8 us at Q = 10 ... 300, cold)
+    constexpr int WPB = 1;
     const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
     const int GL = p.D / VEC;            // lanes across a row (the host checks: a power of two, <= 64, D % VEC == 0)
     const int R = kWave / GL;            // rows per load instruction

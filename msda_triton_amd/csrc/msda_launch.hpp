@@ -242,14 +242,15 @@ template <typename T, int VEC, int G, int MODE, typename TV = T> inline int laun
     if constexpr (MODE == 0 && VEC * sizeof(T) == 16 && sizeof(A) == 4) {
         const long long units = (long long)p.B * p.Q * p.H;
         const int gl = p.D / VEC;
-        if (option_unit_fwd() != 0 && (p.D % VEC) == 0 && gl >= 1 && gl <= kWave && (gl & (gl - 1)) == 0 && p.LP <= 1024 &&
-            units <= (option_unit_fwd() == 2 ? (1ll << 30) : kUnitFwdMaxUnits) && (units + 3) / 4 < (1ll << 31)) {
-            const size_t ulds = kGatherLdsFixed + (size_t)(kBlock / kWave) * 8 * p.LP * 4;
+        const int uopt = option_unit_fwd();
+        if (uopt != 0 && (p.D % VEC) == 0 && gl >= 1 && gl <= kWave && (gl & (gl - 1)) == 0 && p.LP <= 1024 &&
+            units <= (uopt == 2 ? (1ll << 30) : kUnitFwdMaxUnits) && units < (1ll << 31)) {
             const ProfileScope prof("msda_fwd_unit_kernel", stream);
+            const size_t ulds = kGatherLdsFixed + (size_t)8 * p.LP * 4;
             auto kernel = msda_fwd_unit_kernel<T, VEC, TV>;
             static std::atomic<uint64_t> big_lds_unit{0};
             allow_big_lds(kernel, big_lds_unit);
-            hipLaunchKernelGGL(kernel, dim3((unsigned)((units + 3) / 4)), dim3(kBlock), ulds, stream, p);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(kWave), ulds, stream, p);
             return (int)hipGetLastError();
         }
     }

@@ -2,8 +2,8 @@
 (/root/reference/src/msda_triton/frontend.py:175-292) over the HIP operator.
 
 Parameter names (``img_input_proj``, ``query_input_proj``, ``query_output_proj``) and shapes are
-the reference's, so state dicts interchange.  The projections are plain ``nn.Linear`` GEMMs
-(hipBLASLt through PyTorch); only the deformable-attention core is custom.
+the reference's, so state dicts interchange.  The projections are ``nn.Linear`` layers (library
+GEMMs; ``_linear.py`` only re-shapes their weight gradient for tall inputs); the deformable-attention core is custom.
 """
 from __future__ import annotations
 
@@ -12,6 +12,7 @@ from typing import Literal, Optional
 import torch
 from torch import nn
 
+from ._linear import projection
 from .functional import fused_module_core, module_sampling_inputs
 
 
@@ -88,8 +89,8 @@ class MultiscaleDeformableAttention(nn.Module):
                 f"`reference_points` should have the last dim either 2 or 4, but got {reference_points.shape[-1]}.")
         # one projection holds (x offset, y offset, attention logit) per (head, level, point); on the GPU the softmax
         # and the offset -> sampling-point math run inside the attention kernel's prologue
-        proj = self.query_input_proj(queries).reshape(B, N, H, L, P, 3)
-        value = self.img_input_proj(img).reshape(B, I, H, self.hidden_dim // H)
+        proj = projection(self.query_input_proj, queries).reshape(B, N, H, L, P, 3)
+        value = projection(self.img_input_proj, img).reshape(B, I, H, self.hidden_dim // H)
         if self.value_dtype is not None and value.device.type == "cuda":
             # 16-bit value pyramid next to fp32 sampling inputs: the mixed-storage kernels read it as it is (no fp32
             # copy, which is what autocast's cast_inputs would make), so the call sits outside autocast
@@ -100,4 +101,4 @@ class MultiscaleDeformableAttention(nn.Module):
         else:
             attended = fused_module_core(value, img_shapes, proj, reference_points, self.padding_mode,
                                          self.align_corners, level_shapes)
-        return self.query_output_proj(attended.reshape(B, N, self.hidden_dim))
+        return projection(self.query_output_proj, attended.reshape(B, N, self.hidden_dim))

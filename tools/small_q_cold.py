@@ -18,7 +18,7 @@ args = sys.argv[1:]
 want_triton = "--triton" in args
 if "--warm" in args:  # back-to-back instead of the flushed cache
     torch.Tensor.zero_ = lambda self: self
-args = [a for a in args if a not in ("--triton", "--warm")]
+args = [a for a in args if a not in ("--triton", "--warm", "--floor")]
 split = args.index("--") if "--" in args else len(args)
 qs = [int(a) for a in args[:split]] or [10, 100, 300, 900, 1000]
 opts = args[split + 1:] or ["-"]
@@ -58,4 +58,7 @@ for N in qs:
             with torch.no_grad():
                 tc.triton_comparator_msda(img, shapes, pts, att, "border", True)
         line["triton"] = [sweep.do_bench(tfwd, warmup_ms=30.0, rep_ms=300.0)[0] * 1e3 for _ in range(2)]
+    if "--floor" in sys.argv:  # a kernel that does nothing, by the same recipe: what of the figures is the launch itself
+        tiny = torch.zeros(64, device=img.device)
+        line["floor(fill 64 floats)"] = [sweep.do_bench(lambda: tiny.fill_(1.0), warmup_ms=30.0, rep_ms=300.0)[0] * 1e3 for _ in range(2)]
     print("Q=%5d " % N + "  ".join("%s: %s us" % (k, "/".join("%.2f" % x for x in v)) for k, v in line.items()), flush=True)
