@@ -178,6 +178,18 @@ struct CoarseStage {
     uint32_t base, zero;        // LDS byte offsets of the first row and of the row of zeros
     uint32_t row_bytes;         // D * sizeof(TV): distance of two rows in LDS
 };
+// Next-slice prefetch WITHOUT registers (LDSL kernels): the sampling inputs of a wave's next slice travel from memory
+// straight into a per-wave LDS staging area (global_load_lds_*: LDS address = M0 + lane * size, inactive lanes write
+// nothing).  Issued from inline assembly: the compiler does not see these loads, so no ds_read waits for them; the
+// consumer's wait is the explicit dma_wait() the kernels place behind phase 2 — by then the slice's own gathers have
+// returned (vector-memory loads return in order, so the older staging loads have too) and the wait costs nothing.
+constexpr int kStagePre = 2;                                  // samples per lane and slice
+constexpr uint32_t kStageWaveBytes = kStagePre * kWave * 12;  // per wave: [trip][x | y | a][lane] floats
+__device__ __forceinline__ void dma_dword(const void *g, uint32_t lds_uniform)
+{
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(lds_uniform) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <typename TV, int VEC, int BLK>
 __device__ __forceinline__ CoarseStage stage_coarse_levels(const LevelTab *tab, const Params &p, rsrc_t rs, uint32_t plane_row_bytes, size_t lds_off)
 {
@@ -726,6 +738,27 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     constexpr int kPre = 2;
     // (not with LDS-served levels: the wave does not know its first queries before the staging barrier)
     const bool pre = !FUSED && !LDSL && p.sc >= p.LP && UPW * p.LP <= kPre * kWave;
+    // LDSL: the next slice's points and weights go to the wave's LDS staging area instead (dma_dword: no registers)
+    constexpr bool kDma = LDSL && !FUSED && sizeof(T) == 4;
+    const bool pre_dma = kDma && p.sc >= p.LP && UPW * p.LP <= kStagePre * kWave;
+    const size_t rec_bytes = kGatherLdsFixed + (size_t)NU * (p.sc + 1) * (sizeof(uint4) + sizeof(Rec4<A>) + (FUSED ? 3 * sizeof(A) : 0));
+    const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)rec_bytes + (uint32_t)(threadIdx.x / kWave) * kStageWaveBytes);
+    // (M0 wants the absolute LDS address: the dynamic area starts behind any static __shared__ object)
+    const uint32_t stage_abs = stage_lds + __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(__attribute__((address_space(3))) char *)msda_smem);
+    [[maybe_unused]] auto stage_request = [&](int wq, int qlim) {
+#pragma unroll
+        for (int t = 0; t < kStagePre; ++t) {
+            const int f = (int)(threadIdx.x % kWave) + t * kWave;
+            const int fu = div_small(f, p.LP, 1.0f / (float)p.LP);
+            const int fq = wq + fu;
+            if (f < UPW * p.LP && fq < qlim) {
+                const int sidx = imul24(fq, HLP) + (f - imul24(fu, p.LP));
+                dma_dword(loc + 2 * sidx, stage_abs + (uint32_t)t * (3 * kWave * 4));
+                dma_dword(loc + 2 * sidx + 1, stage_abs + (uint32_t)t * (3 * kWave * 4) + kWave * 4);
+                dma_dword(attn + sidx, stage_abs + (uint32_t)t * (3 * kWave * 4) + 2 * kWave * 4);
+            }
+        }
+    };
     Pack<T, 2> pxy[kPre];
     T pa[kPre];
 #pragma unroll
@@ -746,8 +779,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     __syncthreads();
     CoarseStage cs{p.L, 0, 0, (uint32_t)p.D * (uint32_t)sizeof(TV)};
     if constexpr (LDSL)
-        cs = stage_coarse_levels<TV, VEC, BLK>(tab, p, rs, row_bytes,
-                                               kGatherLdsFixed + (size_t)NU * scp * (sizeof(uint4) + sizeof(Rec4<A>) + (FUSED ? 3 * sizeof(A) : 0)));
+        cs = stage_coarse_levels<TV, VEC, BLK>(tab, p, rs, row_bytes, rec_bytes + (kDma ? (size_t)(BLK / kWave) * kStageWaveBytes : 0));
     // levels [fl, L) are SERVED from LDS: the first staged level whose first sample starts an exchange batch of G samples
     // in every trip (P = 4 / 8: every level; a staged level in front of it is simply not used)
     int fl = cs.first;
@@ -759,11 +791,26 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     // LDSL: the workgroup's queries [q_lo, q_hi) go to its waves slice by slice (next_slice)
     const int q_lo = imul24(slot * p.qw, NU), q_hi = min(p.Q, imul24(qc_end, NU));
     const int q_end_ = LDSL ? q_hi : p.Q;  // queries beyond it are not this workgroup's
-    if constexpr (LDSL) stagger_wave(wave, p.lds_stagger);
+    // LDSL: the NEXT slice is taken, and its points requested, as soon as this slice's are consumed (as in the forward)
+    int t_next = 0;
+    bool have_next = false;
+    if constexpr (LDSL) {
+        stagger_wave(wave, p.lds_stagger);
+        if constexpr (kDma) {
+            if (pre_dma) {
+                t_next = next_slice(lane);
+                have_next = true;
+                stage_request(q_lo + t_next * UPW, q_hi);
+                dma_wait();
+            }
+        }
+    }
     for (int it = 0;; ++it) {
         int wq0;  // first query of this wave (wave-uniform)
         if constexpr (LDSL) {
-            wq0 = q_lo + next_slice(lane) * UPW;
+            if (!have_next) t_next = next_slice(lane);
+            have_next = false;
+            wq0 = q_lo + t_next * UPW;
             if (wq0 >= q_hi) break;
         } else {
             const int qc = slot * p.qw + it;
@@ -874,6 +921,23 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
 #pragma unroll
                 for (int t = 0; t < kPre; ++t)
                     if (lane + t * kWave < UPW * sc) tap_sample(lane + t * kWave, true, pxy[t], pa[t]);
+            } else if (pre_dma) {
+                if constexpr (kDma) {
+                    const float *st = reinterpret_cast<const float *>(msda_smem + stage_lds);
+#pragma unroll
+                    for (int t = 0; t < kStagePre; ++t) {
+                        if (lane + t * kWave < UPW * sc) {
+                            Pack<T, 2> hxy;
+                            hxy.v[0] = st[t * 3 * kWave + lane];
+                            hxy.v[1] = st[t * 3 * kWave + kWave + lane];
+                            tap_sample(lane + t * kWave, true, hxy, st[t * 3 * kWave + 2 * kWave + lane]);
+                        }
+                    }
+                    wave_lds_sync();  // (staging area read before it is requested again)
+                    t_next = next_slice(lane);
+                    have_next = true;
+                    stage_request(q_lo + t_next * UPW, q_hi);
+                }
             } else {
                 for (int f = lane; f < UPW * sc; f += kWave) tap_sample(f, false, pxy[0], pa[0]);
             }
@@ -1168,6 +1232,9 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                 }
             }
             wave_lds_sync();
+            if constexpr (kDma) {
+                if (pre_dma) dma_wait();  // the next slice's inputs have landed (they are older than this slice's gathers)
+            }
             // ---- phase 3: coalesced write-out, one sample per lane and trip ----
             for (int f = lane; f < UPW * sc; f += kWave) {
                 const int fu = div_small(f, sc, inv_sc);
@@ -1190,7 +1257,12 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                             kx = TR::to_acc(r[2]) * half_inv_P;
                             ky = TR::to_acc(r[3]) * half_inv_P;
                         }
-                        if (p.mat_loc != nullptr) {
+#ifdef MSDA_DEV  // ablations: 4096 no parked points / weights, 8192 no grad_proj stores
+                        const bool abl_mat = p.debug & 4096, abl_gp = p.debug & 8192;
+#else
+                        constexpr bool abl_mat = false, abl_gp = false;
+#endif
+                        if (p.mat_loc != nullptr && !abl_mat) {
                             // the sampling point and attention weight this kernel derived, for the grad_value passes
                             // (stored here, at the end of the wave's life, where nothing waits behind the stores)
                             const A ox = w_ox[rs_], oy = w_oy[rs_];
@@ -1210,9 +1282,11 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                         g1.v[0] = TR::from_acc(res.v[2] * ky);
                         g2.v[0] = TR::from_acc(a * (res.v[0] - dot));
                         T *gp = static_cast<T *>(p.grad_loc) + 3 * (plane_s0 + sidx);
-                        store_stream(gp, g0);
-                        store_stream(gp + 1, g1);
-                        store_stream(gp + 2, g2);
+                        if (!abl_gp) {
+                            store_stream(gp, g0);
+                            store_stream(gp + 1, g1);
+                            store_stream(gp + 2, g2);
+                        }
                     } else {
                         Pack<T, 1> ga;
                         ga.v[0] = TR::from_acc(res.v[0]);

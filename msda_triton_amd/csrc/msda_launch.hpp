@@ -170,7 +170,7 @@ struct LdsLevelsPlan {
     size_t lds;
     int lev_bytes;
 };
-template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(const Params &p, bool aux)
+template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(const Params &p, bool aux, bool stage = false)
 {
     using A = typename Traits<T>::acc;
     constexpr int NU = kBlockLds / G;
@@ -181,6 +181,7 @@ template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(c
         pl.sc = pl.sc / G * G;
         rec_lds = kGatherLdsFixed + (size_t)NU * (pl.sc + 1) * (16 + (aux ? 7 : 4) * sizeof(A));
     }
+    if (stage) rec_lds += (size_t)(kBlockLds / kWave) * kStageWaveBytes;  // the waves' next-slice staging areas (dma_dword)
     const size_t lev_base = (rec_lds + 127) / 128 * 128, row = (size_t)p.D * sizeof(TV);
     const long long room = (long long)kMaxDynLds - (long long)lev_base - (long long)((row + 15) / 16 * 16);
     pl.nqc = (p.Q + NU - 1) / NU;
@@ -258,7 +259,7 @@ template <typename T, int VEC, int G, int MODE, typename TV = T> inline int laun
     // module's step at the c2 shape went 1.09 -> 1.31 ms with the levels in LDS
     if constexpr (sizeof(T) == 4 && VEC == 4 && sizeof(TV) == 4 &&
                   (((MODE == 0 || MODE == 2) && G <= 16) || ((MODE == 1 || MODE == 3) && (G == 4 || G == 8)))) {
-        const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, MODE == 3);
+        const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, MODE == 3, MODE == 1);
         if (pl.use && (MODE < 2 || pl.sc == p.LP)) return launch_gather_lds<T, VEC, G, MODE, TV>(p, pl, stream);
     }
     size_t lds;
