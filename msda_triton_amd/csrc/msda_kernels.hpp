@@ -458,6 +458,16 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                             const bool inl = l >= fl;
                             make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l] - (inl ? tab->start[cs.first] : 0), p.zeros, p.align,
                                          inl ? cs.row_bytes : row_bytes, t, inl ? cs.base : 0u, inl ? cs.zero : kMaskedOffset);
+#ifdef MSDA_DEV  // ablation 16384 (WRONG results): LDS rows forced onto the bank half of the unit's parity — what a
+                 // conflict-free order of the corner reads would be worth
+                            if ((p.debug & 16384) && inl) {
+                                const uint32_t par = (uint32_t)(fu & 1) << 7;
+                                t.off[0] = cs.base + (((t.off[0] - cs.base) & ~128u) | par);
+                                t.off[2] = cs.base + (((t.off[2] - cs.base) & ~128u) | par);
+                                t.off[1] = cs.base + (((t.off[1] - cs.base) & ~128u) | (par ^ 128u));
+                                t.off[3] = cs.base + (((t.off[3] - cs.base) & ~128u) | (par ^ 128u));
+                            }
+#endif
                         } else {
                             make_taps<A>(sx, sy, tab->h[l], tab->w[l], tab->start[l], p.zeros, p.align, row_bytes, t);
                         }

@@ -1,9 +1,15 @@
 """dev tool: the weight / bias gradients of the module's three Linear layers at the c2 module shape (tall-skinny K:
 dW[out, in] = dY[N, out]^T X[N, in] with N = 21 760 / 40 000, out, in <= 384) — the GEMM the BLAS library picks
 (16 workgroups of 64 x 64 tiles, no split-K) against a batched split over the rows.   python tools/linear_wgrad_bench.py"""
+import sys
+
 import torch
 
 dev = torch.device("cuda", 0)
+if "--tunable" in sys.argv:  # PyTorch's TunableOp: every rocBLAS / hipBLASLt solution is timed once per shape, the best is used
+    torch.cuda.tunable.enable(True)
+    torch.cuda.tunable.tuning_enable(True)
+    torch.cuda.tunable.set_max_tuning_duration(300)
 
 
 def timeit(fn, reps=200):
