@@ -138,6 +138,27 @@ MSDA_DECLARE(f64)
 MSDA_DECLARE(f32_vbf16)
 MSDA_DECLARE(f32_vf16)
 #undef MSDA_DECLARE
+/* Module storage (round 5; fused entry points only): `value`, `proj`, `out` and their gradients (grad_value, grad_proj,
+ * grad_out) are bf16 / fp16, the reference points `ref` and `grad_ref_partial` fp32, all arithmetic fp32 — what the
+ * reference's nn.Module computes under torch.autocast (its core casts every input to fp32, frontend.py:111) without the
+ * fp32 copies of the projection and of the result and their gradients: a 16-bit projection holds exactly what autocast's
+ * GEMM produced, while reference points in 16 bits would put the samples up to a quarter pixel off.  Same signatures as
+ * msda_fwd_fused_<dtype> / msda_bwd_fused_<dtype>; workspace: msda_bwd_fused_workspace_bytes(..., elem_size 4,
+ * value_elem_size 2, ...). */
+#define MSDA_DECLARE_FUSED_STORAGE(SUF)                                                                \
+    MSDA_API int msda_fwd_fused_##SUF(const void *value, const int64_t *shapes, const void *proj,      \
+                       const void *ref, void *out, int64_t B, int64_t I, int64_t H, int64_t D,        \
+                       int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,                 \
+                       int align_corners, void *stream);                                               \
+    MSDA_API int msda_bwd_fused_##SUF(const void *grad_out, const void *value, const int64_t *shapes, \
+                       const void *proj, const void *ref, void *grad_value, void *grad_proj,           \
+                       void *grad_ref_partial, int64_t B, int64_t I, int64_t H, int64_t D,              \
+                       int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,                  \
+                       int align_corners, int64_t max_level_cells, void *workspace,                     \
+                       int64_t workspace_bytes, void *stream);
+MSDA_DECLARE_FUSED_STORAGE(f32_sbf16)
+MSDA_DECLARE_FUSED_STORAGE(f32_sf16)
+#undef MSDA_DECLARE_FUSED_STORAGE
 
 /*
  * Bytes of device workspace msda_bwd_<dtype> wants for these sizes.  elem_size: of everything but `value`;

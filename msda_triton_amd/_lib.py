@@ -20,10 +20,13 @@ PADDING_MODES = {"border": 0, "zeros": 1}
 WS_RECORDS_IN_GRADS = 1  # msda_bwd_workspace_bytes flag (include/msda_hip.h)
 # one storage type for every tensor, then the mixed ones: value / grad_value in 16 bits, everything else fp32
 DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64", "f32_vbf16", "f32_vf16")
+# module storage (fused entry points only): value, projection, out and their gradients in 16 bits, reference points fp32
+FUSED_STORAGE_SUFFIXES = ("f32_sbf16", "f32_sf16")
 
 # every symbol include/msda_hip.h declares
 EXPORTED_SYMBOLS = tuple(
     [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused", "bwd_fused") for s in DTYPE_SUFFIXES]
+    + [f"msda_{d}_{s}" for d in ("fwd_fused", "bwd_fused") for s in FUSED_STORAGE_SUFFIXES]
     + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option", "msda_bwd_workspace_bytes",
        "msda_bwd_fused_workspace_bytes", "msda_bwd_supported", "msda_fused_lp_limit", "msda_profile_read"]
 )
@@ -77,6 +80,13 @@ def load():
             g = getattr(lib, f"msda_bwd_{suf}")
             g.restype = ci
             g.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, i64, vp, i64, vp]
+            gf = getattr(lib, f"msda_bwd_fused_{suf}")
+            gf.restype = ci
+            gf.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, i64, vp, i64, vp]
+        for suf in FUSED_STORAGE_SUFFIXES:
+            ff = getattr(lib, f"msda_fwd_fused_{suf}")
+            ff.restype = ci
+            ff.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, ci, vp]
             gf = getattr(lib, f"msda_bwd_fused_{suf}")
             gf.restype = ci
             gf.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, i64, vp, i64, vp]

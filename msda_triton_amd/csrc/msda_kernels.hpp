@@ -256,9 +256,13 @@ __device__ __forceinline__ void request_all_arguments(const Params &p)
 //  cache a batch of 16 loads per lane takes ~2 500 cycles, four of them per unit — but 64 loads at once took 2.5x as
 //  long as the four batches together (in-kernel clock, Q = 10 / 100).  What small grids want is more WAVES with few
 //  loads each: msda_fwd_unit_kernel below.)
-template <typename T, int VEC, int G, bool FUSED, typename TV = T, int BLK = kBlock, bool LDSL = false>
+// TS (module kernels, FUSED): storage type of the projection and of `out` when it differs from the arithmetic type T —
+// 16-bit projections / results next to fp32 reference points and fp32 arithmetic (msda_*_fused_f32_sbf16 / _sf16)
+template <typename T, int VEC, int G, bool FUSED, typename TV = T, int BLK = kBlock, bool LDSL = false, typename TS = T>
 __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlock ? 5 : 4))) void msda_fwd_kernel(const Params p)
 {
+    using SR = Traits<TS>;
+    static_assert(FUSED || sizeof(TS) == sizeof(T), "a separate storage type exists for the module kernels only");
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
@@ -289,7 +293,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     Rec4<A> *w_rec = lds.s_rec + wave * UPW * scp;
     // per-plane bases (64-bit, uniform) + 32-bit per-sample indices (the host checks Q*H*L*P*3 < 2^31)
     const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
-    const T *loc = static_cast<const T *>(p.loc) + (FUSED ? 3 : 2) * plane_s0;  // FUSED: raw projection (dx, dy, logit)
+    const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
+    [[maybe_unused]] const TS *proj3 = static_cast<const TS *>(p.loc) + 3 * plane_s0;  // FUSED: raw projection (dx, dy, logit)
     const T *attn = FUSED ? nullptr : static_cast<const T *>(p.attn) + plane_s0;
     const T *refp = FUSED ? static_cast<const T *>(p.ref) + (size_t)b * p.Q * p.ref_dim : nullptr;
     const int HLP = p.H * p.LP;
@@ -397,8 +402,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                         if (fq < q_end_) {
                             const int l = div_small(sl, p.P, inv_P);
                             const int sidx = imul24(fq, HLP) + sl;
-                            const A ox = TR::to_acc(loc[3 * sidx]), oy = TR::to_acc(loc[3 * sidx + 1]);
-                            const A lg = TR::to_acc(loc[3 * sidx + 2]);
+                            const A ox = SR::to_acc(proj3[3 * sidx]), oy = SR::to_acc(proj3[3 * sidx + 1]);
+                            const A lg = SR::to_acc(proj3[3 * sidx + 2]);
                             const T *r = refp + (size_t)fq * p.ref_dim;
                             Rec4<A> w;
                             w.v[0] = lg;
@@ -540,10 +545,10 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                 }
             }
             if (lane_ok) {
-                Pack<T, VEC> o;
+                Pack<TS, VEC> o;
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) o.v[i] = TR::from_acc(acc[i]);
-                T *dst = static_cast<T *>(p.out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D + c0;
+                for (int i = 0; i < VEC; ++i) o.v[i] = SR::from_acc(acc[i]);
+                TS *dst = static_cast<TS *>(p.out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D + c0;
 #ifdef MSDA_DEV
                 asm volatile("" ::"v"(o.v[0]));
                 MSDA_STAMP(clk_d);
@@ -696,9 +701,11 @@ __global__ __launch_bounds__(kWave) void msda_fwd_unit_kernel(const Params p)
 // three results are reduced over the unit's G lanes with DPP moves and written exactly once.
 // ==========================================================================================
 // LDSL (BLK = kBlockLds): the coarsest levels served from LDS, as in the forward (reduce-scatter units only).
-template <typename T, int VEC, int G, bool FUSED, typename TV = T, int BLK = kBlock, bool LDSL = false>
+template <typename T, int VEC, int G, bool FUSED, typename TV = T, int BLK = kBlock, bool LDSL = false, typename TS = T>
 __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
 {
+    using SR = Traits<TS>;  // (FUSED only: storage of the projection, grad_out and grad_proj; see msda_fwd_kernel)
+    static_assert(FUSED || sizeof(TS) == sizeof(T), "a separate storage type exists for the module kernels only");
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     static_assert(sizeof(typename Traits<TV>::acc) == sizeof(A), "value rows widen to the same accumulate type");
@@ -733,7 +740,8 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     Rec4<A> *w_rec = lds.s_rec + wave * UPW * scp;
     // per-plane bases (64-bit, uniform) + 32-bit per-sample indices (the host checks Q*H*L*P*2 < 2^31)
     const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
-    const T *loc = static_cast<const T *>(p.loc) + (FUSED ? 3 : 2) * plane_s0;  // FUSED: raw projection (dx, dy, logit)
+    const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
+    [[maybe_unused]] const TS *proj3 = static_cast<const TS *>(p.loc) + 3 * plane_s0;  // FUSED: raw projection (dx, dy, logit)
     const T *attn = FUSED ? nullptr : static_cast<const T *>(p.attn) + plane_s0;
     const T *refp = FUSED ? static_cast<const T *>(p.ref) + (size_t)b * p.Q * p.ref_dim : nullptr;
     A *w_aux = lds.s_aux + wave * UPW * scp * 3;  // FUSED: [slot] = a, [UPW*scp + slot] = ox, [2*UPW*scp + slot] = oy
@@ -846,8 +854,8 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                     if (fq < q_end_) {
                         const int l = div_small(sl, p.P, inv_P);
                         const int sidx = imul24(fq, HLP) + sl;
-                        const A ox = TR::to_acc(loc[3 * sidx]), oy = TR::to_acc(loc[3 * sidx + 1]);
-                        const A lg = TR::to_acc(loc[3 * sidx + 2]);
+                        const A ox = SR::to_acc(proj3[3 * sidx]), oy = SR::to_acc(proj3[3 * sidx + 1]);
+                        const A lg = SR::to_acc(proj3[3 * sidx + 2]);
                         const T *r = refp + (size_t)fq * p.ref_dim;
                         Rec4<A> w;
                         w.v[0] = lg;
@@ -959,7 +967,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
             if (unit_ok) {  // idle lanes of a live unit still join the DPP sums
                 const uint4 *uo = w_off + imul24(wunit, scp);
                 Rec4<A> *up = w_rec + imul24(wunit, scp);
-                const T *go_row = static_cast<const T *>(p.grad_out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D;
+                const TS *go_row = static_cast<const TS *>(p.grad_out) + ((size_t)(b * (size_t)p.Q + q) * p.H + h) * p.D;
                 // one sample's epilogue: combine the four dot products, reduce over the unit, park the result
                 auto finish = [&](int s, const Rec4<A> &r, A d0, A d1, A d2, A d3) {
                     const A dx = r.v[0], dy = r.v[1];
@@ -991,13 +999,13 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                         const int c0 = j * VEC;
                         const bool lane_in = c0 < p.D;
                         const uint32_t lo = lane_in ? (uint32_t)c0 * (uint32_t)sizeof(TV) : 0u;
-                        Pack<T, VEC> gp;
+                        Pack<TS, VEC> gp;
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) gp.v[i] = TR::from_acc((A)0);
-                        if (lane_in) gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
+                        for (int i = 0; i < VEC; ++i) gp.v[i] = SR::from_acc((A)0);
+                        if (lane_in) gp = *reinterpret_cast<const Pack<TS, VEC> *>(go_row + c0);
                         A g[VEC];
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) g[i] = TR::to_acc(gp.v[i]);
+                        for (int i = 0; i < VEC; ++i) g[i] = SR::to_acc(gp.v[i]);
                         using RLV = RawLoad<sizeof(TV) * VEC>;
                         // one exchange: the samples [sb, sb + G) of this trip, their rows from memory or (LDS: a compile-time
                         // tag, so that each loop below is straight-line code) from the LDS-resident levels
@@ -1098,10 +1106,10 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                     const int c0 = j * VEC;
                     const bool lane_in = c0 < p.D;
                     const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(TV);
-                    Pack<T, VEC> gp;
+                    Pack<TS, VEC> gp;
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) gp.v[i] = TR::from_acc((A)0);
-                    if (lane_in) gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
+                    for (int i = 0; i < VEC; ++i) gp.v[i] = SR::from_acc((A)0);
+                    if (lane_in) gp = *reinterpret_cast<const Pack<TS, VEC> *>(go_row + c0);
                     if constexpr (TR::kDot2 && (VEC % 2) == 0 && sizeof(TV) == sizeof(T)) {
                         // 16-bit rows: the four dot products with grad_out straight from the packed pairs
                         // (v_dot2c_f32_f16 / _bf16: two multiply-adds per instruction, no widening)
@@ -1145,7 +1153,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                     } else {
                     A g[VEC];
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i) g[i] = TR::to_acc(gp.v[i]);
+                    for (int i = 0; i < VEC; ++i) g[i] = SR::to_acc(gp.v[i]);
                     for (int sb = 0; sb < sc; sb += UB) {
                         uint4 o[UB];
                         Rec4<A> r[UB];
@@ -1187,7 +1195,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                             const int c0 = (cc * G + j) * VEC;
                             if (c0 < p.D) {
                                 const uint32_t lane_off = (uint32_t)c0 * (uint32_t)sizeof(TV);
-                                const Pack<T, VEC> gp = *reinterpret_cast<const Pack<T, VEC> *>(go_row + c0);
+                                const Pack<TS, VEC> gp = *reinterpret_cast<const Pack<TS, VEC> *>(go_row + c0);
                                 A v0[VEC], v1[VEC], v2[VEC], v3[VEC];
                                 load_row<TV, VEC>(rs, o.x + lane_off, v0);
                                 load_row<TV, VEC>(rs, o.y + lane_off, v1);
@@ -1195,7 +1203,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                                 load_row<TV, VEC>(rs, o.w + lane_off, v3);
 #pragma unroll
                                 for (int i = 0; i < VEC; ++i) {
-                                    const A gg = TR::to_acc(gp.v[i]);
+                                    const A gg = SR::to_acc(gp.v[i]);
                                     d0 = fma_t(gg, v0[i], d0);
                                     d1 = fma_t(gg, v1[i], d1);
                                     d2 = fma_t(gg, v2[i], d2);
@@ -1287,11 +1295,11 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                             *reinterpret_cast<Pack<T, 2> *>(static_cast<T *>(p.mat_loc) + 2 * (plane_s0 + sidx)) = m;
                             static_cast<T *>(p.mat_attn)[plane_s0 + sidx] = TR::from_acc(a);
                         }
-                        Pack<T, 1> g0, g1, g2;
-                        g0.v[0] = TR::from_acc(res.v[1] * kx);
-                        g1.v[0] = TR::from_acc(res.v[2] * ky);
-                        g2.v[0] = TR::from_acc(a * (res.v[0] - dot));
-                        T *gp = static_cast<T *>(p.grad_loc) + 3 * (plane_s0 + sidx);
+                        Pack<TS, 1> g0, g1, g2;
+                        g0.v[0] = SR::from_acc(res.v[1] * kx);
+                        g1.v[0] = SR::from_acc(res.v[2] * ky);
+                        g2.v[0] = SR::from_acc(a * (res.v[0] - dot));
+                        TS *gp = static_cast<TS *>(p.grad_loc) + 3 * (plane_s0 + sidx);
                         if (!abl_gp) {
                             store_stream(gp, g0);
                             store_stream(gp + 1, g1);

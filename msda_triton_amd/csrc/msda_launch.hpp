@@ -232,7 +232,7 @@ template <typename T, int VEC, int G, int MODE, typename TV> inline int launch_g
     return (int)hipGetLastError();
 }
 
-template <typename T, int VEC, int G, int MODE, typename TV = T> inline int launch_gather(Params &p, hipStream_t stream)
+template <typename T, int VEC, int G, int MODE, typename TV = T, typename TS = T> inline int launch_gather(Params &p, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
     constexpr int NU = kBlock / G;
@@ -282,7 +282,7 @@ template <typename T, int VEC, int G, int MODE, typename TV = T> inline int laun
     static std::atomic<uint64_t> big_lds_done{0};  // one per template instantiation
     const ProfileScope prof(MODE == 0 || MODE == 2 ? "msda_fwd_kernel" : "msda_bwd_sample_kernel", stream);
     if constexpr (MODE == 3) {
-        auto kernel = msda_bwd_sample_kernel<T, VEC, G, true, TV>;
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, true, TV, kBlock, false, TS>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else if constexpr (MODE == 1) {
@@ -290,7 +290,7 @@ template <typename T, int VEC, int G, int MODE, typename TV = T> inline int laun
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else if constexpr (MODE == 2) {
-        auto kernel = msda_fwd_kernel<T, VEC, G, true, TV>;
+        auto kernel = msda_fwd_kernel<T, VEC, G, true, TV, kBlock, false, TS>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, p);
     } else {
@@ -301,27 +301,27 @@ template <typename T, int VEC, int G, int MODE, typename TV = T> inline int laun
     return (int)hipGetLastError();
 }
 
-template <typename T, int VEC, int MODE, typename TV = T> inline int dispatch_group(Params &p, hipStream_t stream)
+template <typename T, int VEC, int MODE, typename TV = T, typename TS = T> inline int dispatch_group(Params &p, hipStream_t stream)
 {
     const int lanes = (p.D + VEC - 1) / VEC;
     switch (pick_group(lanes)) {
-    case 4: return launch_gather<T, VEC, 4, MODE, TV>(p, stream);
-    case 8: return launch_gather<T, VEC, 8, MODE, TV>(p, stream);
-    case 16: return launch_gather<T, VEC, 16, MODE, TV>(p, stream);
-    case 32: return launch_gather<T, VEC, 32, MODE, TV>(p, stream);
-    default: return launch_gather<T, VEC, 64, MODE, TV>(p, stream);
+    case 4: return launch_gather<T, VEC, 4, MODE, TV, TS>(p, stream);
+    case 8: return launch_gather<T, VEC, 8, MODE, TV, TS>(p, stream);
+    case 16: return launch_gather<T, VEC, 16, MODE, TV, TS>(p, stream);
+    case 32: return launch_gather<T, VEC, 32, MODE, TV, TS>(p, stream);
+    default: return launch_gather<T, VEC, 64, MODE, TV, TS>(p, stream);
     }
 }
 
-template <typename T, int MODE, typename TV = T> inline int dispatch_gather(Params &p, bool vec_ok, hipStream_t stream)
+template <typename T, int MODE, typename TV = T, typename TS = T> inline int dispatch_gather(Params &p, bool vec_ok, hipStream_t stream)
 {
     constexpr int VECF = 16 / sizeof(T);  // channels per lane (mixed storage: the 16-bit value rows load as 8-byte pieces)
-    if (vec_ok && (p.D % VECF) == 0) return dispatch_group<T, VECF, MODE, TV>(p, stream);
-    return dispatch_group<T, 1, MODE, TV>(p, stream);
+    if (vec_ok && (p.D % VECF) == 0) return dispatch_group<T, VECF, MODE, TV, TS>(p, stream);
+    return dispatch_group<T, 1, MODE, TV, TS>(p, stream);
 }
 
 // ---- sorted (gather-formulated) grad_value: K1..K5 of msda_value_sorted.hpp ----
-template <typename T, int VEC, int G, int GB, typename TV = T> inline int launch_value_gather_block(Params &p, hipStream_t stream)
+template <typename T, int VEC, int G, int GB, typename TV = T, typename TS = T> inline int launch_value_gather_block(Params &p, hipStream_t stream)
 {
     constexpr int NUG = GB / G;
     const int npairs = p.B * p.H;
@@ -332,7 +332,7 @@ template <typename T, int VEC, int G, int GB, typename TV = T> inline int launch
     }
     {
         const ProfileScope prof("msda_value_gather_kernel", stream);
-        hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G, GB>), g4, dim3(GB), 0, stream, p);
+        hipLaunchKernelGGL((msda_value_gather_kernel<T, VEC, G, GB, TS>), g4, dim3(GB), 0, stream, p);
     }
     // (4-lane groups: 64 of them per workgroup, so 64 pixels keep them all busy)
     const int fp = kBlock / G > 32 ? 64 : finish_pixels(npairs, p.I);
@@ -348,21 +348,21 @@ template <typename T, int VEC, int G, int GB, typename TV = T> inline int launch
     return (int)hipGetLastError();
 }
 
-template <typename T, int VEC, int G, typename TV = T> inline int launch_value_gather(Params &p, hipStream_t stream)
+template <typename T, int VEC, int G, typename TV = T, typename TS = T> inline int launch_value_gather(Params &p, hipStream_t stream)
 {
     // (64- and 128-thread gather workgroups were measured too: 71-74 us against 73.6 at c2-10k — no effect, removed)
-    return launch_value_gather_block<T, VEC, G, 256, TV>(p, stream);
+    return launch_value_gather_block<T, VEC, G, 256, TV, TS>(p, stream);
 }
 
-template <typename T, int VEC, typename TV = T> inline int dispatch_value_gather_group(Params &p, hipStream_t stream)
+template <typename T, int VEC, typename TV = T, typename TS = T> inline int dispatch_value_gather_group(Params &p, hipStream_t stream)
 {
     const int lanes = (p.D + VEC - 1) / VEC;
     switch (pick_group(lanes)) {
-    case 4: return launch_value_gather<T, VEC, 4, TV>(p, stream);
-    case 8: return launch_value_gather<T, VEC, 8, TV>(p, stream);
-    case 16: return launch_value_gather<T, VEC, 16, TV>(p, stream);
-    case 32: return launch_value_gather<T, VEC, 32, TV>(p, stream);
-    default: return launch_value_gather<T, VEC, 64, TV>(p, stream);
+    case 4: return launch_value_gather<T, VEC, 4, TV, TS>(p, stream);
+    case 8: return launch_value_gather<T, VEC, 8, TV, TS>(p, stream);
+    case 16: return launch_value_gather<T, VEC, 16, TV, TS>(p, stream);
+    case 32: return launch_value_gather<T, VEC, 32, TV, TS>(p, stream);
+    default: return launch_value_gather<T, VEC, 64, TV, TS>(p, stream);
     }
 }
 
@@ -373,7 +373,7 @@ template <typename T> inline bool value_vec_ok(const Params &p)
     return aligned_to(p.grad_out, 16) && aligned_to(p.grad_value, 16) && (p.D % VECF) == 0;
 }
 
-template <typename T, typename TV = T> inline int run_value_sorted(Params &p, const Dims &d, void *workspace, hipStream_t stream)
+template <typename T, typename TV = T, typename TS = T> inline int run_value_sorted(Params &p, const Dims &d, void *workspace, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
     const bool vec_ok = value_vec_ok<T>(p);
@@ -500,7 +500,7 @@ template <typename T, typename TV = T> inline int run_value_sorted(Params &p, co
         }
         int rc = (int)hipGetLastError();
         if (rc) return rc;
-        rc = vec_ok ? dispatch_value_gather_group<T, VECF, TV>(p, stream) : dispatch_value_gather_group<T, 1, TV>(p, stream);
+        rc = vec_ok ? dispatch_value_gather_group<T, VECF, TV, TS>(p, stream) : dispatch_value_gather_group<T, 1, TV, TS>(p, stream);
         if (rc) return rc;
     }
     return 0;
@@ -566,14 +566,15 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
 
 // Module forward with the prologue fused in: `proj` is the raw query projection
 // [B, Q, H, L, P, 3] = (x offset, y offset, attention logit), `ref` the reference points [B, Q, ref_dim].
-template <typename T, typename TV = T>
+// TS: storage type of `proj` and `out` (T unless the module keeps them in 16 bits next to fp32 reference points)
+template <typename T, typename TV = T, typename TS = T>
 int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, const void *ref, void *out, int64_t B,
                   int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,
                   int align_corners, void *stream_)
 {
     const Dims d{B, I, H, D, Q, L, P};
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const size_t out_bytes = (size_t)(B * Q * H * D) * sizeof(T);
+    const size_t out_bytes = (size_t)(B * Q * H * D) * sizeof(TS);
     if (out_bytes == 0) return 0;
     if (ref_dim != 2 && ref_dim != 4) {
         set_error("ref_dim must be 2 or 4, got %d", ref_dim);
@@ -590,7 +591,7 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
         set_error("projection too large for 32-bit sample offsets");
         return MSDA_ERR_TOO_LARGE;
     }
-    if (!aligned_to(value, sizeof(TV)) || !aligned_to(out, sizeof(T)) || !aligned_to(proj, sizeof(T)) ||
+    if (!aligned_to(value, sizeof(TV)) || !aligned_to(out, sizeof(TS)) || !aligned_to(proj, sizeof(TS)) ||
         !aligned_to(ref, sizeof(T)) || !aligned_to(shapes, 8)) {
         set_error("misaligned buffer");
         return MSDA_ERR_MISALIGNED;
@@ -605,7 +606,7 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
     p.ref = ref;
     p.ref_dim = ref_dim;
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
-    rc = dispatch_gather<T, 2, TV>(p, vec_ok, stream);
+    rc = dispatch_gather<T, 2, TV, TS>(p, vec_ok, stream);
     if (rc > 0) set_error("fused forward launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }
@@ -625,7 +626,7 @@ template <typename T> inline size_t small_need_bytes(const Dims &d, bool vec)
     return small_lds_bytes((size_t)small_cell_cap(d), (size_t)(d.Q * d.P), sizeof(A), vecw);
 }
 
-template <typename T, int VEC, int G, typename TV = T> inline int launch_value_small(Params &p, size_t lds, hipStream_t stream)
+template <typename T, int VEC, int G, typename TV = T, typename TS = T> inline int launch_value_small(Params &p, size_t lds, hipStream_t stream)
 {
     dim3 grid;
     if (!plane_grid(p, p.B * p.H, (int64_t)p.L * p.small_ns, grid)) {
@@ -633,25 +634,25 @@ template <typename T, int VEC, int G, typename TV = T> inline int launch_value_s
         return MSDA_ERR_TOO_LARGE;
     }
     static std::atomic<uint64_t> big_lds_done{0};
-    allow_big_lds(msda_value_small_kernel<T, VEC, G, TV>, big_lds_done);
+    allow_big_lds(msda_value_small_kernel<T, VEC, G, TV, TS>, big_lds_done);
     const ProfileScope prof("msda_value_small_kernel", stream);
-    hipLaunchKernelGGL((msda_value_small_kernel<T, VEC, G, TV>), grid, dim3(kSmallBlock), lds, stream, p);
+    hipLaunchKernelGGL((msda_value_small_kernel<T, VEC, G, TV, TS>), grid, dim3(kSmallBlock), lds, stream, p);
     return (int)hipGetLastError();
 }
 
-template <typename T, int VEC, typename TV = T> inline int dispatch_value_small_group(Params &p, size_t lds, hipStream_t stream)
+template <typename T, int VEC, typename TV = T, typename TS = T> inline int dispatch_value_small_group(Params &p, size_t lds, hipStream_t stream)
 {
     const int lanes = (p.D + VEC - 1) / VEC;
     switch (pick_group(lanes)) {
-    case 4: return launch_value_small<T, VEC, 4, TV>(p, lds, stream);
-    case 8: return launch_value_small<T, VEC, 8, TV>(p, lds, stream);
-    case 16: return launch_value_small<T, VEC, 16, TV>(p, lds, stream);
-    case 32: return launch_value_small<T, VEC, 32, TV>(p, lds, stream);
-    default: return launch_value_small<T, VEC, 64, TV>(p, lds, stream);
+    case 4: return launch_value_small<T, VEC, 4, TV, TS>(p, lds, stream);
+    case 8: return launch_value_small<T, VEC, 8, TV, TS>(p, lds, stream);
+    case 16: return launch_value_small<T, VEC, 16, TV, TS>(p, lds, stream);
+    case 32: return launch_value_small<T, VEC, 32, TV, TS>(p, lds, stream);
+    default: return launch_value_small<T, VEC, 64, TV, TS>(p, lds, stream);
     }
 }
 
-template <typename T, typename TV = T> inline int run_value_small(Params &p, const Dims &d, hipStream_t stream)
+template <typename T, typename TV = T, typename TS = T> inline int run_value_small(Params &p, const Dims &d, hipStream_t stream)
 {
     constexpr int VECF = 16 / sizeof(T);
     const bool vec_ok = value_vec_ok<T>(p);
@@ -663,7 +664,7 @@ template <typename T, typename TV = T> inline int run_value_small(Params &p, con
     // (also measured: one more workgroup for the level with the most pixels only — c4 55 -> 62 us, dropped)
     p.small_ns = option_small_ns() > 0 ? option_small_ns() : wgs <= 64 ? 4 : wgs <= 128 ? 2 : 1;
     const size_t lds = small_need_bytes<T>(d, vec_ok);
-    return vec_ok ? dispatch_value_small_group<T, VECF, TV>(p, lds, stream) : dispatch_value_small_group<T, 1, TV>(p, lds, stream);
+    return vec_ok ? dispatch_value_small_group<T, VECF, TV, TS>(p, lds, stream) : dispatch_value_small_group<T, 1, TV, TS>(p, lds, stream);
 }
 
 // the sorted pipeline's record format: 5 level bits, 23-bit biased pixel index, 32-bit slot offsets
@@ -703,7 +704,7 @@ template <typename T, typename TV = T> inline bool value_ws_ok(const Params &p, 
     return sorted || small_path_chosen<T>(d) || (option_value_path() != 2 && small_fits<T>(d));
 }
 
-template <typename T, typename TV = T>
+template <typename T, typename TV = T, typename TS = T>
 inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspace_bytes, hipStream_t stream)
 {
     using A = typename Traits<T>::acc;
@@ -716,9 +717,9 @@ inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspac
     // (no workspace: the single-launch kernel serves whatever fits its LDS)
     int rc;
     if (small_path) {
-        rc = run_value_small<T, TV>(p, d, stream);
+        rc = run_value_small<T, TV, TS>(p, d, stream);
     } else if (sorted) {
-        rc = run_value_sorted<T, TV>(p, d, workspace, stream);
+        rc = run_value_sorted<T, TV, TS>(p, d, workspace, stream);
     } else if (!fits) {
         set_error("grad_value: this shape is beyond the sorted pipeline's record format (L <= %d, I < 2^22, "
                   "16*D*sizeof(acc) < 2^24, I*4*D*sizeof(acc) < 2^31) and too large for the single-launch kernel",
@@ -847,7 +848,7 @@ inline size_t fused_mat_bytes(int64_t B, int64_t H, int64_t Q, int64_t L, int64_
     return align_up((size_t)(B * Q * H * L * P) * 3 * elem, 256);
 }
 
-template <typename T, typename TV = T>
+template <typename T, typename TV = T, typename TS = T>
 int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes, const void *proj, const void *ref,
                   void *grad_value, void *grad_proj, void *grad_ref_part, int64_t B, int64_t I, int64_t H, int64_t D,
                   int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode, int align_corners,
@@ -870,7 +871,7 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
     if (B * Q * H * D == 0 || L * P == 0 || I == 0) {  // no sample touches anything: all gradients are zero
         hipError_t e = hipSuccess;
         if (gv_bytes && grad_value) e = hipMemsetAsync(grad_value, 0, gv_bytes, stream);
-        if (e == hipSuccess && ns) e = hipMemsetAsync(grad_proj, 0, ns * 3 * sizeof(T), stream);
+        if (e == hipSuccess && ns) e = hipMemsetAsync(grad_proj, 0, ns * 3 * sizeof(TS), stream);
         if (e == hipSuccess && B * Q * H) e = hipMemsetAsync(grad_ref_part, 0, (size_t)(B * Q * H) * ref_dim * sizeof(T), stream);
         return (int)e;
     }
@@ -881,8 +882,8 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
         set_error("projection too large for 32-bit sample offsets");
         return MSDA_ERR_TOO_LARGE;
     }
-    if (!aligned_to(value, sizeof(TV)) || !aligned_to(grad_out, sizeof(T)) || !aligned_to(grad_value, sizeof(TV)) ||
-        !aligned_to(proj, sizeof(T)) || !aligned_to(grad_proj, sizeof(T)) || !aligned_to(ref, sizeof(T)) ||
+    if (!aligned_to(value, sizeof(TV)) || !aligned_to(grad_out, sizeof(TS)) || !aligned_to(grad_value, sizeof(TV)) ||
+        !aligned_to(proj, sizeof(TS)) || !aligned_to(grad_proj, sizeof(TS)) || !aligned_to(ref, sizeof(T)) ||
         !aligned_to(grad_ref_part, sizeof(T)) || !aligned_to(shapes, 8)) {
         set_error("misaligned buffer");
         return MSDA_ERR_MISALIGNED;
@@ -911,7 +912,7 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
         p.mat_attn = ws + ns * 2 * sizeof(T);
     }
     const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
-    rc = dispatch_gather<T, 3, TV>(p, vec_ok, stream);
+    rc = dispatch_gather<T, 3, TV, TS>(p, vec_ok, stream);
     if (rc) {
         if (rc > 0) set_error("fused backward launch failed: %s", hipGetErrorString((hipError_t)rc));
         return rc;
@@ -921,7 +922,7 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
         p.attn = p.mat_attn;
         p.ref = nullptr;
         p.ref_dim = 0;
-        rc = run_value<T, TV>(p, d, ws + mat, workspace_bytes - (int64_t)mat, stream);
+        rc = run_value<T, TV, TS>(p, d, ws + mat, workspace_bytes - (int64_t)mat, stream);
     }
     return rc;
 }
@@ -965,6 +966,29 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
         return msda::run_bwd_fused<T, TV>(grad_out, value, shapes, proj, ref, grad_value, grad_proj,                \
                                       grad_ref_partial, B, I, H, D, Q, L, P, ref_dim, padding_mode,              \
                                       align_corners, max_level_cells, workspace, workspace_bytes, stream);       \
+    }
+
+// the module's kernels with a separate 16-bit STORAGE type TS for value, projection, out and their gradients next to
+// fp32 reference points and fp32 arithmetic (msda_fwd_fused_f32_sbf16 / _sf16): fused entry points only
+#define MSDA_DEFINE_FUSED_STORAGE_ENTRY_POINTS(SUF, T, TS)                                                        \
+    extern "C" int msda_fwd_fused_##SUF(const void *value, const int64_t *shapes, const void *proj,             \
+                                        const void *ref, void *out, int64_t B, int64_t I, int64_t H, int64_t D,  \
+                                        int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,          \
+                                        int align_corners, void *stream)                                         \
+    {                                                                                                            \
+        return msda::run_fwd_fused<T, TS, TS>(value, shapes, proj, ref, out, B, I, H, D, Q, L, P, ref_dim,          \
+                                          padding_mode, align_corners, stream);                                  \
+    }                                                                                                            \
+    extern "C" int msda_bwd_fused_##SUF(const void *grad_out, const void *value, const int64_t *shapes,         \
+                                        const void *proj, const void *ref, void *grad_value, void *grad_proj,   \
+                                        void *grad_ref_partial, int64_t B, int64_t I, int64_t H, int64_t D,      \
+                                        int64_t Q, int64_t L, int64_t P, int ref_dim, int padding_mode,          \
+                                        int align_corners, int64_t max_level_cells, void *workspace,             \
+                                        int64_t workspace_bytes, void *stream)                                   \
+    {                                                                                                            \
+        return msda::run_bwd_fused<T, TS, TS>(grad_out, value, shapes, proj, ref, grad_value, grad_proj,            \
+                                          grad_ref_partial, B, I, H, D, Q, L, P, ref_dim, padding_mode,          \
+                                          align_corners, max_level_cells, workspace, workspace_bytes, stream);   \
     }
 
 // one storage type for every tensor

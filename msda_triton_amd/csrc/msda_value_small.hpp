@@ -44,7 +44,7 @@ inline size_t small_lds_bytes(size_t cells, size_t samples, size_t acc_bytes, si
     return o + 64;
 }
 
-template <typename T, int VEC, int G, typename TV = T>  // TV: storage type of grad_value (see msda_fwd_kernel)
+template <typename T, int VEC, int G, typename TV = T, typename TG = T>  // TV: storage type of grad_value, TG: of grad_out
 __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     constexpr int SMAX = kWave / G;  // lane groups of one wave: their partial rows meet through shuffles
     const int unit = tid / G, j = tid % G;
     const int gbase = tid - j;
-    const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;
-    const uint32_t q_stride = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);
-    const rsrc_t rs_go = make_rsrc(gout, (uint32_t)(((size_t)p.Q * p.H * p.D - (size_t)h * p.D) * sizeof(T)));
+    const TG *gout = static_cast<const TG *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;
+    const uint32_t q_stride = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TG);
+    const rsrc_t rs_go = make_rsrc(gout, (uint32_t)(((size_t)p.Q * p.H * p.D - (size_t)h * p.D) * sizeof(TG)));
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
     const int nbx = (lw + 1) / 2, nby = (lh + 1) / 2;
     const int nblk = min(nbx * nby, p.small_cells / 4 + 2);  // (<= cells / 4; the cap only bites for shapes that disagree with I)
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
         for (int cc = 0; cc < nchan_chunks; ++cc) {
             const int c0 = (cc * G + j) * VEC;
             const bool lane_ok = c0 < p.D;
-            const uint32_t lane_elem = (lane_ok ? (uint32_t)c0 : 0u) * (uint32_t)sizeof(T);
+            const uint32_t lane_elem = (lane_ok ? (uint32_t)c0 : 0u) * (uint32_t)sizeof(TG);
             A acc[4][VEC];  // block pixel i + 2 j'
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -440,15 +440,15 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
 #pragma unroll
                 for (int jj = 0; jj < G; jj += UB) {
                     if (v0 + jj < mine) {  // uniform per group
-                        Pack<T, VEC> g[UB];
+                        Pack<TG, VEC> g[UB];
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
 #pragma unroll
-                            for (int i = 0; i < VEC; ++i) g[u].v[i] = TR::from_acc((A)0);
+                            for (int i = 0; i < VEC; ++i) g[u].v[i] = Traits<TG>::from_acc((A)0);
                             if (v0 + jj + u < mine)  // (uniform inside the group) no record, no load: the workgroup's one CU
                                                      // is bound by its vector-memory path
-                                g[u] = __builtin_bit_cast(Pack<T, VEC>,
-                                                          RawLoad<sizeof(T) * VEC>::load(rs_go, s_q[gbase + jj + u] + lane_elem));
+                                g[u] = __builtin_bit_cast(Pack<TG, VEC>,
+                                                          RawLoad<sizeof(TG) * VEC>::load(rs_go, s_q[gbase + jj + u] + lane_elem));
                         }
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
 #pragma unroll
                             for (int k = 0; k < 4; ++k)
 #pragma unroll
-                                for (int i = 0; i < VEC; ++i) acc[k][i] = fma_t(w.w[k], TR::to_acc(g[u].v[i]), acc[k][i]);
+                                for (int i = 0; i < VEC; ++i) acc[k][i] = fma_t(w.w[k], Traits<TG>::to_acc(g[u].v[i]), acc[k][i]);
                         }
                     }
                 }

@@ -449,7 +449,8 @@ constexpr uint32_t kSegCarry = 2u;  // ... and the cell is the right-hand x-neig
 // VGPRs; asked for four waves per SIMD, 4-lane groups (D = 32 in bf16 / fp16) take 118 without a spill — c3's
 // grad_value group 175.5 -> 171.5 us, same-box A/B — while 8-lane groups and wider spill (c5: no gain), so those keep
 // the compiler's choice.
-template <typename T, int VEC, int G, int GB>
+// TG: storage type of grad_out (the module's 16-bit storage next to fp32 points: msda_bwd_fused_f32_sbf16 / _sf16)
+template <typename T, int VEC, int G, int GB, typename TG = T>
 __global__ __launch_bounds__(GB, (VEC == 8 && G > 4) ? 1 : 4) void msda_value_gather_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
@@ -482,10 +483,10 @@ __global__ __launch_bounds__(GB, (VEC == 8 && G > 4) ? 1 : 4) void msda_value_ga
                                            // LDS is 40 KB, and four workgroups must fit a CU's 160 KB)
 
     const Entry<A> *entries = plane_entries<A>(p, pair);
-    const T *gout = static_cast<const T *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
-    const uint32_t q_stride = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(T);  // bytes; Q*H*D*sizeof < 2^31 is checked on the host
+    const TG *gout = static_cast<const TG *>(p.grad_out) + ((size_t)b * p.Q * p.H + h) * p.D;  // uniform base
+    const uint32_t q_stride = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TG);  // bytes; Q*H*D*sizeof < 2^31 is checked on the host
     // grad_out rows of this plane through a buffer descriptor: scalar base + 32-bit byte offset per lane
-    const rsrc_t rs_go = make_rsrc(gout, (uint32_t)(((size_t)p.Q * p.H * p.D - (size_t)h * p.D) * sizeof(T)));
+    const rsrc_t rs_go = make_rsrc(gout, (uint32_t)(((size_t)p.Q * p.H * p.D - (size_t)h * p.D) * sizeof(TG)));
     const int nchan_chunks = (p.D + G * VEC - 1) / (G * VEC);
 
     // first requests: the window's first batch of records and the record in front of the window (idle groups: the
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(GB, (VEC == 8 && G > 4) ? 1 : 4) void msda_value_ga
     for (int cc = 0; cc < nchan_chunks; ++cc) {
         const int c0 = (cc * G + j) * VEC;
         const bool lane_ok = c0 < p.D;
-        const uint32_t lane_elem = (lane_ok ? (uint32_t)c0 : 0u) * (uint32_t)sizeof(T);
+        const uint32_t lane_elem = (lane_ok ? (uint32_t)c0 : 0u) * (uint32_t)sizeof(TG);
         A acc[4][VEC];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -602,14 +603,14 @@ __global__ __launch_bounds__(GB, (VEC == 8 && G > 4) ? 1 : 4) void msda_value_ga
 #pragma unroll
             for (int jj = 0; jj < G; jj += UB) {  // UB row loads issued back to back, then consumed
                 if (v0 + jj < count) {            // uniform per group; G == UB: always true
-                    Pack<T, VEC> g[UB];
+                    Pack<TG, VEC> g[UB];
                     uint32_t qs[UB], fl[UB];
                     lds_read_u32s<UB>(&s_q[gbase + jj], qs);   // one or two 16-byte LDS reads each
                     lds_read_u32s<UB>(&s_flag[gbase + jj], fl);
 #pragma unroll
                     for (int u = 0; u < UB; ++u)
-                        g[u] = __builtin_bit_cast(Pack<T, VEC>,
-                                                  RawLoad<sizeof(T) * VEC>::load(rs_go, qs[u] + lane_elem));
+                        g[u] = __builtin_bit_cast(Pack<TG, VEC>,
+                                                  RawLoad<sizeof(TG) * VEC>::load(rs_go, qs[u] + lane_elem));
                     __builtin_amdgcn_sched_barrier(0);  // keep the UB loads together: hipcc otherwise serialises some
 #pragma unroll
                     for (int u = 0; u < UB; ++u) {
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(GB, (VEC == 8 && G > 4) ? 1 : 4) void msda_value_ga
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
 #pragma unroll
-                            for (int v = 0; v < VEC; ++v) acc[k][v] = fma_t(w.w[k], TR::to_acc(g[u].v[v]), acc[k][v]);
+                            for (int v = 0; v < VEC; ++v) acc[k][v] = fma_t(w.w[k], Traits<TG>::to_acc(g[u].v[v]), acc[k][v]);
                     }
                 }
             }

@@ -56,6 +56,25 @@ def _suffix_for(img_dtype: torch.dtype, compute_dtype: torch.dtype) -> str:
     return _SUFFIX[img_dtype] if img_dtype == compute_dtype else _MIXED_SUFFIX[img_dtype]
 
 
+# the module's 16-bit storage (fused entry points only): value and projection in one 16-bit dtype, reference points fp32
+_FUSED_STORAGE_SUFFIX = {torch.bfloat16: "f32_sbf16", torch.float16: "f32_sf16"}
+
+
+def fused_storage_dtypes(img_dtype, proj_dtype, ref_dtype) -> bool:
+    """16-bit value pyramid and projection next to fp32 reference points: what autocast's GEMMs hand the module core.
+    The kernels compute in fp32 and return / differentiate in the 16-bit dtype (``msda_*_fused_f32_sbf16`` / ``_sf16``)."""
+    return img_dtype == proj_dtype and proj_dtype in _FUSED_STORAGE_SUFFIX and ref_dtype == torch.float32
+
+
+def _fused_suffix_for(img_dtype, proj_dtype, ref_dtype) -> str:
+    if fused_storage_dtypes(img_dtype, proj_dtype, ref_dtype):
+        return _FUSED_STORAGE_SUFFIX[proj_dtype]
+    if ref_dtype != proj_dtype:
+        raise ValueError(f"`proj` and `reference_points` should share one dtype (or `img` and `proj` be float16 / bfloat16 "
+                         f"next to float32 `reference_points`), but got {proj_dtype} and {ref_dtype}.")
+    return _suffix_for(img_dtype, proj_dtype)
+
+
 def _padding_code(padding_mode: str) -> int:
     try:
         return _lib.PADDING_MODES[padding_mode]
@@ -468,9 +487,7 @@ def msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, al
     _check_devices(img, img_shapes, proj, reference_points)
     pad = _padding_code(padding_mode)
     cdt = proj.dtype
-    if reference_points.dtype != cdt:
-        raise ValueError(f"`proj` and `reference_points` should share one dtype, but got {cdt} and {reference_points.dtype}.")
-    suf = _suffix_for(img.dtype, cdt)
+    suf = _fused_suffix_for(img.dtype, cdt, reference_points.dtype)
     img, proj, reference_points = img.contiguous(), proj.contiguous(), reference_points.contiguous()
     shapes = _shapes_i64(img_shapes)
     out = torch.empty((B, Q, H, D), dtype=cdt, device=img.device)
@@ -501,7 +518,8 @@ def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, paddin
     _check_devices(img, img_shapes, proj, reference_points, out_grad)
     pad = _padding_code(padding_mode)
     cdt = proj.dtype
-    suf = _suffix_for(img.dtype, cdt)
+    suf = _fused_suffix_for(img.dtype, cdt, reference_points.dtype)
+    storage = fused_storage_dtypes(img.dtype, cdt, reference_points.dtype)  # (arithmetic and reference points fp32)
     img, proj, reference_points = img.contiguous(), proj.contiguous(), reference_points.contiguous()
     out_grad = out_grad.contiguous()
     if out_grad.dtype != cdt:
@@ -510,14 +528,14 @@ def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, paddin
     kw = dict(dtype=cdt, device=img.device)
     g_img = torch.empty((B, I, H, D), dtype=img.dtype, device=img.device) if need_img else None
     g_proj = torch.empty((B, Q, H, L, P, 3), **kw)
-    g_ref_part = torch.empty((B, Q, H, ref_dim), **kw)
+    g_ref_part = torch.empty((B, Q, H, ref_dim), dtype=reference_points.dtype, device=img.device)
     lib = _lib.load()
     fn = getattr(lib, f"msda_bwd_fused_{suf}")
     ws, ws_bytes = None, 0
     level_cells = int(level_cells)  # the level-size bound (level_cells_of), an argument of the size query and the launch
     if need_img:  # (a frozen value pyramid needs no workspace at all — ADVICE r04)
-        ws_bytes = int(lib.msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, proj.element_size(), img.element_size(),
-                                                          level_cells))
+        ws_bytes = int(lib.msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, 4 if storage else proj.element_size(),
+                                                          img.element_size(), level_cells))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=img.device)
 
     def call():
@@ -547,8 +565,9 @@ class _HipFusedModuleCoreFunction(Function):
         out = msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, align_corners)
         ctx.fused = out is not None  # the backward has the same L*P limit: do not ask twice
         if out is None:
-            pts, att = module_sampling_inputs(proj, img_shapes, reference_points)
-            out = msda_hip_fwd(img, img_shapes, pts, att, padding_mode, align_corners)
+            # (16-bit storage next to fp32 reference points: the prologue in fp32, the mixed-storage operator)
+            pts, att = module_sampling_inputs(proj.to(reference_points.dtype), img_shapes, reference_points)
+            out = msda_hip_fwd(img, img_shapes, pts, att, padding_mode, align_corners).to(proj.dtype)
         ctx.save_for_backward(img, img_shapes, proj, reference_points)
         ctx.padding_mode, ctx.align_corners = padding_mode, align_corners
         return out
@@ -566,9 +585,10 @@ class _HipFusedModuleCoreFunction(Function):
                 g_img, g_proj, g_ref = res
                 return g_img, None, (g_proj if need_proj else None), (g_ref if need_ref else None), None, None, None
         with torch.enable_grad():
-            proj_ = proj.detach().requires_grad_(need_proj)
+            proj_ = proj.detach().to(reference_points.dtype).requires_grad_(need_proj)
             ref_ = reference_points.detach().requires_grad_(need_ref)
             pts, att = module_sampling_inputs(proj_, img_shapes, ref_)
+        out_grad = out_grad.to(pts.dtype)
         need_sample = need_proj or need_ref
         g_img, g_pts, g_att = msda_hip_bwd(out_grad, img, img_shapes, pts.detach(), att.detach(), ctx.padding_mode,
                                            ctx.align_corners, (need_img, need_sample, need_sample),
@@ -578,7 +598,7 @@ class _HipFusedModuleCoreFunction(Function):
             wrt = [t for t, n in ((proj_, need_proj), (ref_, need_ref)) if n]
             grads = list(torch.autograd.grad([pts, att], wrt, [g_pts, g_att], allow_unused=True))
             if need_proj:
-                g_proj = grads.pop(0)
+                g_proj = grads.pop(0).to(proj.dtype)
             if need_ref:
                 g_ref = grads.pop(0)
         return g_img, None, g_proj, g_ref, None, None, None
@@ -599,6 +619,13 @@ def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, ali
     if img.device.type == "cuda" and floating and _autocast_on() and not torch.compiler.is_compiling():
         # under autocast the op computes in fp32 whatever the projections' dtypes are (custom_fwd casts every floating
         # input, frontend.py:111): mixed bf16 projections / fp32 reference points still take the fused kernels
+        _padding_code(padding_mode)
+        return _HipFusedModuleCoreFunction.apply(img, img_shapes, proj, reference_points, padding_mode,
+                                                 bool(align_corners), level_cells)
+    if img.device.type == "cuda" and floating and fused_storage_dtypes(img.dtype, proj.dtype, reference_points.dtype) and \
+            not torch.compiler.is_compiling():
+        # 16-bit value pyramid and projection (what autocast's GEMMs produce) next to fp32 reference points: fp32
+        # arithmetic, 16-bit result and gradients — no fp32 copy of either tensor (msda_*_fused_f32_sbf16 / _sf16)
         _padding_code(padding_mode)
         return _HipFusedModuleCoreFunction.apply(img, img_shapes, proj, reference_points, padding_mode,
                                                  bool(align_corners), level_cells)

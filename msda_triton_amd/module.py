@@ -91,7 +91,16 @@ class MultiscaleDeformableAttention(nn.Module):
         # and the offset -> sampling-point math run inside the attention kernel's prologue
         proj = projection(self.query_input_proj, queries).reshape(B, N, H, L, P, 3)
         value = projection(self.img_input_proj, img).reshape(B, I, H, self.hidden_dim // H)
-        if self.value_dtype is not None and value.device.type == "cuda":
+        if value.device.type == "cuda" and proj.dtype in (torch.bfloat16, torch.float16) and \
+                self.value_dtype in (None, proj.dtype) and value.dtype == proj.dtype and not torch.compiler.is_compiling():
+            # 16-bit projections (autocast's GEMMs, or 16-bit parameters) with fp32 reference points: the kernels read
+            # and write the 16-bit tensors as they are and compute in fp32 — what the reference's core does under
+            # autocast (it casts every input to fp32, frontend.py:111) without the fp32 copies of value, projection,
+            # result and their gradients; rounding happens at the same places (the GEMMs' outputs / inputs)
+            with torch.autocast("cuda", enabled=False):
+                attended = fused_module_core(value, img_shapes, proj, reference_points.float(), self.padding_mode,
+                                             self.align_corners, level_shapes)
+        elif self.value_dtype is not None and value.device.type == "cuda":
             # 16-bit value pyramid next to fp32 sampling inputs: the mixed-storage kernels read it as it is (no fp32
             # copy, which is what autocast's cast_inputs would make), so the call sits outside autocast
             value = value.to(self.value_dtype)  # nothing to do when autocast already produced this dtype

@@ -16,11 +16,15 @@ def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "msda_hip.h")).read()
     names = set(re.findall(r"MSDA_API\s+(?:const\s+)?\w+\s*\*?\s*(msda_\w+)\s*\(", text))
     names = {n for n in names if "##" not in n}
-    stems = re.findall(r"MSDA_API\s+int\s+(msda_\w+_)##SUF\s*\(", text)   # the per-dtype entry points of MSDA_DECLARE
-    assert len(stems) >= 4, stems
-    for suf in re.findall(r"MSDA_DECLARE\((\w+)\)", text):
-        if suf != "SUF":
-            names |= {stem + suf for stem in stems}
+    # the per-dtype entry points: every `#define MSDA_DECLARE...(SUF)` macro declares its stems for each suffix it is used with
+    macros = re.findall(r"#define\s+(MSDA_DECLARE\w*)\(SUF\)((?:.*\\\n)*.*\n)", text)
+    assert len(macros) == 2, [m for m, _ in macros]
+    for macro, body in macros:
+        stems = re.findall(r"MSDA_API\s+int\s+(msda_\w+_)##SUF\s*\(", body)
+        assert len(stems) >= 2, (macro, stems)
+        for suf in re.findall(macro + r"\((\w+)\)", text):
+            if suf != "SUF":
+                names |= {stem + suf for stem in stems}
     return names
 
 
