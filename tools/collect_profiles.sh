@@ -11,7 +11,7 @@ for W in "${@:-c2_q10k}"; do
   B="python bench.py --workload $W --steps $STEPS --warmup 3 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton --opt overlap=0"
   rm -rf gpurun_out/${TAG}_${W}_stats gpurun_out/${TAG}_${W}_fetch gpurun_out/${TAG}_${W}_write
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_${W}_stats -- $B > gpurun_out/${TAG}_${W}_stats.log 2>&1 &&
-  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_${W}_fetch -- python bench.py --workload $W --steps 3 --warmup 2 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton > gpurun_out/${TAG}_${W}_fetch.log 2>&1 &&
-  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_${W}_write -- python bench.py --workload $W --steps 3 --warmup 2 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton > gpurun_out/${TAG}_${W}_write.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_${W}_fetch -- python bench.py --workload $W --steps 3 --warmup 2 --spin-up-ms 0 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton > gpurun_out/${TAG}_${W}_fetch.log 2>&1 &&
+  timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_${W}_write -- python bench.py --workload $W --steps 3 --warmup 2 --spin-up-ms 0 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton > gpurun_out/${TAG}_${W}_write.log 2>&1
   echo "$W done: $(tail -c 300 gpurun_out/${TAG}_${W}_stats.log | grep -o '"fwd_bwd_ms": [0-9.]*')"
 done
