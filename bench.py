@@ -780,6 +780,9 @@ def main():
         single = {}
         try:
             _lib.set_option("profile", 1)
+            for _ in range(args.warmup):  # (the first profiled launches create their event pairs: not measured)
+                step()
+            torch.cuda.synchronize()
             _lib.profile_read()
             timed(step, args.steps, collect=False)
             single = _lib.profile_read()

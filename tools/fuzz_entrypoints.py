@@ -5,6 +5,8 @@ oracle):
           points' gradient) vs module_sampling_inputs + multiscale_deformable_attention, fp64 at 1e-9 / fp32 at 1e-4
   mixed   a bf16 / fp16 value pyramid next to fp32 sampling inputs vs the fp32 operator on the rounded pyramid
   half    the whole operator in fp16 / bf16 vs the fp32 operator on the rounded inputs (loose: 2e-2 relative)
+  storage the module kernels with 16-bit storage (value, projection, result and their gradients in bf16 / fp16, fp32
+          reference points: msda_*_fused_f32_sbf16 / _sf16) vs the fp32 fused kernels on the rounded inputs
 Usage: fuzz_entrypoints.py [seconds] [first_seed]; one line per failure, a summary, exit status 1 on failure."""
 import json
 import os
@@ -40,7 +42,7 @@ seed = seed0
 while time.time() - t0 < budget:
     rng = np.random.default_rng(91000 + seed)
     g = torch.Generator(device="cpu").manual_seed(91000 + seed)
-    kind = ("fused", "mixed", "half")[seed % 3]
+    kind = ("fused", "mixed", "half", "storage")[seed % 4]
     B, H = int(rng.integers(1, 4)), int(rng.integers(1, 5))
     D = int(rng.choice([8, 16, 24, 32, 40, 64]))
     L, P = int(rng.integers(1, 5)), int(rng.integers(1, 6))
@@ -50,7 +52,8 @@ while time.time() - t0 < budget:
     I = sum(h * w for h, w in levels)
     pm, ac = MODES[int(rng.integers(0, 4))]
     shapes = torch.tensor(levels, dtype=torch.int64, device=dev)
-    opts = {"value_path": int(rng.choice([0, 2, 3])), "small_ns": int(rng.choice([0, 0, 2, 3]))}
+    opts = {"value_path": int(rng.choice([0, 2, 3])), "small_ns": int(rng.choice([0, 0, 2, 3])),
+            "lds_levels": int(rng.choice([1, 1, 2, 0])), "unit_fwd": int(rng.choice([1, 1, 0, 2]))}
     desc = dict(seed=seed, kind=kind, B=B, Q=Q, H=H, D=D, levels=levels, P=P, pm=pm, ac=ac, **opts)
     try:
         for k, v in opts.items():
@@ -78,6 +81,30 @@ while time.time() - t0 < budget:
                 # fp32: a sample whose pixel coordinate rounds across a grid line differently in the two routes has a
                 # different grad_proj / grad_ref there (the kink the other fp32 tests mask): allow 1 % of entries
                 close(a, b, atol, rtol, name, frac_ok=1.0 if dt == torch.float64 or name in ("out", "grad_value") else 0.99)
+        elif kind == "storage":
+            sdt = torch.bfloat16 if rng.integers(0, 2) else torch.float16
+            coords = int(rng.choice([2, 4]))
+            desc.update(storage=str(sdt), coords=coords)
+            value = torch.randn(B, I, H, D, generator=g).to(sdt)
+            proj = (torch.randn(B, Q, H, L, P, 3, generator=g) * float(rng.choice([0.5, 1.5, 4.0]))).to(sdt)
+            ref = torch.rand(B, Q, coords, generator=g)
+            gout = torch.rand(B, Q, H, D, generator=g).to(sdt)
+            res = []
+            for low in (True, False):
+                v, pr, go = ((t if low else t.float()).clone().to(dev) for t in (value, proj, gout))
+                v.requires_grad_(True), pr.requires_grad_(True)
+                rf = ref.clone().to(dev).requires_grad_(True)
+                out = fused_module_core(v, shapes, pr, rf, pm, ac)
+                assert out.dtype == (sdt if low else torch.float32), out.dtype
+                out.backward(go)
+                res.append((out.detach().float(), v.grad.float(), pr.grad.float(), rf.grad.float()))
+            eps = 8e-3 if sdt == torch.bfloat16 else 1e-3
+            for name, a, b in zip(("out", "grad_value", "grad_proj", "grad_ref"), res[0], res[1]):
+                scale = float(b.abs().max()) + 1e-6
+                if name == "grad_ref":  # fp32 sums of the same numbers
+                    close(a, b, 2e-4 * scale, 2e-3, name, frac_ok=0.99)
+                else:  # the fp32 result rounded to the storage type
+                    close(a, b, 2 * eps * scale * (2.0 ** -3), 2 * eps, name, frac_ok=0.999)
         else:
             sdt = torch.bfloat16 if rng.integers(0, 2) else torch.float16
             desc.update(storage=str(sdt))
@@ -107,7 +134,7 @@ while time.time() - t0 < budget:
         print("FAIL", json.dumps(desc), "::", str(e).strip().splitlines()[0][:300], flush=True)
     finally:
         for k in opts:
-            _lib.set_option(k, 0)
+            _lib.set_option(k, {"lds_levels": 1, "unit_fwd": 1}.get(k, 0))
     n += 1
     seen[kind] = seen.get(kind, 0) + 1
     seed += 1

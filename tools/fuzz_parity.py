@@ -47,9 +47,15 @@ def make_case(seed):
         c["loc"][m] = (hot + rng.normal(0, 0.002, size=(int(m.sum()), 2))).astype(c["loc"].dtype)
     td = torch.float64 if f64 else torch.float32
     opts = {"value_path": int(rng.choice([0, 2, 3])), "place_path": int(rng.choice([0, 0, 1])),
-            "q_round": int(rng.choice([0, 0, 0, max(1, Q // 3)])), "small_ns": int(rng.choice([0, 0, 1, 2, 3, 5]))}
+            "q_round": int(rng.choice([0, 0, 0, max(1, Q // 3)])), "small_ns": int(rng.choice([0, 0, 1, 2, 3, 5])),
+            # round 5: the LDS-served-level variants of the gather kernels (2: whenever a row fits) and the one-wave-per-unit
+            # forward (2: every problem it can serve)
+            "lds_levels": int(rng.choice([1, 1, 2, 2, 0])), "unit_fwd": int(rng.choice([1, 1, 0, 2]))}
     desc = dict(seed=seed, B=B, Q=Q, H=H, D=D, levels=levels, P=P, range=(lo, hi), pm=pm, ac=ac, f64=f64, **opts)
     return c, pm, ac, td, opts, desc, kind
+
+
+OPTION_DEFAULTS = {"lds_levels": 1, "unit_fwd": 1}
 
 
 def run_case(c, pm, ac, td, opts):
@@ -59,7 +65,7 @@ def run_case(c, pm, ac, td, opts):
         tp.check_against_oracle(msda_oracle, c, pm, ac, tp.FWD_TOL[td], tp.BWD_TOL[td])
     finally:
         for k in opts:
-            _lib.set_option(k, 0)
+            _lib.set_option(k, OPTION_DEFAULTS.get(k, 0))
 
 
 msda_oracle.build()
