@@ -205,7 +205,7 @@ template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(c
     return pl;
 }
 
-template <typename T, int VEC, int G, int MODE, typename TV> inline int launch_gather_lds(Params &p, const LdsLevelsPlan &pl, hipStream_t stream)
+template <typename T, int VEC, int G, int MODE, typename TV, typename TS = T> inline int launch_gather_lds(Params &p, const LdsLevelsPlan &pl, hipStream_t stream)
 {
     // MODE as in launch_gather: the forward and sample-gradient kernels, plain (0, 1) and with the module prologue (2, 3)
     p.sc = pl.sc;
@@ -221,11 +221,11 @@ template <typename T, int VEC, int G, int MODE, typename TV> inline int launch_g
     static std::atomic<uint64_t> big_lds_done{0};
     const ProfileScope prof(MODE == 0 || MODE == 2 ? "msda_fwd_kernel" : "msda_bwd_sample_kernel", stream);
     if constexpr (MODE == 0 || MODE == 2) {
-        auto kernel = msda_fwd_kernel<T, VEC, G, MODE == 2, TV, kBlockLds, true>;
+        auto kernel = msda_fwd_kernel<T, VEC, G, MODE == 2, TV, kBlockLds, true, std::conditional_t<MODE == 2, TS, T>>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlockLds), pl.lds, stream, p);
     } else {
-        auto kernel = msda_bwd_sample_kernel<T, VEC, G, MODE == 3, TV, kBlockLds, true>;
+        auto kernel = msda_bwd_sample_kernel<T, VEC, G, MODE == 3, TV, kBlockLds, true, std::conditional_t<MODE == 3, TS, T>>;
         allow_big_lds(kernel, big_lds_done);
         hipLaunchKernelGGL(kernel, grid, dim3(kBlockLds), pl.lds, stream, p);
     }
@@ -255,12 +255,14 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, typename TS = T
             return (int)hipGetLastError();
         }
     }
-    // ... and the module's kernels (fused prologue).  fp32 rows only there too: over a bf16 pyramid (64-byte rows) the
-    // module's step at the c2 shape went 1.09 -> 1.31 ms with the levels in LDS
-    if constexpr (sizeof(T) == 4 && VEC == 4 && sizeof(TV) == 4 &&
+    // ... and the module's kernels (fused prologue).  (An early version of the variant had lost over a bf16 pyramid — the
+    // module's step 1.09 -> 1.31 ms; with the waves' dynamic slices it wins there as well: fused forward 116-126 -> 75-79 us,
+    // fused sample gradients 124-135 -> 115-123 at the c2 shape.)
+    if constexpr (sizeof(T) == 4 && VEC == 4 &&
                   (((MODE == 0 || MODE == 2) && G <= 16) || ((MODE == 1 || MODE == 3) && (G == 4 || G == 8)))) {
+        // (fp32 arithmetic; the rows may be 16-bit — the mixed-storage and module-storage kernels: 8-byte pieces, half the LDS)
         const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, MODE == 3, MODE == 1);
-        if (pl.use && (MODE < 2 || pl.sc == p.LP)) return launch_gather_lds<T, VEC, G, MODE, TV>(p, pl, stream);
+        if (pl.use && (MODE < 2 || pl.sc == p.LP)) return launch_gather_lds<T, VEC, G, MODE, TV, TS>(p, pl, stream);
     }
     size_t lds;
     plan_gather(NU, p.LP, sizeof(A), p.sc, lds, MODE == 3);

@@ -1,6 +1,7 @@
 """dev tool: per-kernel times (the library's own event pairs) of the module CORE — fused_module_core forward + backward at
 the c2 module shape — for option strings alternated inside one process, next to the unfused operator on the same
-inputs:   python tools/fused_core_bench.py [value=bf16] [ref4] [--] opt=val[,opt=val] ...      ("-" = defaults)"""
+inputs:   python tools/fused_core_bench.py [value=bf16 | storage] [ref4] [--] opt=val[,opt=val] ...      ("-" = defaults;
+"storage": value, projection and grad_out in bf16 next to fp32 reference points, the msda_*_fused_f32_sbf16 kernels)"""
 import os
 import sys
 
@@ -12,24 +13,26 @@ from msda_triton_amd.functional import fused_module_core, module_sampling_inputs
 
 dev = torch.device("cuda", 0)
 args = [a for a in sys.argv[1:] if a != "--"]
-vdt = torch.bfloat16 if "value=bf16" in args else torch.float32
+storage = "storage" in args
+vdt = torch.bfloat16 if ("value=bf16" in args or storage) else torch.float32
 rd = 4 if "ref4" in args else 2
 opts = [a for a in args if a == "-" or ("=" in a and not a.startswith("value="))] or ["-"]
 wl = synth.WORKLOADS["c2_q10k"]
 torch.manual_seed(0)
 shapes = torch.tensor(wl.levels, device=dev)
 value = torch.randn(wl.B, wl.I, wl.H, wl.D, device=dev).to(vdt).requires_grad_()
-proj = torch.randn(wl.B, wl.Q, wl.H, wl.L, wl.P, 3, device=dev, requires_grad=True)
+proj = torch.randn(wl.B, wl.Q, wl.H, wl.L, wl.P, 3, device=dev).to(vdt if storage else torch.float32).requires_grad_()
 ref = torch.rand(wl.B, wl.Q, rd, device=dev)
 go = torch.randn(wl.B, wl.Q, wl.H, wl.D, device=dev)
+go_f = go.to(vdt) if storage else go
 with torch.no_grad():
-    pts, att = module_sampling_inputs(proj, shapes, ref)
+    pts, att = module_sampling_inputs(proj.float(), shapes, ref)
 pts, att = pts.detach().requires_grad_(), att.detach().requires_grad_()
 
 
 def fused():
     out = fused_module_core(value, shapes, proj, ref, wl.padding_mode, wl.align_corners)
-    out.backward(go)
+    out.backward(go_f)
     value.grad = proj.grad = None
 
 

@@ -1,6 +1,7 @@
 """dev tool: N training steps of the MultiscaleDeformableAttention module at the c2 shape (B=4, Q=10 000, emb = hidden =
 256, H=8, L=4, P=4) under bf16 autocast — run it under rocprofv3 --kernel-trace --stats to list every kernel of the step
-(tools/prof_module_step.sh), or alone for the step time.   python tools/module_step.py [fp32|bf16] [value_dtype=bf16] [steps]"""
+(tools/prof_module_step.sh), or alone for the step time (after 200 ms of untimed steps: a GPU that has just idled is 6-10 %
+slower).   python tools/module_step.py [fp32|bf16] [value_dtype=bf16] [steps] [opt:key=int ...]"""
 import os
 import sys
 import time
@@ -32,9 +33,20 @@ def step():
     img.grad = q.grad = None
 
 
+from msda_triton_amd import _lib  # noqa: E402
+
+for a in sys.argv[1:]:
+    if a.startswith("opt:"):
+        k, v = a[4:].split("=")
+        _lib.set_option(k, int(v))
 for _ in range(8):
     step()
 torch.cuda.synchronize()
+t_spin = time.perf_counter()
+while time.perf_counter() - t_spin < 0.2:
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
     step()

@@ -14,7 +14,7 @@ for f in glob.glob('gpurun_out/prof_mstep/*/*kernel_stats.csv'):
         nm = nm.split('msda::')[1].split('(')[0] if 'msda::' in nm else nm[:110]
         rows.append((float(r['TotalDurationNs']), int(r['Calls']), float(r['AverageNs']), nm))
 rows.sort(reverse=True)
-steps = 46.0  # 8 warm-up + 38 timed steps of tools/module_step.py
+steps = float(max([c for _, c, _, nm in rows if 'msda_fwd_kernel' in nm or 'msda_fwd_unit_kernel' in nm] or [46]))  # one forward per step
 tot = sum(r[0] for r in rows)
 print("kernel,calls_per_step,avg_us,us_per_step,share")
 for t, c, a, nm in rows:
