@@ -170,19 +170,19 @@ struct LdsLevelsPlan {
     size_t lds;
     int lev_bytes;
 };
-template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(const Params &p, bool aux, bool stage = false)
+// (G lanes per unit, accumulators of acc_size bytes, rows of D * row_elem_size bytes)
+inline LdsLevelsPlan lds_levels_plan_rt(const Params &p, int G, size_t acc_size, size_t row_elem_size, bool aux, bool stage)
 {
-    using A = typename Traits<T>::acc;
-    constexpr int NU = kBlockLds / G;
+    const int NU = kBlockLds / G;
     LdsLevelsPlan pl{};
     size_t rec_lds;
-    plan_gather(NU, p.LP, sizeof(A), pl.sc, rec_lds, aux, aux ? (size_t)100 * 1024 : kRecordLdsBudgetLds);
+    plan_gather(NU, p.LP, acc_size, pl.sc, rec_lds, aux, aux ? (size_t)100 * 1024 : kRecordLdsBudgetLds);
     if (pl.sc < p.LP && pl.sc > G) {  // several trips: whole exchange batches of the sample-gradient kernel per trip
         pl.sc = pl.sc / G * G;
-        rec_lds = kGatherLdsFixed + (size_t)NU * (pl.sc + 1) * (16 + (aux ? 7 : 4) * sizeof(A));
+        rec_lds = kGatherLdsFixed + (size_t)NU * (pl.sc + 1) * (16 + (aux ? 7 : 4) * acc_size);
     }
     if (stage) rec_lds += (size_t)(kBlockLds / kWave) * kStageWaveBytes;  // the waves' next-slice staging areas (dma_dword)
-    const size_t lev_base = (rec_lds + 127) / 128 * 128, row = (size_t)p.D * sizeof(TV);
+    const size_t lev_base = (rec_lds + 127) / 128 * 128, row = (size_t)p.D * row_elem_size;
     const long long room = (long long)kMaxDynLds - (long long)lev_base - (long long)((row + 15) / 16 * 16);
     pl.nqc = (p.Q + NU - 1) / NU;
     const int npairs = p.B * p.H, ncu = device_cu_count();
@@ -203,6 +203,10 @@ template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(c
     const bool pays = wgs * 10 >= rounds * ncu * 8 && pl.lev_bytes >= (int)(64 * row);
     pl.use = opt == 2 ? pl.lev_bytes >= (int)row : opt == 1 && pays;
     return pl;
+}
+template <typename T, int G, typename TV> inline LdsLevelsPlan lds_levels_plan(const Params &p, bool aux, bool stage = false)
+{
+    return lds_levels_plan_rt(p, G, sizeof(typename Traits<T>::acc), sizeof(TV), aux, stage);
 }
 
 template <typename T, int VEC, int G, int MODE, typename TV, typename TS = T> inline int launch_gather_lds(Params &p, const LdsLevelsPlan &pl, hipStream_t stream)
@@ -258,7 +262,7 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, typename TS = T
     // ... and the module's kernels (fused prologue).  (An early version of the variant had lost over a bf16 pyramid — the
     // module's step 1.09 -> 1.31 ms; with the waves' dynamic slices it wins there as well: fused forward 116-126 -> 75-79 us,
     // fused sample gradients 124-135 -> 115-123 at the c2 shape.)
-    if constexpr (sizeof(T) == 4 && VEC == 4 &&
+    if constexpr (VEC == 4 && sizeof(A) == 4 && (sizeof(T) == 4 || MODE == 0) &&
                   (((MODE == 0 || MODE == 2) && G <= 16) || ((MODE == 1 || MODE == 3) && (G == 4 || G == 8)))) {
         // (fp32 arithmetic; the rows may be 16-bit — the mixed-storage and module-storage kernels: 8-byte pieces, half the LDS)
         const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, MODE == 3, MODE == 1);
@@ -318,6 +322,20 @@ template <typename T, int VEC, int MODE, typename TV = T, typename TS = T> inlin
 template <typename T, int MODE, typename TV = T, typename TS = T> inline int dispatch_gather(Params &p, bool vec_ok, hipStream_t stream)
 {
     constexpr int VECF = 16 / sizeof(T);  // channels per lane (mixed storage: the 16-bit value rows load as 8-byte pieces)
+    // the 16-bit operators' forward: when the LDS-served-level variant would be taken, as units of 8-byte pieces (twice the
+    // lanes per row — 128 units per 1024-thread workgroup, whose records leave room for the levels; bit-identical results:
+    // a channel's sum does not depend on the lane that holds it): c3 forward 81 -> 75.5 us, encoder-local points 72 -> 66
+    if constexpr (MODE == 0 && sizeof(T) == 2 && sizeof(TV) == 2 && sizeof(typename Traits<T>::acc) == 4) {
+        // (64-byte rows, all samples of a unit in one trip: at c5 — 128-byte rows, L * P = 40 — the variant loses, 2.92 -> 3.21 ms)
+        if (vec_ok && (p.D % 4) == 0 && p.D <= 32) {
+            const int g = pick_group((p.D + 3) / 4);
+            const long long units = (long long)p.B * p.Q * p.H;
+            if (units > kUnitFwdMaxUnits) {
+                const LdsLevelsPlan pl = lds_levels_plan_rt(p, g, 4, sizeof(TV), false, false);
+                if (pl.use && pl.sc == p.LP) return dispatch_group<T, 4, MODE, TV, TS>(p, stream);
+            }
+        }
+    }
     if (vec_ok && (p.D % VECF) == 0) return dispatch_group<T, VECF, MODE, TV, TS>(p, stream);
     return dispatch_group<T, 1, MODE, TV, TS>(p, stream);
 }
