@@ -204,9 +204,10 @@ MSDA_API const char *msda_last_error(void);
  * normal use: the defaults are the fastest measured variants.  Unknown keys return MSDA_ERR_BAD_ARG.  Keys:
  *   "xcd_map"    1 (default): blockIdx -> (batch, head) mapping keeps each (b,h) plane on one XCD's L2
  *                0: plain linear mapping   2: as 1 with the planes of an XCD rotated through the heads
- *   "lds_levels" 1 (default): fp32 problems large enough to amortise it run the forward / sample-gradient kernels with
- *                   the coarsest pyramid levels served from LDS (1024-thread workgroups, one per CU: c2 @ 10k forward
- *                   99 -> 75 us);  0: never;  2: wherever the variant exists (tests)
+ *   "lds_levels" 1 (default): problems large enough to amortise it run the forward / sample-gradient kernels with the
+ *                   coarsest pyramid levels served from LDS (1024-thread workgroups, one per CU: c2 @ 10k forward
+ *                   99 -> 75 us) — fp32 arithmetic over fp32 or 16-bit rows, and the 16-bit operators' forward over
+ *                   64-byte rows; bit-identical results;  0: never;  2: wherever the variant exists (tests)
  *   "unit_fwd"   1 (default): forwards of at most 12 288 (b, q, h) units take the one-wave-per-unit kernel (decoder
  *                   calls: cold-cache forward at Q = 100 12.8 -> 9.3 us);  0: never;  2: wherever it exists (tests)
  *   "value_path" 0 (default): grad_value by the single-launch LDS kernel when a (plane, level) fits one workgroup
