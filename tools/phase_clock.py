@@ -25,17 +25,26 @@ if d is None:
     dt = getattr(torch, wl.dtype)
     d = {k: torch.from_numpy(v).to("cuda:0") if k == "shapes" else torch.from_numpy(v).to("cuda:0", dt) for k, v in h.items()}
 shift = int(os.environ.get("SHIFT", "0"))  # floats: move `value` (and with SHIFT_ALL=1 every tensor) off its allocation's start
-def shifted(t):
-    if not shift or t.dtype == torch.int64:
+def shifted(t, by=None):
+    by = shift if by is None else by
+    if not by or t.dtype == torch.int64:
         return t
-    buf = torch.empty(t.numel() + shift, dtype=t.dtype, device=t.device)
-    v = buf[shift:].view(t.shape)
+    buf = torch.empty(t.numel() + by, dtype=t.dtype, device=t.device)
+    v = buf[by:].view(t.shape)
     v.copy_(t)
     return v
 d["value"] = shifted(d["value"])
 if os.environ.get("SHIFT_ALL"):
     d["loc"], d["attn"] = shifted(d["loc"]), shifted(d["attn"])
-print("value ptr % 1024 =", d["value"].data_ptr() % 1024, " loc ptr % 1024 =", d["loc"].data_ptr() % 1024)
+# LOC_SHIFT / ATTN_SHIFT / OUT_SHIFT (elements): move one of the STREAMED tensors instead — does the slow head follow it?
+d["loc"] = shifted(d["loc"], int(os.environ.get("LOC_SHIFT", "0")))
+d["attn"] = shifted(d["attn"], int(os.environ.get("ATTN_SHIFT", "0")))
+out_buf = shifted(torch.empty(wl.B, wl.Q, wl.H, wl.D, dtype=d["value"].dtype, device="cuda:0"), int(os.environ.get("OUT_SHIFT", "0")))
+print("ptr % 1024: value", d["value"].data_ptr() % 1024, " loc", d["loc"].data_ptr() % 1024, " attn", d["attn"].data_ptr() % 1024,
+      " out", out_buf.data_ptr() % 1024)
+_fwd = msda_hip_fwd
+def msda_hip_fwd(*a, **k):  # noqa: E302  (every call below writes into the same, possibly shifted, result buffer)
+    return _fwd(*a, out=out_buf, **k)
 for _ in range(3):
     out = msda_hip_fwd(d["value"], d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
 _lib.set_option("debug", 2048 | _lib.get_option("debug"))
