@@ -227,7 +227,7 @@ MSDA_API const char *msda_last_error(void);
  *   "profile"    0 (default);  1: event pairs around every kernel launch, read with msda_profile_read (measurement only)
  *   "level_cells" 0 (default): unknown;  n: process-wide form of the max_level_cells argument (an argument wins)
  * Builds with -DMSDA_DEV (development only; the shipped library rejects these keys) add the experiment knobs
- * "cell_slices", "gather_win", "wg_target", "lds_budget", "lds_stagger" and the ablation / phase-clock mask "debug":
+ * "cell_slices", "gather_win", "wg_target", "lds_budget", "lds_stagger", "lds_over" and the ablation / phase-clock mask "debug":
  * see msda_triton_amd/csrc/msda_launch.hpp, msda_value_sorted.hpp and tools/phase_clock.py.
  *
  * Reproducibility.  out, grad_loc and grad_attn are bitwise reproducible by construction (no atomics, fixed summation

@@ -33,6 +33,7 @@ static std::atomic<int> g_strict{0};
 static std::atomic<int> g_lds_levels{1};
 static std::atomic<int> g_lds_budget{-1};
 static std::atomic<int> g_unit_fwd{1};
+static std::atomic<int> g_lds_over{1};
 static std::atomic<int> g_lds_stagger{0};  // (measured 0 / 4 / 12 / 24 at c2 @ 10k: 0 is fastest — the work counter desynchronises the waves by itself)
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
@@ -112,6 +113,7 @@ int option_records_in_grads() { return g_records_in_grads.load(std::memory_order
 int option_strict() { return g_strict.load(std::memory_order_relaxed); }
 int option_lds_levels() { return g_lds_levels.load(std::memory_order_relaxed); }
 int option_lds_stagger() { return g_lds_stagger.load(std::memory_order_relaxed); }
+int option_lds_over() { return g_lds_over.load(std::memory_order_relaxed); }
 int option_unit_fwd() { return g_unit_fwd.load(std::memory_order_relaxed); }
 int option_lds_budget() { return g_lds_budget.load(std::memory_order_relaxed); }  // dev knob: cap on the level bytes (-1: none)
 // CUs of the current device, asked once per device (the LDS-level gather variants size their grid by it)
@@ -285,6 +287,7 @@ static const OptionEntry kOptions[] = {
     {"wg_target", &g_wg_target, 1, 0x7fffffff, true},
     {"lds_budget", &g_lds_budget, -1, 0x7fffffff, true},
     {"lds_stagger", &g_lds_stagger, 0, 4096, true},
+    {"lds_over", &g_lds_over, 1, 8, true},
 };
 static const OptionEntry *find_option(const char *key)
 {

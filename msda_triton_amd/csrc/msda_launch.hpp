@@ -160,6 +160,7 @@ int option_unit_fwd();  // 1 (default): small problems take the one-wave-per-uni
 // A/B): Q = 10 10.3 -> 7.5 us, 100 12.8 -> 9.4, 300 ~15 -> 13.2; from Q ~ 500 the general kernel is faster (900: 18-23 against 23.7)
 constexpr long long kUnitFwdMaxUnits = 12288;
 int option_lds_budget();  // dev knob: cap on the bytes of LDS-resident levels (-1: none)
+int option_lds_over();     // workgroups per CU the LDS-served-level launches are cut into (1: one round)
 int option_lds_stagger();  // dev knob: start-up stagger of an LDSL workgroup's waves, in units of 64 cycles per wave
 int device_cu_count();    // CUs of the current device (cached; msda_api.hip)
 constexpr size_t kRecordLdsBudgetLds = 72 * 1024;  // the records of 16 waves (the fused backward's larger records: 100 KB)
@@ -187,6 +188,7 @@ inline LdsLevelsPlan lds_levels_plan_rt(const Params &p, int G, size_t acc_size,
     pl.nqc = (p.Q + NU - 1) / NU;
     const int npairs = p.B * p.H, ncu = device_cu_count();
     int slots = npairs >= ncu ? 1 : (ncu + npairs / 2) / npairs;
+    slots *= option_lds_over();
     if (slots > pl.nqc) slots = pl.nqc;
     if (slots < 1) slots = 1;
     pl.qw = (pl.nqc + slots - 1) / slots;
