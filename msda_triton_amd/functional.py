@@ -508,7 +508,7 @@ def msda_hip_fwd_fused(img, img_shapes, proj, reference_points, padding_mode, al
 
 
 def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, padding_mode, align_corners,
-                       need_img: bool = True, level_cells: int = 0):
+                       need_img: bool = True, level_cells: int = 0, need_ref: bool = True):
     """Backward of the module core with the prologue's chain rule done in the kernel: returns
     ``(img_grad | None, proj_grad, reference_points_grad)``, or None when the library declines (L*P too large
     for one pass; nothing was launched)."""
@@ -550,7 +550,9 @@ def msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, paddin
     if rc == -5:  # MSDA_ERR_UNSUPPORTED
         return None
     _lib.check(rc, f"msda_bwd_fused_{suf}")
-    return g_img, g_proj, g_ref_part.sum(dim=2)
+    # (the kernel leaves per-head partials of grad_reference_points; their sum is a launch of its own — 16 us at the c2
+    # shape — and reference points rarely require a gradient)
+    return g_img, g_proj, (g_ref_part.sum(dim=2) if need_ref else None)
 
 
 class _HipFusedModuleCoreFunction(Function):
@@ -580,7 +582,7 @@ class _HipFusedModuleCoreFunction(Function):
         need_img, _, need_proj, need_ref = ctx.needs_input_grad[:4]
         if ctx.fused and (need_proj or need_ref):
             res = msda_hip_bwd_fused(out_grad, img, img_shapes, proj, reference_points, ctx.padding_mode,
-                                     ctx.align_corners, need_img, level_cells=ctx.level_cells)
+                                     ctx.align_corners, need_img, level_cells=ctx.level_cells, need_ref=need_ref)
             if res is not None:
                 g_img, g_proj, g_ref = res
                 return g_img, None, (g_proj if need_proj else None), (g_ref if need_ref else None), None, None, None
