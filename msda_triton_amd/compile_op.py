@@ -152,15 +152,22 @@ def _fused_lp_limit(head_dim: int, elem_size: int) -> int:
     return int(_lib.load().msda_fused_lp_limit(int(head_dim), int(elem_size)))
 
 
-def fused_lp_ok(img: torch.Tensor, proj: torch.Tensor) -> bool:
+def fused_lp_ok(img: torch.Tensor, proj: torch.Tensor, reference_points=None) -> bool:
     """Do the fused kernels take this L*P for this head dimension / dtype?  (Static shapes: decided at trace time.)"""
-    return int(proj.shape[3]) * int(proj.shape[4]) <= _fused_lp_limit(int(img.shape[-1]), proj.element_size())
+    storage = reference_points is not None and F.fused_storage_dtypes(img.dtype, proj.dtype, reference_points.dtype)
+    elem = 4 if storage else proj.element_size()  # (16-bit storage: the kernels' records are those of fp32 arithmetic)
+    return int(proj.shape[3]) * int(proj.shape[4]) <= _fused_lp_limit(int(img.shape[-1]), elem)
 
 
 def compiled_fused_module_core(img, img_shapes, proj, reference_points, padding_mode, align_corners,
                                level_cells: int = 0) -> torch.Tensor:
     """``fused_module_core`` through the registered custom ops (traceable); fp32 under autocast like the eager path."""
     F._padding_code(padding_mode)
+    if F.fused_storage_dtypes(img.dtype, proj.dtype, reference_points.dtype):
+        # 16-bit value pyramid and projection next to fp32 reference points: the storage kernels as they are (fp32 arithmetic)
+        with torch.autocast("cuda", enabled=False):
+            return msda_fused_forward(img, img_shapes, proj, reference_points, padding_mode == "zeros",
+                                      bool(align_corners), int(level_cells))
     if torch.is_autocast_enabled("cuda"):
         with torch.autocast("cuda", enabled=False):
             return msda_fused_forward(img.float(), img_shapes, proj.float(), reference_points.float(),

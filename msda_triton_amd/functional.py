@@ -650,10 +650,11 @@ def fused_module_core(img, img_shapes, proj, reference_points, padding_mode, ali
                 return ext.msda_fused(img, img_shapes, proj, reference_points, pad, bool(align_corners), level_cells)
         return _HipFusedModuleCoreFunction.apply(img, img_shapes, proj, reference_points, padding_mode,
                                                  bool(align_corners), level_cells)
-    if img.device.type == "cuda" and torch.compiler.is_compiling() and dtypes_supported(img.dtype, proj.dtype) and \
-            reference_points.dtype == proj.dtype:
+    if img.device.type == "cuda" and torch.compiler.is_compiling() and \
+            ((dtypes_supported(img.dtype, proj.dtype) and reference_points.dtype == proj.dtype) or
+             fused_storage_dtypes(img.dtype, proj.dtype, reference_points.dtype)):
         from . import compile_op  # traced: keep the fused kernels as one custom op per direction
-        if compile_op.fused_lp_ok(img, proj):
+        if compile_op.fused_lp_ok(img, proj, reference_points):
             return compile_op.compiled_fused_module_core(img, img_shapes, proj, reference_points, padding_mode,
                                                          align_corners, level_cells)
     pts, att = module_sampling_inputs(proj, img_shapes, reference_points)

@@ -92,7 +92,7 @@ class MultiscaleDeformableAttention(nn.Module):
         proj = projection(self.query_input_proj, queries).reshape(B, N, H, L, P, 3)
         value = projection(self.img_input_proj, img).reshape(B, I, H, self.hidden_dim // H)
         if value.device.type == "cuda" and proj.dtype in (torch.bfloat16, torch.float16) and \
-                self.value_dtype in (None, proj.dtype) and value.dtype == proj.dtype and not torch.compiler.is_compiling():
+                self.value_dtype in (None, proj.dtype) and value.dtype == proj.dtype:
             # 16-bit projections (autocast's GEMMs, or 16-bit parameters) with fp32 reference points: the kernels read
             # and write the 16-bit tensors as they are and compute in fp32 — what the reference's core does under
             # autocast (it casts every input to fp32, frontend.py:111) without the fp32 copies of value, projection,

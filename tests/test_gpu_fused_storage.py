@@ -135,3 +135,44 @@ def test_module_under_autocast_takes_the_storage_kernels_and_matches_the_fp32_co
         assert a.dtype == b.dtype and a.shape == b.shape
         scale = b.float().abs().max().clamp_min(1e-6)
         torch.testing.assert_close(a.float() / scale, b.float() / scale, rtol=3e-2, atol=2e-2)
+
+
+def test_compiled_module_under_autocast_keeps_the_storage_kernels():
+    """torch.compile(fullgraph) of the module under bf16 autocast: the 16-bit storage kernels stay in the graph as the
+    registered custom ops (bf16 value / projection, fp32 reference points) and match the eager module."""
+    import msda_triton_amd.compile_op  # noqa: F401
+    torch.manual_seed(6)
+    m = MultiscaleDeformableAttention(32, 32, 2, 4, 3, "zeros", False).to(DEV)
+    levels = [(6, 5), (3, 4)]
+    s = torch.tensor(levels, device=DEV)
+    img = torch.randn(2, sum(h * w for h, w in levels), 32, device=DEV)
+    q = torch.randn(2, 21, 32, device=DEV)
+    ref = torch.rand(2, 21, 4, device=DEV)
+    seen = []
+    real = functional.msda_hip_fwd_fused
+
+    def spy(img_, shapes_, proj_, ref_, *a, **k):
+        seen.append((img_.dtype, proj_.dtype, ref_.dtype))
+        return real(img_, shapes_, proj_, ref_, *a, **k)
+
+    functional.msda_hip_fwd_fused = spy
+    try:
+        compiled = torch.compile(m, fullgraph=True, backend="aot_eager")
+        res = []
+        for f in (m, compiled):
+            m.zero_grad()
+            i_, q_ = img.clone().requires_grad_(True), q.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = f(i_, s, q_, ref)
+            out.float().square().sum().backward()
+            res.append((out.detach(), i_.grad, q_.grad, m.query_input_proj.weight.grad.clone()))
+    finally:
+        functional.msda_hip_fwd_fused = real
+    assert seen == [(torch.bfloat16, torch.bfloat16, torch.float32)] * 2, seen
+    for a, b in zip(*res):
+        assert a.dtype == b.dtype
+        torch.testing.assert_close(a.float(), b.float(), atol=2e-2, rtol=2e-2)
+    v = torch.randn(2, 42, 4, 8, device=DEV).bfloat16()
+    pr = torch.randn(2, 21, 4, 2, 3, 3, device=DEV).bfloat16()
+    torch.library.opcheck(torch.ops.msda_amd.fused_forward.default, (v, s, pr, ref, False, True),
+                          test_utils=("test_schema", "test_faketensor"))
