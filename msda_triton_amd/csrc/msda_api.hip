@@ -34,6 +34,7 @@ static std::atomic<int> g_lds_levels{1};
 static std::atomic<int> g_lds_budget{-1};
 static std::atomic<int> g_unit_fwd{1};
 static std::atomic<int> g_lds_over{1};
+static std::atomic<int> g_lds_planes{0};
 static std::atomic<int> g_lds_stagger{0};  // (measured 0 / 4 / 12 / 24 at c2 @ 10k: 0 is fastest — the work counter desynchronises the waves by itself)
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
@@ -114,6 +115,7 @@ int option_strict() { return g_strict.load(std::memory_order_relaxed); }
 int option_lds_levels() { return g_lds_levels.load(std::memory_order_relaxed); }
 int option_lds_stagger() { return g_lds_stagger.load(std::memory_order_relaxed); }
 int option_lds_over() { return g_lds_over.load(std::memory_order_relaxed); }
+int option_lds_planes() { return g_lds_planes.load(std::memory_order_relaxed); }
 int option_unit_fwd() { return g_unit_fwd.load(std::memory_order_relaxed); }
 int option_lds_budget() { return g_lds_budget.load(std::memory_order_relaxed); }  // dev knob: cap on the level bytes (-1: none)
 // CUs of the current device, asked once per device (the LDS-level gather variants size their grid by it)
@@ -288,6 +290,7 @@ static const OptionEntry kOptions[] = {
     {"lds_budget", &g_lds_budget, -1, 0x7fffffff, true},
     {"lds_stagger", &g_lds_stagger, 0, 4096, true},
     {"lds_over", &g_lds_over, 1, 8, true},
+    {"lds_planes", &g_lds_planes, 0, 2, false},
 };
 static const OptionEntry *find_option(const char *key)
 {

@@ -75,6 +75,7 @@ struct Params {
     void *ws_accum;     // [pairs][I][D] acc-typed running sums between rounds (nullptr: a single round)
     int lds_lev_bytes;  // LDSL gather kernels: LDS bytes set aside for the rows of the coarsest levels
     int lds_stagger;    // ... wave w starts w * lds_stagger * 64 cycles late
+    int lds_planes;     // ... 2: a workgroup serves the planes (b, 2k) and (b, 2k + 1) and its waves take slices of either
     int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
     int small_ns;       // ... workgroups per (plane, level)
     int small_hinted;   // ... small_cells is the caller's promise (msda_hint_level_cells), not the bound from I
@@ -147,6 +148,27 @@ __device__ __forceinline__ int next_slice(int lane)
     if (lane == 0) t = __hip_atomic_fetch_add(gather_work_counter(), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __builtin_amdgcn_readfirstlane(t);
 }
+// Two planes per workgroup (Params::lds_planes == 2): a counter per plane; a wave takes its next slice from the plane that
+// has MORE slices left (ties: its home plane), so the two planes of a workgroup finish together whatever their rows cost —
+// the rows of one head can be 20 % slower to gather than its neighbour's.  Returns the slice (>= nslices:
+// both planes are done) and the plane in `hp`.
+__device__ __forceinline__ int next_slice2(int lane, int home, int nslices, int &hp)
+{
+    int t = 0, pick = 0;
+    if (lane == 0) {
+        int *c = gather_work_counter();
+        const int c0 = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int c1 = __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pick = c0 == c1 ? home : (c1 < c0 ? 1 : 0);
+        t = __hip_atomic_fetch_add(c + pick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (t >= nslices) {
+            pick ^= 1;
+            t = __hip_atomic_fetch_add(c + pick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    hp = __builtin_amdgcn_readfirstlane(pick);
+    return __builtin_amdgcn_readfirstlane(t);
+}
 __device__ __forceinline__ void stagger_wave(int wave, int units)
 {
     for (int i = 0; i < wave * units; ++i) __builtin_amdgcn_s_sleep(1);
@@ -177,6 +199,7 @@ struct CoarseStage {
     int first;                  // levels [first, L) are LDS-resident
     uint32_t base, zero;        // LDS byte offsets of the first row and of the row of zeros
     uint32_t row_bytes;         // D * sizeof(TV): distance of two rows in LDS
+    uint32_t plane_stride;      // Params::lds_planes == 2: bytes from one plane's copy to the other's
 };
 // Next-slice prefetch WITHOUT registers (LDSL kernels): the sampling inputs of a wave's next slice travel from memory
 // straight into a per-wave LDS staging area (global_load_lds_*: LDS address = M0 + lane * size, inactive lanes write
@@ -191,28 +214,32 @@ __device__ __forceinline__ void dma_dword(const void *g, uint32_t lds_uniform)
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <typename TV, int VEC, int BLK>
-__device__ __forceinline__ CoarseStage stage_coarse_levels(const LevelTab *tab, const Params &p, rsrc_t rs, uint32_t plane_row_bytes, size_t lds_off)
+__device__ __forceinline__ CoarseStage stage_coarse_levels(const LevelTab *tab, const Params &p, rsrc_t rs, uint32_t plane_row_bytes, size_t lds_off,
+                                                           int half = 0)
 {
+    // Params::lds_planes == 2: each half of the workgroup's threads stages ITS plane's levels into its own region
+    const int nthr = p.lds_planes == 2 ? BLK / 2 : BLK;
     constexpr uint32_t kPiece = VEC * sizeof(TV);  // bytes a lane loads of a row
     CoarseStage cs;
     cs.row_bytes = (uint32_t)p.D * (uint32_t)sizeof(TV);
-    cs.base = (uint32_t)((lds_off + 127) / 128 * 128);
     const CoarseLevels cl = coarse_levels(tab, p.L, cs.row_bytes, p.lds_lev_bytes);
     cs.first = cl.first;
+    cs.plane_stride = (((uint32_t)cl.pixels + 1) * cs.row_bytes + 127) / 128 * 128;  // bytes between the two planes' copies
+    cs.base = (uint32_t)((lds_off + 127) / 128 * 128) + (uint32_t)half * cs.plane_stride;
     cs.zero = cs.base + (uint32_t)cl.pixels * cs.row_bytes;
     const int ppr = (int)(cs.row_bytes / kPiece);  // pieces per row
     const int npieces = cl.pixels * ppr;
     const float inv_ppr = 1.0f / (float)ppr;
     const uint32_t first_row = (uint32_t)(cl.first < p.L ? tab->start[cl.first] : 0);
     using RLV = RawLoad<kPiece>;
-    const int tid = threadIdx.x;
-    if (tid == 0) *gather_work_counter() = 0;
-    for (int i = tid; i < npieces; i += BLK) {
+    const int tid = p.lds_planes == 2 ? (int)threadIdx.x - half * nthr : (int)threadIdx.x;
+    if (tid == 0) gather_work_counter()[half] = 0;
+    for (int i = tid; i < npieces; i += nthr) {
         const int r = div_small(i, ppr, inv_ppr), c = i - imul24(r, ppr);
         const typename RLV::type v = RLV::load(rs, mul24(first_row + (uint32_t)r, plane_row_bytes) + (uint32_t)c * kPiece);
         *reinterpret_cast<typename RLV::type *>(msda_smem + cs.base + (uint32_t)i * kPiece) = v;
     }
-    for (int i = tid; i < ppr; i += BLK) {
+    for (int i = tid; i < ppr; i += nthr) {
         typename RLV::type z{};
         *reinterpret_cast<typename RLV::type *>(msda_smem + cs.zero + (uint32_t)i * kPiece) = z;
     }
@@ -273,8 +300,15 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
 
     const int slots = (p.nqc + p.qw - 1) / p.qw;
     int pair, slot;
-    if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
-    const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
+    // LDSL with Params::lds_planes == 2: the workgroup serves the planes 2 * pair and 2 * pair + 1 (neighbouring heads of
+    // one batch element); `half` (wave-uniform) is a wave's home plane, `hp` below the plane of the slice it works on
+    const int two = LDSL && p.lds_planes == 2;
+    if (!decode_block(p.grid3d, two ? (p.B * p.H) >> 1 : p.B * p.H, slots, p.xcd_map, pair, slot)) return;
+    const int half = two ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= BLK / 2)) : 0;
+    const int pair0 = two ? 2 * pair : pair;  // (the workgroup's first plane)
+    pair = pair0 + half;
+    const int b = (int)fast_div((uint32_t)pair, p.div_h);
+    int h = pair - b * p.H;
 
     const int scp = p.sc + 1;  // +1 record of padding: units land on different LDS banks
     const GatherLds<A> lds(NU, scp);
@@ -284,7 +318,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TV);
     const TV *plane = static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
     const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV));
-    const rsrc_t rs = make_rsrc(plane, plane_bytes);
+    rsrc_t rs = make_rsrc(plane, plane_bytes);  // (home plane; re-made per slice when the wave works on the other one)
 
     const int tid = threadIdx.x;
     const int wave = tid / kWave, lane = tid % kWave;
@@ -292,10 +326,20 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     uint4 *w_off = lds.s_off + wave * UPW * scp;
     Rec4<A> *w_rec = lds.s_rec + wave * UPW * scp;
     // per-plane bases (64-bit, uniform) + 32-bit per-sample indices (the host checks Q*H*L*P*3 < 2^31)
-    const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
+    size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
     const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
     [[maybe_unused]] const TS *proj3 = static_cast<const TS *>(p.loc) + 3 * plane_s0;  // FUSED: raw projection (dx, dy, logit)
     const T *attn = FUSED ? nullptr : static_cast<const T *>(p.attn) + plane_s0;
+    // the wave's plane-dependent values for plane pair0 + hp_ (two planes per workgroup: per slice)
+    auto select_plane = [&](int hp_) {
+        h = pair0 + hp_ - b * p.H;
+        const TV *pl_ = static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
+        rs = make_rsrc(pl_, (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV)));
+        plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
+        loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
+        proj3 = static_cast<const TS *>(p.loc) + 3 * plane_s0;
+        attn = FUSED ? nullptr : static_cast<const T *>(p.attn) + plane_s0;
+    };
     const T *refp = FUSED ? static_cast<const T *>(p.ref) + (size_t)b * p.Q * p.ref_dim : nullptr;
     const int HLP = p.H * p.LP;
     const float inv_P = 1.0f / (float)p.P;
@@ -313,7 +357,14 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     T pa[kPre];
     // request the sampling points and weights of the wave's units [wq, wq + UPW) (queries below qlim), one sample per
     // lane and trip
-    auto prefetch = [&](int wq, int qlim) {
+    auto prefetch = [&](int wq, int qlim, int hp_ = -1) {
+        // (two planes per workgroup: the NEXT slice may belong to the other plane — its own bases, the current ones stay)
+        const T *loc_ = loc, *attn_ = attn;
+        if (hp_ >= 0) {
+            const size_t ps_ = ((size_t)b * p.Q * p.H + (size_t)(pair0 + hp_ - b * p.H)) * p.LP;
+            loc_ = static_cast<const T *>(p.loc) + 2 * ps_;
+            attn_ = FUSED ? nullptr : static_cast<const T *>(p.attn) + ps_;
+        }
 #pragma unroll
         for (int t = 0; t < kPre; ++t) {
             if constexpr (!FUSED) {
@@ -325,8 +376,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
 #endif
                 if (f < UPW * p.LP && fq < qlim) {
                     const int sidx = imul24(fq, HLP) + (f - imul24(fu, p.LP));
-                    pxy[t] = *reinterpret_cast<const Pack<T, 2> *>(loc + 2 * sidx);
-                    pa[t] = attn[sidx];
+                    pxy[t] = *reinterpret_cast<const Pack<T, 2> *>(loc_ + 2 * sidx);
+                    pa[t] = attn_[sidx];
                 }
             }
         }
@@ -340,7 +391,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     // (what a corner masked by "zeros" padding reads)
     CoarseStage cs{p.L, 0, 0, (uint32_t)p.D * (uint32_t)sizeof(TV)};
     if constexpr (LDSL)
-        cs = stage_coarse_levels<TV, VEC, BLK>(tab, p, rs, row_bytes, kGatherLdsFixed + (size_t)NU * scp * (sizeof(uint4) + sizeof(Rec4<A>)));
+        cs = stage_coarse_levels<TV, VEC, BLK>(tab, p, rs, row_bytes, kGatherLdsFixed + (size_t)NU * scp * (sizeof(uint4) + sizeof(Rec4<A>)), half);
+    const uint32_t cs_base0 = cs.base - (uint32_t)half * cs.plane_stride, cs_zero_rel = cs.zero - cs.base;
     const int fl = cs.first;
 
     // LDSL: the workgroup's queries [q_lo, q_hi) go to its waves slice by slice (next_slice)
@@ -355,20 +407,28 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
     [[maybe_unused]] unsigned long long clk_t0 = 0, clk_a = 0, clk_b = 0, clk_c = 0, clk_d = 0, clk_e = 0;
     [[maybe_unused]] float clk_ph[5] = {0, 0, 0, 0, 0};
     MSDA_STAMP(clk_t0);
+    int hp_next = half;  // (plane of the slice in t_next)
+    const int nslices = (q_hi - q_lo + UPW - 1) / UPW;
+    auto grab = [&]() { t_next = two ? next_slice2(lane, half, nslices, hp_next) : next_slice(lane); };
     if constexpr (LDSL) {
         stagger_wave(wave, p.lds_stagger);
-        t_next = next_slice(lane);
+        grab();
         have_next = true;
-        if (pre) prefetch(q_lo + t_next * UPW, q_hi);
+        if (pre) prefetch(q_lo + t_next * UPW, q_hi, two ? hp_next : -1);
     }
     for (int it = 0;; ++it) {
         int wq0;  // first query of this wave (wave-uniform)
         MSDA_STAMP(clk_a);
         if constexpr (LDSL) {
-            if (!have_next) t_next = next_slice(lane);
+            if (!have_next) grab();
             have_next = false;
             wq0 = q_lo + t_next * UPW;
             if (wq0 >= q_hi) break;
+            if (two) {  // this slice's plane: descriptor, sample bases, LDS copy of its levels
+                select_plane(hp_next);
+                cs.base = cs_base0 + (uint32_t)hp_next * cs.plane_stride;
+                cs.zero = cs.base + cs_zero_rel;
+            }
         } else {
             const int qc = slot * p.qw + it;
             if (qc >= qc_end) break;
@@ -492,9 +552,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
                     for (int t = 0; t < kPre; ++t)
                         if (lane + t * kWave < UPW * sc) tap_sample(lane + t * kWave, true, pxy[t], pa[t]);
                     if constexpr (LDSL) {  // (pre: one channel chunk, one trip — this runs once per slice)
-                        t_next = next_slice(lane);
+                        grab();
                         have_next = true;
-                        prefetch(q_lo + t_next * UPW, q_hi);
+                        prefetch(q_lo + t_next * UPW, q_hi, two ? hp_next : -1);
                     }
                 } else {
                     for (int f = lane; f < UPW * sc; f += kWave) tap_sample(f, false, pxy[0], pa[0]);
@@ -720,8 +780,14 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
 
     const int slots = (p.nqc + p.qw - 1) / p.qw;
     int pair, slot;
-    if (!decode_block(p.grid3d, p.B * p.H, slots, p.xcd_map, pair, slot)) return;
-    const int b = (int)fast_div((uint32_t)pair, p.div_h), h = pair - b * p.H;
+    // LDSL with Params::lds_planes == 2: two planes per workgroup, the waves take slices of either (see msda_fwd_kernel)
+    const int two = LDSL && p.lds_planes == 2;
+    if (!decode_block(p.grid3d, two ? (p.B * p.H) >> 1 : p.B * p.H, slots, p.xcd_map, pair, slot)) return;
+    const int half = two ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= BLK / 2)) : 0;
+    const int pair0 = two ? 2 * pair : pair;
+    pair = pair0 + half;
+    const int b = (int)fast_div((uint32_t)pair, p.div_h);
+    int h = pair - b * p.H;
 
     const int scp = p.sc + 1;
     // record in : {dx, dy, a*sx*gx_on, a*sy*gy_on};  record out (same slot): {gA, gX, gY, -}
@@ -731,7 +797,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TV);
     const TV *plane = static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
     const uint32_t plane_bytes = (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV));
-    const rsrc_t rs = make_rsrc(plane, plane_bytes);
+    rsrc_t rs = make_rsrc(plane, plane_bytes);  // (home plane; re-made per slice when the wave works on the other one)
 
     const int tid = threadIdx.x;
     const int wave = tid / kWave, lane = tid % kWave;
@@ -739,10 +805,19 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     uint4 *w_off = lds.s_off + wave * UPW * scp;
     Rec4<A> *w_rec = lds.s_rec + wave * UPW * scp;
     // per-plane bases (64-bit, uniform) + 32-bit per-sample indices (the host checks Q*H*L*P*2 < 2^31)
-    const size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
+    size_t plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
     const T *loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
     [[maybe_unused]] const TS *proj3 = static_cast<const TS *>(p.loc) + 3 * plane_s0;  // FUSED: raw projection (dx, dy, logit)
     const T *attn = FUSED ? nullptr : static_cast<const T *>(p.attn) + plane_s0;
+    auto select_plane = [&](int hp_) {  // the plane-dependent values for plane pair0 + hp_
+        h = pair0 + hp_ - b * p.H;
+        const TV *pl_ = static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
+        rs = make_rsrc(pl_, (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV)));
+        plane_s0 = ((size_t)b * p.Q * p.H + h) * p.LP;
+        loc = static_cast<const T *>(p.loc) + 2 * plane_s0;
+        proj3 = static_cast<const TS *>(p.loc) + 3 * plane_s0;
+        attn = FUSED ? nullptr : static_cast<const T *>(p.attn) + plane_s0;
+    };
     const T *refp = FUSED ? static_cast<const T *>(p.ref) + (size_t)b * p.Q * p.ref_dim : nullptr;
     A *w_aux = lds.s_aux + wave * UPW * scp * 3;  // FUSED: [slot] = a, [UPW*scp + slot] = ox, [2*UPW*scp + slot] = oy
     A *w_a = w_aux, *w_ox = w_aux + UPW * scp, *w_oy = w_aux + 2 * UPW * scp;
@@ -758,7 +833,8 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     const bool pre = !FUSED && !LDSL && p.sc >= p.LP && UPW * p.LP <= kPre * kWave;
     // LDSL: the next slice's points and weights go to the wave's LDS staging area instead (dma_dword: no registers)
     constexpr bool kDma = LDSL && !FUSED && sizeof(T) == 4;
-    const bool pre_dma = kDma && p.sc >= p.LP && UPW * p.LP <= kStagePre * kWave;
+    // (two planes per workgroup: the staging areas do not fit next to two copies of the levels)
+    const bool pre_dma = kDma && !two && p.sc >= p.LP && UPW * p.LP <= kStagePre * kWave;
     const size_t rec_bytes = kGatherLdsFixed + (size_t)NU * (p.sc + 1) * (sizeof(uint4) + sizeof(Rec4<A>) + (FUSED ? 3 * sizeof(A) : 0));
     const uint32_t stage_lds = __builtin_amdgcn_readfirstlane((uint32_t)rec_bytes + (uint32_t)(threadIdx.x / kWave) * kStageWaveBytes);
     // (M0 wants the absolute LDS address: the dynamic area starts behind any static __shared__ object)
@@ -797,7 +873,8 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     __syncthreads();
     CoarseStage cs{p.L, 0, 0, (uint32_t)p.D * (uint32_t)sizeof(TV)};
     if constexpr (LDSL)
-        cs = stage_coarse_levels<TV, VEC, BLK>(tab, p, rs, row_bytes, rec_bytes + (kDma ? (size_t)(BLK / kWave) * kStageWaveBytes : 0));
+        cs = stage_coarse_levels<TV, VEC, BLK>(tab, p, rs, row_bytes, rec_bytes + (kDma && !two ? (size_t)(BLK / kWave) * kStageWaveBytes : 0), half);
+    const uint32_t cs_base0 = cs.base - (uint32_t)half * cs.plane_stride, cs_zero_rel = cs.zero - cs.base;
     // levels [fl, L) are SERVED from LDS: the first staged level whose first sample starts an exchange batch of G samples
     // in every trip (P = 4 / 8: every level; a staged level in front of it is simply not used)
     int fl = cs.first;
@@ -810,13 +887,15 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     const int q_lo = imul24(slot * p.qw, NU), q_hi = min(p.Q, imul24(qc_end, NU));
     const int q_end_ = LDSL ? q_hi : p.Q;  // queries beyond it are not this workgroup's
     // LDSL: the NEXT slice is taken, and its points requested, as soon as this slice's are consumed (as in the forward)
-    int t_next = 0;
+    int t_next = 0, hp_next = half;
     bool have_next = false;
+    const int nslices = (q_hi - q_lo + UPW - 1) / UPW;
+    auto grab = [&]() { t_next = two ? next_slice2(lane, half, nslices, hp_next) : next_slice(lane); };
     if constexpr (LDSL) {
         stagger_wave(wave, p.lds_stagger);
         if constexpr (kDma) {
             if (pre_dma) {
-                t_next = next_slice(lane);
+                grab();
                 have_next = true;
                 stage_request(q_lo + t_next * UPW, q_hi);
                 dma_wait();
@@ -826,10 +905,15 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     for (int it = 0;; ++it) {
         int wq0;  // first query of this wave (wave-uniform)
         if constexpr (LDSL) {
-            if (!have_next) t_next = next_slice(lane);
+            if (!have_next) grab();
             have_next = false;
             wq0 = q_lo + t_next * UPW;
             if (wq0 >= q_hi) break;
+            if (two) {
+                select_plane(hp_next);
+                cs.base = cs_base0 + (uint32_t)hp_next * cs.plane_stride;
+                cs.zero = cs.base + cs_zero_rel;
+            }
         } else {
             const int qc = slot * p.qw + it;
             if (qc >= qc_end) break;
@@ -952,7 +1036,7 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
                         }
                     }
                     wave_lds_sync();  // (staging area read before it is requested again)
-                    t_next = next_slice(lane);
+                    grab();
                     have_next = true;
                     stage_request(q_lo + t_next * UPW, q_hi);
                 }

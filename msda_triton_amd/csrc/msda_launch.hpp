@@ -160,6 +160,7 @@ int option_unit_fwd();  // 1 (default): small problems take the one-wave-per-uni
 // A/B): Q = 10 10.3 -> 7.5 us, 100 12.8 -> 9.4, 300 ~15 -> 13.2; from Q ~ 500 the general kernel is faster (900: 18-23 against 23.7)
 constexpr long long kUnitFwdMaxUnits = 12288;
 int option_lds_budget();  // dev knob: cap on the bytes of LDS-resident levels (-1: none)
+int option_lds_planes();   // 0 (default): two planes per LDS-level workgroup where the plan says so; 1: never; 2: whenever H is even
 int option_lds_over();     // workgroups per CU the LDS-served-level launches are cut into (1: one round)
 int option_lds_stagger();  // dev knob: start-up stagger of an LDSL workgroup's waves, in units of 64 cycles per wave
 int device_cu_count();    // CUs of the current device (cached; msda_api.hip)
@@ -170,9 +171,11 @@ struct LdsLevelsPlan {
     int nqc, qw, slots, sc;
     size_t lds;
     int lev_bytes;
+    int planes;  // 2: a workgroup serves the planes of two neighbouring heads and balances its waves between them
 };
 // (G lanes per unit, accumulators of acc_size bytes, rows of D * row_elem_size bytes)
-inline LdsLevelsPlan lds_levels_plan_rt(const Params &p, int G, size_t acc_size, size_t row_elem_size, bool aux, bool stage)
+inline LdsLevelsPlan lds_levels_plan_rt(const Params &p, int G, size_t acc_size, size_t row_elem_size, bool aux, bool stage,
+                                        bool two_ok = false)
 {
     const int NU = kBlockLds / G;
     LdsLevelsPlan pl{};
@@ -182,22 +185,67 @@ inline LdsLevelsPlan lds_levels_plan_rt(const Params &p, int G, size_t acc_size,
         pl.sc = pl.sc / G * G;
         rec_lds = kGatherLdsFixed + (size_t)NU * (pl.sc + 1) * (16 + (aux ? 7 : 4) * acc_size);
     }
-    if (stage) rec_lds += (size_t)(kBlockLds / kWave) * kStageWaveBytes;  // the waves' next-slice staging areas (dma_dword)
-    const size_t lev_base = (rec_lds + 127) / 128 * 128, row = (size_t)p.D * row_elem_size;
-    const long long room = (long long)kMaxDynLds - (long long)lev_base - (long long)((row + 15) / 16 * 16);
-    pl.nqc = (p.Q + NU - 1) / NU;
-    const int npairs = p.B * p.H, ncu = device_cu_count();
-    int slots = npairs >= ncu ? 1 : (ncu + npairs / 2) / npairs;
-    slots *= option_lds_over();
-    if (slots > pl.nqc) slots = pl.nqc;
-    if (slots < 1) slots = 1;
-    pl.qw = (pl.nqc + slots - 1) / slots;
-    pl.slots = (pl.nqc + pl.qw - 1) / pl.qw;
+    // the waves' next-slice staging areas (dma_dword) — not with two planes per workgroup: they do not fit next to two copies
+    const size_t lev_base2 = (rec_lds + 127) / 128 * 128;
+    if (stage) rec_lds += (size_t)(kBlockLds / kWave) * kStageWaveBytes;
+    size_t lev_base = (rec_lds + 127) / 128 * 128;
+    const size_t row = (size_t)p.D * row_elem_size;
+    const int npairs_all = p.B * p.H, ncu = device_cu_count();
     // the whole plane at most; the kernel takes the longest suffix of the level list that fits
     const long long plane = (long long)p.I * (long long)row;
-    pl.lev_bytes = (int)(room < plane ? (room < 0 ? 0 : room) : plane);
-    if (option_lds_budget() >= 0 && option_lds_budget() < pl.lev_bytes) pl.lev_bytes = option_lds_budget();
-    pl.lds = lev_base + (size_t)pl.lev_bytes + (row + 15) / 16 * 16;
+    auto levels_for = [&](int planes) {
+        const long long room = ((long long)kMaxDynLds - (long long)(planes == 2 ? lev_base2 : lev_base)) / planes -
+                               (long long)((row + 127) / 128 * 128) - 128;
+        long long lb = room < plane ? (room < 0 ? 0 : room) : plane;
+        if (option_lds_budget() >= 0 && option_lds_budget() < lb) lb = option_lds_budget();
+        return (int)lb;
+    };
+    auto slots_for = [&](int npairs, int nqc) {
+        int sl = npairs >= ncu ? 1 : (ncu + npairs / 2) / npairs;
+        sl *= option_lds_over();
+        if (sl > nqc) sl = nqc;
+        return sl < 1 ? 1 : sl;
+    };
+    pl.nqc = (p.Q + NU - 1) / NU;
+    pl.planes = 1;
+    pl.lev_bytes = levels_for(1);
+    // TWO planes per workgroup — the neighbouring heads (b, 2k), (b, 2k + 1) — whose waves take slices of whichever plane
+    // has more left (next_slice2): the rows of one head can gather 20 % slower than its neighbour's (they use half of the
+    // vector L1's tag RAMs), and a workgroup that owns one plane cannot give it more waves.  When both planes'
+    // levels fit where one plane's did and a workgroup still has >= 640 queries per plane (it stages twice the levels: c2 @ 10k
+    // forward 69.3 -> 65.4 us, @ 5k 39.2 -> 43.5).
+    if (two_ok && option_lds_planes() != 1 && (p.H % 2) == 0 && npairs_all >= 2) {
+        // The level sizes live on the device; the host has I and L.  For a pyramid whose levels shrink four-fold count the
+        // levels of the suffix that fits either budget: two planes when halving the budget loses none of them (a wrong guess
+        // costs speed, never correctness — the kernel fits its suffix itself).
+        const int lb2 = levels_for(2);
+        auto fit = [&](long long budget) {
+            double total = 0.0, w = 1.0;
+            for (int l = 0; l < p.L; ++l, w *= 0.25) total += w;
+            double px = (double)p.I / total;
+            for (int l = 1; l < p.L; ++l) px *= 0.25;  // pixels of the coarsest level
+            double sum = 0.0;
+            int n = 0;
+            for (int l = p.L - 1; l >= 0; --l, px *= 4.0) {
+                if ((sum + px) * (double)row > (double)budget) break;
+                sum += px;
+                ++n;
+            }
+            return n;
+        };
+        const int sl2 = slots_for(npairs_all / 2, pl.nqc);
+        const long long q_per_wg = (long long)((pl.nqc + sl2 - 1) / sl2) * NU;
+        if (option_lds_planes() == 2 || (fit(lb2) == fit(pl.lev_bytes) && fit(lb2) > 0 && q_per_wg >= 640)) {
+            pl.planes = 2;
+            pl.lev_bytes = lb2;
+            lev_base = lev_base2;
+        }
+    }
+    const int npairs = npairs_all / pl.planes;
+    const int slots = slots_for(npairs, pl.nqc);
+    pl.qw = (pl.nqc + slots - 1) / slots;
+    pl.slots = (pl.nqc + pl.qw - 1) / pl.qw;
+    pl.lds = lev_base + (size_t)pl.planes * ((size_t)pl.lev_bytes + (row + 127) / 128 * 128 + 128);
     const long long wgs = (long long)npairs * pl.slots, rounds = (wgs + ncu - 1) / ncu;
     const int opt = option_lds_levels();
     // worth it when the workgroups fill the CUs (one 1024-thread workgroup each) evenly: c2 @ 10k 99 -> 75 us, @ 1k
@@ -219,8 +267,9 @@ template <typename T, int VEC, int G, int MODE, typename TV, typename TS = T> in
     p.qw = pl.qw;
     p.lds_lev_bytes = pl.lev_bytes;
     p.lds_stagger = option_lds_stagger();
+    p.lds_planes = pl.planes;
     dim3 grid;
-    if (!plane_grid(p, p.B * p.H, pl.slots, grid)) {
+    if (!plane_grid(p, p.B * p.H / pl.planes, pl.slots, grid)) {
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
@@ -267,7 +316,8 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, typename TS = T
     if constexpr (VEC == 4 && sizeof(A) == 4 && (sizeof(T) == 4 || MODE == 0) &&
                   (((MODE == 0 || MODE == 2) && G <= 16) || ((MODE == 1 || MODE == 3) && (G == 4 || G == 8)))) {
         // (fp32 arithmetic; the rows may be 16-bit — the mixed-storage and module-storage kernels: 8-byte pieces, half the LDS)
-        const LdsLevelsPlan pl = lds_levels_plan<T, G, TV>(p, MODE == 3, MODE == 1);
+        const LdsLevelsPlan pl = lds_levels_plan_rt(p, G, sizeof(A), sizeof(TV), MODE == 3, MODE == 1, /*two planes*/ MODE != 1);
+        // (not the plain sample-gradient kernel: it would give up its LDS-DMA prefetch for them — 92.9 against 92.7 us, a draw)
         if (pl.use && (MODE < 2 || pl.sc == p.LP)) return launch_gather_lds<T, VEC, G, MODE, TV, TS>(p, pl, stream);
     }
     size_t lds;

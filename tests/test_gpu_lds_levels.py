@@ -117,3 +117,55 @@ def test_lds_served_levels_are_chosen_by_default_at_c2_size():
     a = _forward(c, torch.float32, "border", True, 1)
     b = _forward(c, torch.float32, "border", True, 0)
     assert torch.equal(a, b)
+
+
+# ---- two planes per workgroup (msda_set_option("lds_planes", 2): neighbouring heads share a workgroup, its waves take
+#      slices of whichever plane has more left) — the same arithmetic per unit, so still bit-identical ----
+@pytest.mark.parametrize("name", ["c2_like_f32", "all_levels_fit", "no_level_fits_but_last", "odd_points_boundary",
+                                  "many_samples_two_trips", "d64_f32_g16"])
+@pytest.mark.parametrize("pm,ac", MODES, ids=[mode_key(*m) for m in MODES])
+def test_two_planes_per_workgroup_forward_is_bit_identical(name, pm, ac):
+    from msda_triton_amd import _lib
+    B, Q, H, D, levels, P, td = CASES[name]
+    c = rand_case(np.random.default_rng(zlib.crc32(name.encode()) + 1), B, Q, H, D, levels, P)
+    plain = _forward(c, td, pm, ac, 0)
+    old = _lib.get_option("lds_planes")
+    try:
+        res = {}
+        for planes in (1, 2):  # (H odd: 2 falls back to one plane per workgroup)
+            _lib.set_option("lds_planes", planes)
+            res[planes] = _forward(c, td, pm, ac, 2)
+    finally:
+        _lib.set_option("lds_planes", old)
+    assert torch.equal(plain, res[1]) and torch.equal(plain, res[2])
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+def test_two_planes_per_workgroup_fused_forward_and_backward_are_bit_identical(ref_dim):
+    from msda_triton_amd import _lib
+    from msda_triton_amd.functional import fused_module_core
+    g = torch.Generator().manual_seed(ref_dim)
+    levels = [(16, 16), (8, 8), (4, 4), (2, 2)]
+    B, Q, H, D, P = 2, 650, 4, 32, 4
+    I = sum(h * w for h, w in levels)  # noqa: E741
+    value = torch.randn(B, I, H, D, generator=g).to(DEV)
+    proj = (torch.randn(B, Q, H, len(levels), P, 3, generator=g) * 2).to(DEV)
+    ref = torch.rand(B, Q, ref_dim, generator=g).to(DEV)
+    go = torch.randn(B, Q, H, D, generator=g).to(DEV)
+    shapes = torch.tensor(levels, device=DEV)
+    olds = {k: _lib.get_option(k) for k in ("lds_levels", "lds_planes")}
+    res = {}
+    try:
+        for key, (lv, pl) in {"plain": (0, 1), "one": (2, 1), "two": (2, 2)}.items():
+            _lib.set_option("lds_levels", lv)
+            _lib.set_option("lds_planes", pl)
+            v, pr = value.clone().requires_grad_(), proj.clone().requires_grad_()
+            out = fused_module_core(v, shapes, pr, ref, "border", True)
+            out.backward(go)
+            res[key] = (out.detach(), pr.grad, v.grad)
+    finally:
+        for k, v_ in olds.items():
+            _lib.set_option(k, v_)
+    for key in ("one", "two"):
+        for a, b in zip(res["plain"], res[key]):
+            assert torch.equal(a, b), key
