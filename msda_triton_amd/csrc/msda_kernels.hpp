@@ -781,7 +781,8 @@ __global__ __launch_bounds__(BLK) void msda_bwd_sample_kernel(const Params p)
     const int slots = (p.nqc + p.qw - 1) / p.qw;
     int pair, slot;
     // LDSL with Params::lds_planes == 2: two planes per workgroup, the waves take slices of either (see msda_fwd_kernel)
-    const int two = LDSL && p.lds_planes == 2;
+    // (the plain kernel never runs it — msda_launch.hpp — and is compiled without: the extra live scalars cost it 2-4 %)
+    const int two = LDSL && FUSED && p.lds_planes == 2;
     if (!decode_block(p.grid3d, two ? (p.B * p.H) >> 1 : p.B * p.H, slots, p.xcd_map, pair, slot)) return;
     const int half = two ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= BLK / 2)) : 0;
     const int pair0 = two ? 2 * pair : pair;
