@@ -180,6 +180,7 @@ struct LdsLevelsPlan {
     size_t lds;
     int lev_bytes;
     int planes;  // 2: a workgroup serves the planes of two neighbouring heads and balances its waves between them
+    bool rotate; // one plane per workgroup, but two workgroups per CU and the heads rotated over the XCDs (below)
 };
 // (G lanes per unit, accumulators of acc_size bytes, rows of D * row_elem_size bytes)
 inline LdsLevelsPlan lds_levels_plan_rt(const Params &p, int G, size_t acc_size, size_t row_elem_size, bool aux, bool stage,
@@ -250,7 +251,17 @@ inline LdsLevelsPlan lds_levels_plan_rt(const Params &p, int G, size_t acc_size,
         }
     }
     const int npairs = npairs_all / pl.planes;
-    const int slots = slots_for(npairs, pl.nqc);
+    int slots = slots_for(npairs, pl.nqc);
+    // One plane per workgroup (the plain sample-gradient kernel) and >= 1024 queries per workgroup: cut the launch into two
+    // workgroups per CU and rotate the heads over the XCDs, so that the dispatcher hands an XCD's CUs their second workgroup
+    // as they come free and a slow head is shared by four XCDs: c2 @ 10k 91 -> 87.4 us; smaller problems pay
+    // more for staging the levels twice than they get back (c2 @ 5k: 50.7 -> 55.2), so not there.
+    pl.rotate = false;
+    if (two_ok == false && pl.planes == 1 && option_lds_planes() != 1 && option_lds_over() == 1 && npairs_all >= 16 &&
+        (long long)((pl.nqc + slots - 1) / slots) * NU >= 1024 && slots * 2 <= pl.nqc) {
+        slots *= 2;
+        pl.rotate = true;
+    }
     pl.qw = (pl.nqc + slots - 1) / slots;
     pl.slots = (pl.nqc + pl.qw - 1) / pl.qw;
     pl.lds = lev_base + (size_t)pl.planes * ((size_t)pl.lev_bytes + (row + 127) / 128 * 128 + 128);
@@ -281,6 +292,7 @@ template <typename T, int VEC, int G, int MODE, typename TV, typename TS = T> in
         set_error("grid too large");
         return MSDA_ERR_TOO_LARGE;
     }
+    if (pl.rotate && p.xcd_map == 1) p.xcd_map = 2;  // (this launch only: plane_grid sets it afresh for the next one)
     static std::atomic<uint64_t> big_lds_done{0};
     const ProfileScope prof(MODE == 0 || MODE == 2 ? "msda_fwd_kernel" : "msda_bwd_sample_kernel", stream);
     if constexpr (MODE == 0 || MODE == 2) {
