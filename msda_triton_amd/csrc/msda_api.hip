@@ -35,6 +35,7 @@ static std::atomic<int> g_lds_budget{-1};
 static std::atomic<int> g_unit_fwd{1};
 static std::atomic<int> g_lds_over{1};
 static std::atomic<int> g_lds_planes{0};
+static std::atomic<int> g_linear_slots{320};
 static std::atomic<int> g_lds_stagger{0};  // (measured 0 / 4 / 12 / 24 at c2 @ 10k: 0 is fastest — the work counter desynchronises the waves by itself)
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
@@ -116,6 +117,7 @@ int option_lds_levels() { return g_lds_levels.load(std::memory_order_relaxed); }
 int option_lds_stagger() { return g_lds_stagger.load(std::memory_order_relaxed); }
 int option_lds_over() { return g_lds_over.load(std::memory_order_relaxed); }
 int option_lds_planes() { return g_lds_planes.load(std::memory_order_relaxed); }
+int option_linear_slots() { return g_linear_slots.load(std::memory_order_relaxed); }
 int option_unit_fwd() { return g_unit_fwd.load(std::memory_order_relaxed); }
 int option_lds_budget() { return g_lds_budget.load(std::memory_order_relaxed); }  // dev knob: cap on the level bytes (-1: none)
 // CUs of the current device, asked once per device (the LDS-level gather variants size their grid by it)
@@ -291,6 +293,7 @@ static const OptionEntry kOptions[] = {
     {"lds_stagger", &g_lds_stagger, 0, 4096, true},
     {"lds_over", &g_lds_over, 1, 8, true},
     {"lds_planes", &g_lds_planes, 0, 2, false},
+    {"linear_slots", &g_linear_slots, 1, 1 << 30, false},
 };
 static const OptionEntry *find_option(const char *key)
 {

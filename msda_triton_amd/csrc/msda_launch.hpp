@@ -100,16 +100,18 @@ inline int check_common(const Dims &d, int padding_mode, const void *const *ptrs
 // decode_block's 1-D formula, so the kernel needs no integer division; falls back to 1-D when a
 // dimension would exceed the 65535 limit.  Returns false if even the 1-D grid is too large.
 // Which workgroups share an XCD (decode_block): by default the planes stay on "their" XCD (xcd_map 1) so that its L2 holds
-// few planes.  A launch with THOUSANDS of workgroups per plane walks the planes one after another anyway — every XCD works
-// on the same plane at any time, its L2 holds that one plane — and then the plain linear order is better: all eight XCDs
-// share every plane's work, so a head whose rows gather slower slows everybody a little instead of one XCD
-// a lot.  c5 (3 125 workgroups per plane): forward 2.92 -> 2.45 ms, sample gradients 3.44 -> 2.89 ms.
-constexpr int64_t kLinearMapSlots = 2048;
+// few planes.  A launch with HUNDREDS of workgroups per plane walks the planes one after another anyway — the workgroups
+// resident at any time belong to a few planes, whose rows every L2 can hold — and then the plain linear order is better:
+// all eight XCDs share every plane's work, so a head whose rows gather slower slows everybody a little
+// instead of one XCD a lot.  c5 (3 125 workgroups per plane): forward 2.92 -> 2.45 ms, sample gradients 3.44 -> 2.89 ms; its
+// shards of 12 500 / 25 000 / 50 000 queries per plane (391 ... 1 563 workgroups): step -8 % each.  The threshold (option
+// "linear_slots", default 320) is empirical: c3's sample-gradient kernel (279 workgroups per plane) loses 2 % in linear order.
+int option_linear_slots();
 inline bool plane_grid(Params &p, int npairs, int64_t slots, dim3 &grid)
 {
     if (slots < 1) slots = 1;
     p.xcd_map = option_xcd_map();
-    if (p.xcd_map == 1 && slots >= kLinearMapSlots) p.xcd_map = 0;
+    if (p.xcd_map == 1 && slots >= option_linear_slots()) p.xcd_map = 0;
     const int64_t groups = (npairs + 7) / 8;
     if (p.xcd_map && slots <= 65535 && groups <= 65535) {
         p.grid3d = 1;
@@ -527,7 +529,8 @@ template <typename T, typename TV = T, typename TS = T> inline int run_value_sor
         return MSDA_ERR_TOO_LARGE;
     }
     constexpr int VECF = 16 / sizeof(T);
-    const int g3_cell = p.grid3d, cell_cap_pm = p.cell_cap;
+    // (a grid and the block -> plane mapping it was built for — plane_grid picks it per launch — travel together)
+    const int g3_cell = p.grid3d, map_cell = p.xcd_map, cell_cap_pm = p.cell_cap;
     // The level-major place pass (msda_value_place.hpp; reproducible record order) serves every shape it can (P <= its
     // workgroup).  On pyramids much larger than the sample count (a decoder over a real image without the level-size
     // bound: 14 k samples against 36 k cells per plane) every workgroup loads its level's whole table and the
@@ -559,13 +562,14 @@ template <typename T, typename TV = T, typename TS = T> inline int run_value_sor
         if (place_cells > kPlaceCellsTwoPerCu) place_cells = kPlaceCellsTwoPerCu;
     }
     dim3 gplace;
-    int g3_place = 0;
+    int g3_place = 0, map_place = p.xcd_map;
     if (place_lm) {
         if (!plane_grid(p, npairs, (int64_t)d.L * p.nsplit, gplace)) {
             set_error("grid too large");
             return MSDA_ERR_TOO_LARGE;
         }
         g3_place = p.grid3d;
+        map_place = p.xcd_map;
         static std::atomic<uint64_t> big_lds_lm{0}, big_lds_lm_small{0};
         allow_big_lds(msda_cell_place_lm_kernel<T, kPlaceBlock>, big_lds_lm);
         allow_big_lds(msda_cell_place_lm_kernel<T, kPlaceBlockSmall>, big_lds_lm_small);
@@ -575,6 +579,7 @@ template <typename T, typename TV = T, typename TS = T> inline int run_value_sor
         p.q_end = p.q_begin + w.q_round < p.Q ? p.q_begin + w.q_round : p.Q;
         p.finish_mode = w.rounds == 1 ? 0 : r == 0 ? 1 : r == w.rounds - 1 ? 3 : 2;
         p.grid3d = g3_cell;
+        p.xcd_map = map_cell;
         p.cell_cap = cell_cap_pm;
         {
             const ProfileScope prof("msda_cell_pass_kernel<count>", stream);
@@ -588,6 +593,7 @@ template <typename T, typename TV = T, typename TS = T> inline int run_value_sor
         const ProfileScope prof_place(place_lm ? "msda_cell_place_lm_kernel" : "msda_cell_pass_kernel<place>", stream);
         if (place_lm) {
             p.grid3d = g3_place;
+            p.xcd_map = map_place;
             p.cell_cap = place_cells;
             if (place_small)
                 hipLaunchKernelGGL((msda_cell_place_lm_kernel<T, kPlaceBlockSmall>), gplace, dim3(kPlaceBlockSmall), (size_t)place_cells * 4, stream, p);

@@ -1417,3 +1417,21 @@ def test_seventeen_levels_beyond_the_single_launch_kernel(oracle):
         check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float32], BWD_TOL[torch.float32])
 
 
+
+
+@pytest.mark.parametrize("slots", [1, 6, 40])
+def test_block_mapping_may_differ_between_the_kernels_of_one_call(oracle, slots):
+    """`linear_slots`: launches with many workgroups per plane take the linear block order, the others the XCD-aware one —
+    inside ONE backward the count, place, gather and finish passes may therefore disagree about the mapping, and each grid
+    has to travel with the mapping it was built for (a full-size c5 run caught a stale one in round 5)."""
+    from msda_triton_amd import _lib
+    c = rand_case(np.random.default_rng(100 + slots), 2, 1500, 8, 32, [(16, 16), (8, 8), (4, 4)], 4)
+    old = {k: _lib.get_option(k) for k in ("linear_slots", "value_path")}
+    _lib.set_option("linear_slots", slots)
+    _lib.set_option("value_path", 2)  # the sorted pipeline (five launches)
+    try:
+        for pm, ac in (MODES[0], MODES[3]):
+            check_against_oracle(oracle, c, pm, ac, FWD_TOL[torch.float32], BWD_TOL[torch.float32])
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)

@@ -6,7 +6,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 C="$1"; K=${2:-msda_fwd_kernel}
 rm -rf gpurun_out/pmc_xcc
-timeout -k 10 120 rocprofv3 --pmc $C --output-format json -d gpurun_out/pmc_xcc -- python bench.py --steps 2 --warmup 1 --spin-up-ms 0 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton $OPTS > gpurun_out/pmc_xcc.log 2>&1
+timeout -k 10 120 rocprofv3 --pmc $C --output-format json -d gpurun_out/pmc_xcc -- python bench.py --workload ${W:-c2_q10k} --steps 2 --warmup 1 --spin-up-ms 0 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton $OPTS > gpurun_out/pmc_xcc.log 2>&1
 python - "$K" <<'PY'
 import collections, glob, json, os, sys
 want = sys.argv[1]
