@@ -112,6 +112,9 @@ inline bool plane_grid(Params &p, int npairs, int64_t slots, dim3 &grid)
     if (slots < 1) slots = 1;
     p.xcd_map = option_xcd_map();
     if (p.xcd_map == 1 && slots >= option_linear_slots()) p.xcd_map = 0;
+    // ... and so is a launch whose planes do not cover the eight XCDs evenly (the XCD-aware grid gives plane-group x to XCD x
+    // and pads the rest: 4 planes would use half the chip — step 0.312 -> 0.204 ms at B = 1, H = 4, Q = 40 000; 12 planes: -11 %)
+    if (p.xcd_map == 1 && option_linear_slots() > 0 && (int64_t)npairs * 100 < ((int64_t)npairs + 7) / 8 * 8 * 85) p.xcd_map = 0;
     const int64_t groups = (npairs + 7) / 8;
     if (p.xcd_map && slots <= 65535 && groups <= 65535) {
         p.grid3d = 1;
@@ -225,7 +228,9 @@ inline LdsLevelsPlan lds_levels_plan_rt(const Params &p, int G, size_t acc_size,
     // vector L1's tag RAMs), and a workgroup that owns one plane cannot give it more waves.  When both planes'
     // levels fit where one plane's did and a workgroup still has >= 640 queries per plane (it stages twice the levels: c2 @ 10k
     // forward 69.3 -> 65.4 us, @ 5k 39.2 -> 43.5).
-    if (two_ok && option_lds_planes() != 1 && (p.H % 2) == 0 && npairs_all >= 2) {
+    // (... and the pairs still cover the eight XCDs evenly: the XCD-aware grid gives plane-group x to XCD x)
+    if (two_ok && option_lds_planes() != 1 && (p.H % 2) == 0 && npairs_all >= 2 &&
+        (option_lds_planes() == 2 || (npairs_all / 2) % 8 == 0)) {
         // The level sizes live on the device; the host has I and L.  For a pyramid whose levels shrink four-fold count the
         // levels of the suffix that fits either budget: two planes when halving the budget loses none of them (a wrong guess
         // costs speed, never correctness — the kernel fits its suffix itself).
