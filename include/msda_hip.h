@@ -212,8 +212,8 @@ MSDA_API const char *msda_last_error(void);
  *                   99 -> 75 us) — fp32 arithmetic over fp32 or 16-bit rows, and the 16-bit operators' forward over
  *                   64-byte rows; bit-identical results;  0: never;  2: wherever the variant exists (tests)
  *   "lds_planes" 0 (default): the LDS-level forward kernels (and the module's fused backward) serve TWO planes — the
- *                   neighbouring heads (b, 2k), (b, 2k + 1) — per workgroup where both planes' levels fit and a
- *                   workgroup keeps >= 640 queries per plane; its waves take slices of whichever plane has more left
+ *                   neighbouring heads (b, 2k), (b, 2k + 1) — per workgroup where both planes' levels fit and the
+ *                   pairs' workgroups come out no heavier than single planes' would; its waves take slices of whichever plane has more left
  *                   (c2 @ 10k forward 69.5 -> 64.3 us; bit-identical results);  1: never;  2: whenever H is even (tests)
  *   "unit_fwd"   1 (default): forwards of at most 12 288 (b, q, h) units take the one-wave-per-unit kernel (decoder
  *                   calls: cold-cache forward at Q = 100 12.8 -> 9.3 us);  0: never;  2: wherever it exists (tests)
