@@ -204,7 +204,8 @@ MSDA_API const char *msda_last_error(void);
  * normal use: the defaults are the fastest measured variants.  Unknown keys return MSDA_ERR_BAD_ARG.  Keys:
  *   "xcd_map"    1 (default): blockIdx -> (batch, head) mapping keeps each (b,h) plane on one XCD's L2
  *                0: plain linear mapping   2: as 1 with the planes of an XCD rotated through the heads
- *   "linear_slots" 320 (default): launches with at least this many workgroups per (batch, head) plane use the plain
+ *   "linear_slots" 320 (default): launches over 128-byte rows 1 KB apart (H * D * sizeof = 1024: the layout with a slow
+ *                   head) with at least this many workgroups per (batch, head) plane use the plain
  *                   linear block order instead of the XCD-aware one of "xcd_map" 1 (they walk the planes one after another
  *                   anyway, and all XCDs then share every plane's work: c5 step 11.2 -> 10.4 ms)
  *   "lds_levels" 1 (default): problems large enough to amortise it run the forward / sample-gradient kernels with the

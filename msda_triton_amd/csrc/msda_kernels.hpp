@@ -76,6 +76,7 @@ struct Params {
     int lds_lev_bytes;  // LDSL gather kernels: LDS bytes set aside for the rows of the coarsest levels
     int lds_stagger;    // ... wave w starts w * lds_stagger * 64 cycles late
     int lds_planes;     // ... 2: a workgroup serves the planes (b, 2k) and (b, 2k + 1) and its waves take slices of either
+    int vrow_bytes;     // host only: D * sizeof(value element) (plane_grid's block-order rule)
     int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
     int small_ns;       // ... workgroups per (plane, level)
     int small_hinted;   // ... small_cells is the caller's promise (msda_hint_level_cells), not the bound from I

@@ -111,7 +111,11 @@ inline bool plane_grid(Params &p, int npairs, int64_t slots, dim3 &grid)
 {
     if (slots < 1) slots = 1;
     p.xcd_map = option_xcd_map();
-    if (p.xcd_map == 1 && slots >= option_linear_slots()) p.xcd_map = 0;
+    // (... where there is an imbalance for it to level: 128-byte rows 1 KB apart — H * D * sizeof = 1024 —, the layout whose
+    // head 3 runs on half of the L1's tag RAMs.  Elsewhere the linear order only costs L2 locality: D = 128 / 256 in fp32 with
+    // 625 / 500 workgroups per plane lost 10-19 % of their forward to it.)
+    const bool skewed_layout = p.vrow_bytes == 128 && (int64_t)p.H * p.vrow_bytes == 1024;
+    if (p.xcd_map == 1 && skewed_layout && slots >= option_linear_slots()) p.xcd_map = 0;
     // ... and so is a launch whose planes do not cover the eight XCDs evenly (the XCD-aware grid gives plane-group x to XCD x
     // and pads the rest: 4 planes would use half the chip — step 0.312 -> 0.204 ms at B = 1, H = 4, Q = 40 000; 12 planes: -11 %)
     if (p.xcd_map == 1 && option_linear_slots() > 0 && (int64_t)npairs * 100 < ((int64_t)npairs + 7) / 8 * 8 * 85) p.xcd_map = 0;
@@ -670,6 +674,7 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
     p.attn = attn;
     p.out = out;
     fill_params(p, d, padding_mode, align_corners);
+    p.vrow_bytes = (int)(d.D * (int64_t)sizeof(TV));
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
     rc = dispatch_gather<T, 0, TV>(p, vec_ok, stream);
     if (rc > 0) set_error("forward launch failed: %s", hipGetErrorString((hipError_t)rc));  // negative: message already set
@@ -715,6 +720,7 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
     p.attn = nullptr;
     p.out = out;
     fill_params(p, d, padding_mode, align_corners);
+    p.vrow_bytes = (int)(d.D * (int64_t)sizeof(TV));
     p.ref = ref;
     p.ref_dim = ref_dim;
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
@@ -893,6 +899,7 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     p.grad_loc = grad_loc;
     p.grad_attn = grad_attn;
     fill_params(p, d, padding_mode, align_corners);
+    p.vrow_bytes = (int)(d.D * (int64_t)sizeof(TV));
     // Both halves wanted, one after the other: the sorted records are dead once the gather has run and grad_loc /
     // grad_attn are written only by the sample-gradient kernel, so that kernel goes LAST and the records of as many
     // planes as fit live in those two buffers (three quarters of them in fp32: 61 of 82 MB at c2 @ 10k); the rest go
@@ -1016,6 +1023,7 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
     p.grad_loc = grad_proj;
     p.grad_attn = grad_ref_part;
     fill_params(p, d, padding_mode, align_corners);
+    p.vrow_bytes = (int)(d.D * (int64_t)sizeof(TV));
     p.ref = ref;
     p.ref_dim = ref_dim;
     unsigned char *ws = static_cast<unsigned char *>(workspace);
