@@ -442,8 +442,9 @@ __device__ __forceinline__ bool decode_block(int grid3d, int npairs, int slots, 
 {
     if (grid3d) {
         if (xcd_map) {
-            // (xcd_map 2: the planes of one XCD rotate through the heads instead of all having the same one)
-            pair = (int)(blockIdx.z * 8 + (xcd_map == 2 ? ((blockIdx.x + blockIdx.z) & 7) : blockIdx.x));
+            // (xcd_map 2: the planes of one XCD rotate through the heads instead of all having the same one; by 3 per batch
+            //  element, so that with H = 8 neighbouring heads — which can be slow together, c3's 6 and 7 — do not meet again)
+            pair = (int)(blockIdx.z * 8 + (xcd_map == 2 ? ((blockIdx.x + 3 * blockIdx.z) & 7) : blockIdx.x));
             slot = (int)blockIdx.y;
         } else {
             pair = (int)blockIdx.y;
