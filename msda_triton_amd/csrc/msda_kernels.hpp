@@ -77,6 +77,7 @@ struct Params {
     int lds_stagger;    // ... wave w starts w * lds_stagger * 64 cycles late
     int lds_planes;     // ... 2: a workgroup serves the planes (b, 2k) and (b, 2k + 1) and its waves take slices of either
     int vrow_bytes;     // host only: D * sizeof(value element) (plane_grid's block-order rule)
+    int touch;          // forward kernels: the workgroups request every row of their plane once at the start (touch_rows)
     int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
     int small_ns;       // ... workgroups per (plane, level)
     int small_hinted;   // ... small_cells is the caller's promise (msda_hint_level_cells), not the bound from I
@@ -248,6 +249,28 @@ __device__ __forceinline__ CoarseStage stage_coarse_levels(const LevelTab *tab, 
     return cs;
 }
 // VEC consecutive elements of an LDS-resident row at byte offset `off` of the workgroup's LDS, widened
+// Params::touch (small forwards on cold caches): the workgroups of a plane request one dword of every row of the plane
+// — row first + k * stride, k < N per thread — right behind their sampling points, so that the rows stream into the XCD's
+// L2 while the points and the level table are on their way, and the gather's dependent trips find them there.  The
+// values are not used: retire() only keeps the loads alive (and is where the wave waits for them — behind the barrier
+// for the level table, which it waits for anyway).
+template <int N> struct Touch {
+    uint32_t v[N];
+    __device__ __forceinline__ void issue(const rsrc_t &rs, uint32_t row_bytes, int first, int stride, int rows)
+    {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int i = first + k * stride;
+            v[k] = RawLoad<4>::load(rs, i < rows ? (uint32_t)i * row_bytes : kMaskedOffset);
+        }
+    }
+    __device__ __forceinline__ void retire() const
+    {
+#pragma unroll
+        for (int k = 0; k < N; ++k) asm volatile("" ::"v"(v[k]));
+    }
+};
+
 template <typename T, int VEC> __device__ __forceinline__ void lds_row(uint32_t off, typename Traits<T>::acc (&dst)[VEC])
 {
     const Pack<T, VEC> pk = *reinterpret_cast<const Pack<T, VEC> *>(msda_smem + off);
@@ -386,8 +409,14 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
 #pragma unroll
     for (int t = 0; t < kPre; ++t) pxy[t].v[0] = pxy[t].v[1] = pa[t] = TR::from_acc((A)0);
     if (!LDSL && pre) prefetch((slot * p.qw) * NU + wave * UPW, p.Q);
+    Touch<4> touch;
+    if (p.touch) {  // (two planes per workgroup: each half touches its own plane)
+        const int nthr = two ? BLK / 2 : BLK;
+        touch.issue(rs, row_bytes, slot * nthr + (tid - half * (BLK / 2)), slots * nthr, p.I);
+    }
     load_level_table(tab, p.shapes, p.L);
     __syncthreads();
+    if (p.touch) touch.retire();
     // LDSL: levels [fl, L) live in LDS behind the records, rows D * sizeof(TV) bytes apart, then one row of zeros
     // (what a corner masked by "zeros" padding reads)
     CoarseStage cs{p.L, 0, 0, (uint32_t)p.D * (uint32_t)sizeof(TV)};
@@ -655,42 +684,45 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
 // Phase 1: lanes < L * P compute one sample's taps each and leave {offset, weight} per (sample, corner) in the wave's
 // LDS slice; phase 2: lane (r, j) blends the pairs r, r + R, ...; the R partial rows meet through lane shuffles.
 // ==========================================================================================
+// The arguments in front of `p` are the ones the first round of loads needs (sampling points, weights, level sizes):
+// the build asks for them to be PRELOADED into SGPRs at wave launch (-amdgpu-kernarg-preload-count, Makefile), so that
+// round leaves without waiting for the kernel-argument segment — one memory trip less in a chain of four.
 template <typename T, int VEC, typename TV = T>
-__global__ __launch_bounds__(kWave) void msda_fwd_unit_kernel(const Params p)
+__global__ __launch_bounds__(kWave) void msda_fwd_unit_kernel(const void *a_loc, const void *a_attn, const int64_t *a_shapes, int a_LP, int a_L,
+                                                              int a_units, const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     static_assert(sizeof(A) == 4, "float accumulation (the shuffles below move 32-bit values)");
-    request_all_arguments(p);
     // one unit per 64-thread workgroup: a few hundred one-wave workgroups land on different CUs, each with the CU's
     // texture path to itself (four-wave workgroups: +0.5 ... 0.8 us at Q = 10 ... 300, cold)
     constexpr int WPB = 1;
     const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
-    const int GL = p.D / VEC;            // lanes across a row (the host checks: a power of two, <= 64, D % VEC == 0)
-    const int R = kWave / GL;            // rows per load instruction
-    const int r = lane / GL, j = lane - r * GL;
     const int unit = (int)blockIdx.x * WPB + wave;  // (b * Q + q) * H + h
-    const int units = p.B * p.Q * p.H;
-    LevelTab *tab = reinterpret_cast<LevelTab *>(msda_smem);
-    // per wave: [4 * LP] offsets, [4 * LP] weights
-    uint32_t *w_off = reinterpret_cast<uint32_t *>(msda_smem + kGatherLdsFixed) + (size_t)wave * 8 * p.LP;
-    A *w_wgt = reinterpret_cast<A *>(w_off + 4 * p.LP);
-    const bool live = unit < units;
-    const int bq = live ? (int)fast_div((uint32_t)unit, p.div_h) : 0, h = unit - bq * p.H;
-    const int b = live ? bq / p.Q : 0;
-    // the unit's samples: requested before the level table is waited for
-    const size_t s_base = (size_t)(live ? unit : 0) * p.LP;
+    const bool live = unit < a_units;
+    // the unit's samples and the level sizes: requested from the preloaded arguments alone
+    const size_t s_base = (size_t)(live ? unit : 0) * a_LP;
     Pack<T, 2> xy;
     T at;
     xy.v[0] = xy.v[1] = at = TR::from_acc((A)0);
-    const bool has = live && lane < p.LP;
+    const bool has = live && lane < a_LP;
     if (has) {
-        xy = *reinterpret_cast<const Pack<T, 2> *>(static_cast<const T *>(p.loc) + 2 * (s_base + lane));
-        at = static_cast<const T *>(p.attn)[s_base + lane];
+        xy = *reinterpret_cast<const Pack<T, 2> *>(static_cast<const T *>(a_loc) + 2 * (s_base + lane));
+        at = static_cast<const T *>(a_attn)[s_base + lane];
     }
-    load_level_table(tab, p.shapes, p.L);
+    LevelTab *tab = reinterpret_cast<LevelTab *>(msda_smem);
+    load_level_table(tab, a_shapes, a_L);
     __syncthreads();
     if (!live) return;  // (wave-uniform; no barrier below)
+    request_all_arguments(p);
+    const int GL = p.D / VEC;            // lanes across a row (the host checks: a power of two, <= 64, D % VEC == 0)
+    const int R = kWave / GL;            // rows per load instruction
+    const int r = lane / GL, j = lane - r * GL;
+    // per wave: [4 * LP] offsets, [4 * LP] weights
+    uint32_t *w_off = reinterpret_cast<uint32_t *>(msda_smem + kGatherLdsFixed) + (size_t)wave * 8 * p.LP;
+    A *w_wgt = reinterpret_cast<A *>(w_off + 4 * p.LP);
+    const int bq = (int)fast_div((uint32_t)unit, p.div_h), h = unit - bq * p.H;
+    const int b = bq / p.Q;
     const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TV);
     const TV *plane = static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
     const rsrc_t rs = make_rsrc(plane, (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV)));

@@ -137,6 +137,20 @@ inline bool plane_grid(Params &p, int npairs, int64_t slots, dim3 &grid)
     return true;
 }
 
+// Params::touch (msda_kernels.hpp, Touch; option "touch": 0 never, 2 always, 1 = this rule): calls whose samples will read
+// most rows of the pyramid anyway (4 Q L P taps >= 2 I rows per plane) and that are small enough for a cold start to be what
+// they cost.  In-process A/B, B = 4, H = 8, c2 pyramid, caches AND Infinity Cache flushed (tools/small_q_cold.py --flush 1024):
+// Q = 500 19.9 -> 19.0 us, 900 26.2 -> 22.8, 1000 26.6 -> 23.2, 2000 35.4 -> 32.9; rows cached (--warm): 12.76 -> 12.88 at 900.
+// (The one-wave-per-unit kernel does not touch: its waves all start together, the touches only queue in front of the rows
+// they want — Q = 100 10.7 -> 15.0 us, 300 15.7 -> 17.5.)
+int option_touch();
+inline int touch_plan(const Dims &d)
+{
+    const int o = option_touch();
+    if (o != 1) return o == 2;
+    return d.Q * d.L * d.P * 4 >= 2 * d.I && d.B * d.Q * d.H <= 65536;
+}
+
 inline FastDiv make_fast_div(uint32_t d)
 {
     FastDiv fd{0, 0};
@@ -339,7 +353,7 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, typename TS = T
             auto kernel = msda_fwd_unit_kernel<T, VEC, TV>;
             static std::atomic<uint64_t> big_lds_unit{0};
             allow_big_lds(kernel, big_lds_unit);
-            hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(kWave), ulds, stream, p);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(kWave), ulds, stream, p.loc, p.attn, p.shapes, p.LP, p.L, (int)units, p);
             return (int)hipGetLastError();
         }
     }
@@ -679,6 +693,7 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
     p.out = out;
     fill_params(p, d, padding_mode, align_corners);
     p.vrow_bytes = (int)(d.D * (int64_t)sizeof(TV));
+    p.touch = touch_plan(d);
     const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
     rc = dispatch_gather<T, 0, TV>(p, vec_ok, stream);
     if (rc > 0) set_error("forward launch failed: %s", hipGetErrorString((hipError_t)rc));  // negative: message already set

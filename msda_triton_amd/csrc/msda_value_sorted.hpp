@@ -454,7 +454,7 @@ template <typename T, int VEC, int G, int GB, typename TG = T>
 __global__ __launch_bounds__(GB, (VEC == 8 && G > 4) ? 1 : 4) void msda_value_gather_kernel(const Params p)
 {
     using A = typename Traits<T>::acc;
-    using TR = Traits<T>;
+    using TR [[maybe_unused]] = Traits<T>;
     constexpr int kGatherItemBlock = GB;  // threads per workgroup
     constexpr int NU = kGatherItemBlock / G;
     constexpr int UB = G < 8 ? G : 8;  // row loads in flight per lane

@@ -7,7 +7,7 @@ comparator written for this repo (scripts/triton_comparator.py — not the refer
 
 Timing follows triton.testing.do_bench's recipe (which the reference uses): ~100 ms warm-up, ~1 s of
 repetitions, one HIP-event pair per repetition, an L2-sized buffer zeroed before each, median and the
-20 / 80 % quantiles.  Results go to outputs/benchmark_results/*.csv.
+20 / 80 % quantiles — behind 0.7 s of the same loop unmeasured (--spin-up-ms; see do_bench).  Results go to outputs/benchmark_results/*.csv.
 
 The three plots the reference ships (assets/images/msda *.png; benchmark.py:177-180 saves them next to the CSV) are
 written as PNGs beside the CSV: forward ms, forward+backward ms and peak memory over the number of queries.
@@ -26,12 +26,29 @@ from msda_triton_amd import multiscale_deformable_attention, native_multiscale_d
 
 SHAPES = [(64, 64), (32, 32), (16, 16), (8, 8)]
 B, H, C, P = 4, 8, 32, 4
+SPIN_UP_MS = 700.0  # (--spin-up-ms)
+# Bytes zeroed before every repetition (--flush-mib).  256 MiB is triton.testing.do_bench's figure — enough for the L2s,
+# but exactly the size of the 256 MB Infinity Cache behind them: how much of the inputs survives there depends on what
+# ran before (tools/cold_state_probe.py: the same call reads 25.3 us on fresh inputs, 21.6 after a plain img.sum(), 20.4
+# after one call in another block order, 25.7 again after 1 GiB of zeros).  1024 makes "cold" mean HBM for everybody.
+FLUSH_MIB = 256
 
 
-def do_bench(fn, warmup_ms=100.0, rep_ms=1000.0):
+def do_bench(fn, warmup_ms=100.0, rep_ms=1000.0, spin_ms=None):
+    import time
     fn()
     torch.cuda.synchronize()
-    flush = torch.empty(256 << 20, dtype=torch.int8, device="cuda")
+    flush = torch.empty(FLUSH_MIB << 20, dtype=torch.int8, device="cuda")
+    # Spin-up (every provider alike): the measured loop itself — flush, call — for SPIN_UP_MS of wall time first.  A GPU
+    # that has just idled (the inputs were being made, the previous result reduced on the host) serves the first ~0.5 s
+    # of this loop 20-25 % slower than the rest (tools/small_q_cold.py --reps 3: the first option after make_inputs reads
+    # 22.6 us at Q = 900, every later one 17.3), so whoever was measured first looked slow.  0 turns it off.
+    t_end = time.perf_counter() + (SPIN_UP_MS if spin_ms is None else spin_ms) * 1e-3
+    while time.perf_counter() < t_end:
+        for _ in range(20):
+            flush.zero_()
+            fn()
+        torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(5):
@@ -67,6 +84,7 @@ def make_inputs(N, requires_grad):
 
 
 def main():
+    global SPIN_UP_MS, FLUSH_MIB
     ap = argparse.ArgumentParser()
     ap.add_argument("--queries", type=int, nargs="+", default=[10, 100, 300, 900, 1000, 10000])
     ap.add_argument("--no-native", action="store_true")
@@ -74,7 +92,13 @@ def main():
     ap.add_argument("--no-triton", action="store_true", help="leave out the Triton comparator (scripts/triton_comparator.py)")
     ap.add_argument("--out", default="outputs/benchmark_results")
     ap.add_argument("--fwd-only", action="store_true", help="forward timings only (development: the small-Q latency work)")
+    ap.add_argument("--flush-mib", type=int, default=FLUSH_MIB,
+                    help="MiB zeroed before every repetition: 256 = the reference recipe (L2-cold, Infinity Cache undefined), 1024 = HBM-cold")
+    ap.add_argument("--spin-up-ms", type=float, default=SPIN_UP_MS,
+                    help="wall time of the flush + call loop run before every measurement (do_bench); 0: none")
     args = ap.parse_args()
+    SPIN_UP_MS = args.spin_up_ms
+    FLUSH_MIB = args.flush_mib
     providers = {"hip": multiscale_deformable_attention}
     if not args.no_native:
         providers["torch"] = native_multiscale_deformable_attention

@@ -169,3 +169,30 @@ def test_two_planes_per_workgroup_fused_forward_and_backward_are_bit_identical(r
     for key in ("one", "two"):
         for a, b in zip(res["plain"], res[key]):
             assert torch.equal(a, b), key
+
+
+@pytest.mark.parametrize("lds", [0, 2], ids=["plain", "lds_levels"])
+@pytest.mark.parametrize("name", ["c2_like_f32", "nothing_fits", "odd_points_boundary", "bf16_g4", "fp16_d64", "f64", "d64_f32_g16"])
+def test_touched_rows_do_not_change_the_forward(name, lds):
+    """``touch``: the workgroups request one dword of every row of their plane at the start (a cache warm-up for forwards of
+    few queries, msda_launch.hpp ``touch_plan``); the values are dropped, so forcing it (2) must give the bits of never (0) —
+    also with two planes per workgroup, where each half of the workgroup touches its own plane, with rows beyond the
+    touched range (I > 4 rows per thread x threads) and with pyramids shorter than one round of touches."""
+    from msda_triton_amd import _lib
+    B, Q, H, D, levels, P, td = CASES[name]
+    c = rand_case(np.random.default_rng(zlib.crc32(name.encode()) + 3), B, Q, H, D, levels, P,
+                  dtype=np.float64 if td == torch.float64 else np.float32)
+    old = {k: _lib.get_option(k) for k in ("touch", "lds_planes")}
+    try:
+        outs = {}
+        for planes in (1, 2):
+            _lib.set_option("lds_planes", planes)
+            for t in (0, 2, 1):
+                _lib.set_option("touch", t)
+                outs[planes, t] = _forward(c, td, "zeros", False, lds)
+        first = outs[1, 0]
+        for k, o in outs.items():
+            assert torch.equal(first, o), k
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)

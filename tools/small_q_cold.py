@@ -18,6 +18,20 @@ args = sys.argv[1:]
 want_triton = "--triton" in args
 if "--warm" in args:  # back-to-back instead of the flushed cache
     torch.Tensor.zero_ = lambda self: self
+reps = 2
+spin = 0.0
+if "--spin" in args:  # ms of the sweep's spin-up in front of every measurement (default here: none)
+    i = args.index("--spin")
+    spin = float(args[i + 1])
+    del args[i:i + 2]
+if "--flush" in args:  # MiB zeroed before every repetition (256: the recipe; 1024: also the Infinity Cache)
+    i = args.index("--flush")
+    sweep.FLUSH_MIB = int(args[i + 1])
+    del args[i:i + 2]
+if "--reps" in args:  # repetitions of the whole option list (the first measurement after make_inputs tends to read high)
+    i = args.index("--reps")
+    reps = int(args[i + 1])
+    del args[i:i + 2]
 args = [a for a in args if a not in ("--triton", "--warm", "--floor")]
 split = args.index("--") if "--" in args else len(args)
 qs = [int(a) for a in args[:split]] or [10, 100, 300, 900, 1000]
@@ -47,18 +61,22 @@ for N in qs:
         with torch.no_grad():
             multiscale_deformable_attention(img, shapes, pts, att, "border", True)
 
+    def tfwd():
+        with torch.no_grad():
+            tc.triton_comparator_msda(img, shapes, pts, att, "border", True)
+
+    have_triton = tc is not None and tc.HAVE_TRITON
+    if have_triton:
+        tfwd()  # (compile + autotune before anything is measured)
     line = {}
-    for rep in range(2):
+    for rep in range(reps):  # the comparator takes its turn in every round, like an option
         for o in opts:
             apply(o, defaults)
-            line.setdefault(o, []).append(sweep.do_bench(fwd, warmup_ms=30.0, rep_ms=300.0)[0] * 1e3)
-    apply("-", defaults)
-    if tc is not None and tc.HAVE_TRITON:
-        def tfwd():
-            with torch.no_grad():
-                tc.triton_comparator_msda(img, shapes, pts, att, "border", True)
-        line["triton"] = [sweep.do_bench(tfwd, warmup_ms=30.0, rep_ms=300.0)[0] * 1e3 for _ in range(2)]
+            line.setdefault(o, []).append(sweep.do_bench(fwd, warmup_ms=30.0, rep_ms=300.0, spin_ms=spin)[0] * 1e3)
+        apply("-", defaults)
+        if have_triton:
+            line.setdefault("triton", []).append(sweep.do_bench(tfwd, warmup_ms=30.0, rep_ms=300.0, spin_ms=spin)[0] * 1e3)
     if "--floor" in sys.argv:  # a kernel that does nothing, by the same recipe: what of the figures is the launch itself
         tiny = torch.zeros(64, device=img.device)
-        line["floor(fill 64 floats)"] = [sweep.do_bench(lambda: tiny.fill_(1.0), warmup_ms=30.0, rep_ms=300.0)[0] * 1e3 for _ in range(2)]
+        line["floor(fill 64 floats)"] = [sweep.do_bench(lambda: tiny.fill_(1.0), warmup_ms=30.0, rep_ms=300.0, spin_ms=spin)[0] * 1e3 for _ in range(2)]
     print("Q=%5d " % N + "  ".join("%s: %s us" % (k, "/".join("%.2f" % x for x in v)) for k, v in line.items()), flush=True)
