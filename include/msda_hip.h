@@ -219,12 +219,13 @@ MSDA_API const char *msda_last_error(void);
  *   "unit_fwd"   1 (default): forwards of at most 12 288 (b, q, h) units take the one-wave-per-unit kernel (decoder
  *                   calls: cold-cache forward at Q = 100 12.8 -> 9.3 us);  0: never;  2: wherever it exists (tests)
  *   "touch"      1 (default): a forward of few queries that will read most of the pyramid anyway (4 Q L P >= 2 I, at most
- *                   65 536 (b, q, h) units, not the one-wave-per-unit kernel) has its workgroups request one dword of every
- *                   row of their plane behind their first sampling points, so that the rows stream into the XCD's L2
- *                   while the points are on their way: with the pyramid in HBM (nothing in L2 or the Infinity Cache)
- *                   forward at B = 4, H = 8, Q = 900 26.2 -> 22.8 us, Q = 500 19.9 -> 19.0; nothing when the rows are
- *                   cached (+0.1 us); the values are not used, results are bit-identical;  0: never;  2: every forward
- *                   through msda_fwd_kernel (tests)
+ *                   65 536 (b, q, h) units, one round of workgroups with at most 768 rows of the plane each, not the
+ *                   one-wave-per-unit kernel) has its workgroups request one dword of every row of their plane behind
+ *                   their first sampling points, so that the rows stream into the XCD's L2 while the points are on their
+ *                   way: with the pyramid in HBM (nothing in L2 or the Infinity Cache) forward at B = 4, H = 8, Q = 900
+ *                   26.6 -> 22.7 us, Q = 2000 35.8 -> 32.9; nothing measurable when the rows are cached (larger shares
+ *                   per workgroup do cost then: hence the 768); the values are not used, results are bit-identical;
+ *                   0: never;  2: every forward through msda_fwd_kernel (tests)
  *   "value_path" 0 (default): grad_value by the single-launch LDS kernel when a (plane, level) fits one workgroup
  *                   (small problems; no workspace needed), else by the sorted gather in the caller's workspace
  *                2: the sorted gather always   3: the single-launch kernel whenever it fits

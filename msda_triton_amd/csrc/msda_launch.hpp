@@ -140,15 +140,27 @@ inline bool plane_grid(Params &p, int npairs, int64_t slots, dim3 &grid)
 // Params::touch (msda_kernels.hpp, Touch; option "touch": 0 never, 2 always, 1 = this rule): calls whose samples will read
 // most rows of the pyramid anyway (4 Q L P taps >= 2 I rows per plane) and that are small enough for a cold start to be what
 // they cost.  In-process A/B, B = 4, H = 8, c2 pyramid, caches AND Infinity Cache flushed (tools/small_q_cold.py --flush 1024):
-// Q = 500 19.9 -> 19.0 us, 900 26.2 -> 22.8, 1000 26.6 -> 23.2, 2000 35.4 -> 32.9; rows cached (--warm): 12.76 -> 12.88 at 900.
+// Q = 500 19.9 -> 19.0 us, 900 26.2 -> 22.8, 1000 26.6 -> 23.2 (2000, two rounds of workgroups: 35.4 -> 32.9, given up for
+// touch_settle's rule below).
 // (The one-wave-per-unit kernel does not touch: its waves all start together, the touches only queue in front of the rows
 // they want — Q = 100 10.7 -> 15.0 us, 300 15.7 -> 17.5.)
 int option_touch();
 inline int touch_plan(const Dims &d)
 {
     const int o = option_touch();
-    if (o != 1) return o == 2;
+    if (o != 1) return o;  // (2: forced)
     return d.Q * d.L * d.P * 4 >= 2 * d.I && d.B * d.Q * d.H <= 65536;
+}
+// ... and, known once the grid is: only launches of ONE round of workgroups in which a workgroup touches at most 768 rows.
+// The touches go through the texture path in front of the workgroup's first samples (one row per lane: 64 tag look-ups per
+// wave instruction), which is free while everything waits for memory and is not when the rows are already in L2: c4 (64
+// planes x 4 workgroups, 1 360 rows each) 23.7 -> 26.5 us warm with the touches; c2 @ 1k and c1 (680 rows each) unchanged
+// within +-0.5 us (rocprofv3, options alternated on one box).
+int device_cu_count();
+inline void touch_settle(Params &p, const dim3 &grid, long long slots)
+{
+    if (p.touch == 1 && ((long long)grid.x * grid.y * grid.z > device_cu_count() || (p.I + slots - 1) / slots > 768)) p.touch = 0;
+    if (p.touch == 2) p.touch = 1;
 }
 
 inline FastDiv make_fast_div(uint32_t d)
@@ -320,6 +332,7 @@ template <typename T, int VEC, int G, int MODE, typename TV, typename TS = T> in
         return MSDA_ERR_TOO_LARGE;
     }
     if (pl.rotate && p.xcd_map == 1) p.xcd_map = 2;  // (this launch only: plane_grid sets it afresh for the next one)
+    touch_settle(p, grid, pl.slots);
     static std::atomic<uint64_t> big_lds_done{0};
     const ProfileScope prof(MODE == 0 || MODE == 2 ? "msda_fwd_kernel" : "msda_bwd_sample_kernel", stream);
     if constexpr (MODE == 0 || MODE == 2) {
@@ -388,6 +401,7 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, typename TS = T
     // that an XCD's planes belong to different heads and the dispatcher, which hands its CUs the next workgroup as they come
     // free, levels a head whose rows gather slower.  c3: sample gradients 84.7 -> 81.0 us, forward 76.2 -> 75.1.
     if (p.xcd_map == 1 && npairs >= 16 && slots >= 32) p.xcd_map = 2;
+    touch_settle(p, grid, slots);
     static std::atomic<uint64_t> big_lds_done{0};  // one per template instantiation
     const ProfileScope prof(MODE == 0 || MODE == 2 ? "msda_fwd_kernel" : "msda_bwd_sample_kernel", stream);
     if constexpr (MODE == 3) {
