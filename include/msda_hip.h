@@ -218,6 +218,8 @@ MSDA_API const char *msda_last_error(void);
  *                   (c2 @ 10k forward 69.5 -> 64.3 us; bit-identical results);  1: never;  2: whenever H is even (tests)
  *   "unit_fwd"   1 (default): forwards of at most 12 288 (b, q, h) units take the one-wave-per-unit kernel (decoder
  *                   calls: cold-cache forward at Q = 100 12.8 -> 9.3 us);  0: never;  2: wherever it exists (tests)
+ *   "unit_waves" 1 (default): that kernel serves one unit per wave;  2: two (one per half wave) where its rows allow it:
+ *                   ~1 us faster at Q = 200-300 with the pyramid in HBM, 0.3-0.6 us slower with it cached
  *   "touch"      1 (default): a forward of few queries that will read most of the pyramid anyway (4 Q L P >= 2 I, at most
  *                   65 536 (b, q, h) units, one round of workgroups with at most 768 rows of the plane each, not the
  *                   one-wave-per-unit kernel) has its workgroups request one dword of every row of their plane behind

@@ -687,50 +687,61 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlo
 // The arguments in front of `p` are the ones the first round of loads needs (sampling points, weights, level sizes):
 // the build asks for them to be PRELOADED into SGPRs at wave launch (-amdgpu-kernarg-preload-count, Makefile), so that
 // round leaves without waiting for the kernel-argument segment — one memory trip less in a chain of four.
-template <typename T, int VEC, typename TV = T>
+// U (1 or 2): units per wave.  U = 2 gives each half of the wave a unit: the same instructions serve two units (most of
+// phase 1 runs with 16 of 64 lanes doing anything), a unit's rows take twice the load instructions, all still in flight
+// together.  Measured (msda_launch.hpp): ahead by ~1 us at Q = 200-300 when the rows come from HBM, behind by 0.3-0.6 us
+// when they are cached — option "unit_waves", off by default.
+template <typename T, int VEC, typename TV = T, int U = 1>
 __global__ __launch_bounds__(kWave) void msda_fwd_unit_kernel(const void *a_loc, const void *a_attn, const int64_t *a_shapes, int a_LP, int a_L,
                                                               int a_units, const Params p)
 {
     using A = typename Traits<T>::acc;
     using TR = Traits<T>;
     static_assert(sizeof(A) == 4, "float accumulation (the shuffles below move 32-bit values)");
-    // one unit per 64-thread workgroup: a few hundred one-wave workgroups land on different CUs, each with the CU's
+    static_assert(U == 1 || U == 2, "one unit per wave or per half wave");
+    // one WAVE per 64-thread workgroup: a few hundred one-wave workgroups land on different CUs, each with the CU's
     // texture path to itself (four-wave workgroups: +0.5 ... 0.8 us at Q = 10 ... 300, cold)
-    constexpr int WPB = 1;
-    const int tid = threadIdx.x, wave = tid / kWave, lane = tid % kWave;
-    const int unit = (int)blockIdx.x * WPB + wave;  // (b * Q + q) * H + h
+    constexpr int UL = kWave / U;  // lanes of a unit
+    const int lane = threadIdx.x % kWave;
+    const int part = lane / UL, ul = lane - part * UL;  // the lane's unit inside the wave, the lane inside the unit
+    const int unit = (int)blockIdx.x * U + part;  // (b * Q + q) * H + h
     const bool live = unit < a_units;
     // the unit's samples and the level sizes: requested from the preloaded arguments alone
     const size_t s_base = (size_t)(live ? unit : 0) * a_LP;
     Pack<T, 2> xy;
     T at;
     xy.v[0] = xy.v[1] = at = TR::from_acc((A)0);
-    const bool has = live && lane < a_LP;
+    const bool has = live && ul < a_LP;
     if (has) {
-        xy = *reinterpret_cast<const Pack<T, 2> *>(static_cast<const T *>(a_loc) + 2 * (s_base + lane));
-        at = static_cast<const T *>(a_attn)[s_base + lane];
+        xy = *reinterpret_cast<const Pack<T, 2> *>(static_cast<const T *>(a_loc) + 2 * (s_base + ul));
+        at = static_cast<const T *>(a_attn)[s_base + ul];
     }
     LevelTab *tab = reinterpret_cast<LevelTab *>(msda_smem);
     load_level_table(tab, a_shapes, a_L);
     __syncthreads();
-    if (!live) return;  // (wave-uniform; no barrier below)
+    if (U == 1 && !live) return;  // (wave-uniform; no barrier below)
     request_all_arguments(p);
-    const int GL = p.D / VEC;            // lanes across a row (the host checks: a power of two, <= 64, D % VEC == 0)
-    const int R = kWave / GL;            // rows per load instruction
-    const int r = lane / GL, j = lane - r * GL;
-    // per wave: [4 * LP] offsets, [4 * LP] weights
-    uint32_t *w_off = reinterpret_cast<uint32_t *>(msda_smem + kGatherLdsFixed) + (size_t)wave * 8 * p.LP;
+    const int GL = p.D / VEC;            // lanes across a row (the host checks: a power of two, <= 64 / U, D % VEC == 0)
+    const int R = UL / GL;               // rows of a unit per load instruction
+    const int r = ul / GL, j = ul - r * GL;
+    // per unit of the wave: [4 * LP] offsets, [4 * LP] weights
+    uint32_t *w_off = reinterpret_cast<uint32_t *>(msda_smem + kGatherLdsFixed) + (size_t)part * 8 * p.LP;
     A *w_wgt = reinterpret_cast<A *>(w_off + 4 * p.LP);
-    const int bq = (int)fast_div((uint32_t)unit, p.div_h), h = unit - bq * p.H;
-    const int b = bq / p.Q;
+    const int u_ = live ? unit : 0;
+    const int bq = (int)fast_div((uint32_t)u_, p.div_h), h = u_ - bq * p.H;
+    const int b = U == 1 ? bq / p.Q : (int)fast_div((uint32_t)bq, p.div_win);  // (U == 2: the host put Q's divider into div_win)
     const uint32_t row_bytes = (uint32_t)(p.H * p.D) * (uint32_t)sizeof(TV);
-    const TV *plane = static_cast<const TV *>(p.value) + (size_t)b * p.I * p.H * p.D + (size_t)h * p.D;
-    const rsrc_t rs = make_rsrc(plane, (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV)));
-    for (int s0 = 0; s0 < p.LP; s0 += kWave) {  // (L * P <= 64: one trip)
-        const int sl = s0 + lane;
+    // U == 2: the halves may sit on different planes, so the descriptor covers the whole tensor and the plane is an offset
+    // (the host checks B * I * H * D * sizeof < 2^31 for this variant)
+    const TV *plane = static_cast<const TV *>(p.value) + (U == 1 ? (size_t)b * p.I * p.H * p.D + (size_t)h * p.D : (size_t)0);
+    const rsrc_t rs = make_rsrc(plane, U == 1 ? (uint32_t)(((size_t)p.I * p.H * p.D - (size_t)h * p.D) * sizeof(TV))
+                                                : (uint32_t)((size_t)p.B * p.I * p.H * p.D * sizeof(TV)));
+    const uint32_t plane_off = U == 1 ? 0u : (uint32_t)(((size_t)b * p.I * p.H * p.D + (size_t)h * p.D) * sizeof(TV));
+    for (int s0 = 0; s0 < p.LP; s0 += UL) {  // (L * P <= 64 / U: one trip)
+        const int sl = s0 + ul;
         if (s0 > 0) {
             wave_lds_sync();
-            if (sl < p.LP) {
+            if (live && sl < p.LP) {
                 xy = *reinterpret_cast<const Pack<T, 2> *>(static_cast<const T *>(p.loc) + 2 * (s_base + sl));
                 at = static_cast<const T *>(p.attn)[s_base + sl];
             }
@@ -738,7 +749,7 @@ __global__ __launch_bounds__(kWave) void msda_fwd_unit_kernel(const void *a_loc,
         if (sl < p.LP) {
             const int l = div_small(sl, p.P, 1.0f / (float)p.P);
             Taps<A> t;
-            make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], tab->start[l], p.zeros, p.align, row_bytes, t);
+            make_taps<A>(TR::to_acc(xy.v[0]), TR::to_acc(xy.v[1]), tab->h[l], tab->w[l], tab->start[l], p.zeros, p.align, row_bytes, t, plane_off);
             const A a = TR::to_acc(at), wy0 = (A)1 - t.dy, wx0 = (A)1 - t.dx;
             *reinterpret_cast<uint4 *>(w_off + 4 * sl) = make_uint4(t.off[0], t.off[1], t.off[2], t.off[3]);
             Rec4<A> w;
@@ -758,7 +769,7 @@ __global__ __launch_bounds__(kWave) void msda_fwd_unit_kernel(const void *a_loc,
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = (A)0;
     using RLV = RawLoad<sizeof(TV) * VEC>;
-    constexpr int kFly = 8;  // load instructions in flight together
+    constexpr int kFly = 8 * U;  // load instructions in flight together
     for (int p0 = r; p0 < npairs; p0 += kFly * R) {
         Pack<TV, VEC> v[kFly];
         A wv[kFly];
@@ -777,11 +788,11 @@ __global__ __launch_bounds__(kWave) void msda_fwd_unit_kernel(const void *a_loc,
         }
     }
     // the R partial rows of the unit: lanes j, j + GL, j + 2 GL, ... hold the same channels
-    for (int m = GL; m < kWave; m <<= 1) {
+    for (int m = GL; m < UL; m <<= 1) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] += __shfl_xor(acc[i], m, kWave);
     }
-    if (r == 0) {
+    if (r == 0 && live) {
         Pack<T, VEC> o;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) o.v[i] = TR::from_acc(acc[i]);

@@ -202,6 +202,7 @@ int option_unit_fwd();  // 1 (default): small problems take the one-wave-per-uni
 // (b, q, h) units up to which the one-wave-per-unit forward is taken: cold-cache forward at B = 4, H = 8 (round 5, in-process
 // A/B): Q = 10 10.3 -> 7.5 us, 100 12.8 -> 9.4, 300 ~15 -> 13.2; from Q ~ 500 the general kernel is faster (900: 18-23 against 23.7)
 constexpr long long kUnitFwdMaxUnits = 12288;
+int option_unit_waves();  // 1 (default): one unit per wave; 2: two wherever the variant exists
 int option_lds_budget();  // dev knob: cap on the bytes of LDS-resident levels (-1: none)
 int option_lds_planes();   // 0 (default): two planes per LDS-level workgroup where the plan says so; 1: never; 2: whenever H is even
 int option_lds_over();     // workgroups per CU the LDS-served-level launches are cut into (1: one round)
@@ -362,11 +363,25 @@ template <typename T, int VEC, int G, int MODE, typename TV = T, typename TS = T
         if (uopt != 0 && (p.D % VEC) == 0 && gl >= 1 && gl <= kWave && (gl & (gl - 1)) == 0 && p.LP <= 1024 &&
             units <= (uopt == 2 ? (1ll << 30) : kUnitFwdMaxUnits) && units < (1ll << 31)) {
             const ProfileScope prof("msda_fwd_unit_kernel", stream);
-            const size_t ulds = kGatherLdsFixed + (size_t)8 * p.LP * 4;
-            auto kernel = msda_fwd_unit_kernel<T, VEC, TV>;
-            static std::atomic<uint64_t> big_lds_unit{0};
-            allow_big_lds(kernel, big_lds_unit);
-            hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(kWave), ulds, stream, p.loc, p.attn, p.shapes, p.LP, p.L, (int)units, p);
+            static std::atomic<uint64_t> big_lds_unit{0}, big_lds_unit2{0};
+            // two units per wave (option "unit_waves" 2; msda_kernels.hpp): faster with the rows in HBM, slower with them
+            // cached — which is the usual case, so one unit per wave is the default.  In-process A/B at B = 4, H = 8, one / two
+            // units per wave: rows in the Infinity Cache Q = 100 7.96 / 8.32 us, 200 9.60 / 9.68, 300 11.28 / 11.92; rows in
+            // HBM 100 10.4 / 10.4, 200 13.5 / 12.6, 300 16.7 / 15.4 (tools/small_q_cold.py --flush 256 / 1024).
+            const bool pairs_ok = gl <= kWave / 2 && (size_t)p.B * p.I * p.H * p.D * sizeof(TV) < ((size_t)1 << 31);
+            if (pairs_ok && option_unit_waves() == 2) {
+                p.div_win = make_fast_div((uint32_t)p.Q);  // (the forward has no other use for this field)
+                auto kernel = msda_fwd_unit_kernel<T, VEC, TV, 2>;
+                allow_big_lds(kernel, big_lds_unit2);
+                const size_t ulds = kGatherLdsFixed + (size_t)2 * 8 * p.LP * 4;
+                hipLaunchKernelGGL(kernel, dim3((unsigned)((units + 1) / 2)), dim3(kWave), ulds, stream, p.loc, p.attn, p.shapes, p.LP, p.L,
+                                   (int)units, p);
+            } else {
+                auto kernel = msda_fwd_unit_kernel<T, VEC, TV, 1>;
+                allow_big_lds(kernel, big_lds_unit);
+                const size_t ulds = kGatherLdsFixed + (size_t)8 * p.LP * 4;
+                hipLaunchKernelGGL(kernel, dim3((unsigned)units), dim3(kWave), ulds, stream, p.loc, p.attn, p.shapes, p.LP, p.L, (int)units, p);
+            }
             return (int)hipGetLastError();
         }
     }

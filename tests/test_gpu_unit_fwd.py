@@ -82,3 +82,23 @@ def test_unit_forward_is_the_default_for_decoder_calls_and_not_for_large_ones():
     _lib.set_option("unit_fwd", old)
     assert seen["c1_readme"] == {"msda_fwd_unit_kernel"}, seen
     assert seen["c4_gdino_dec"] == {"msda_fwd_kernel"}, seen
+
+
+@pytest.mark.parametrize("name", list(SHAPE_MATRIX), ids=list(SHAPE_MATRIX))
+def test_two_units_per_wave_agree_with_one(name):
+    """``unit_waves`` 2: each half of a wave serves a unit (rows of a unit over 32 lanes instead of 64: other partial sums, so
+    not bit-identical in general — but within rounding of the one-unit kernel, reproducible, and correct for an odd number
+    of units, where the last wave's second half has nothing to do)"""
+    from msda_triton_amd import _lib
+    B, Q, H, D, levels, P = SHAPE_MATRIX[name]
+    c = rand_case(np.random.default_rng(zlib.crc32(name.encode()) + 11), B, Q, H, D, levels, P)
+    old = _lib.get_option("unit_waves")
+    try:
+        outs = {}
+        for uw in (1, 2, 2):
+            _lib.set_option("unit_waves", uw)
+            outs.setdefault(uw, []).append(_forward(c, torch.float32, "zeros", False, 2))
+    finally:
+        _lib.set_option("unit_waves", old)
+    assert torch.equal(outs[2][0], outs[2][1])
+    np.testing.assert_allclose(outs[2][0].cpu().numpy(), outs[1][0].cpu().numpy(), atol=2e-5, rtol=1e-5)

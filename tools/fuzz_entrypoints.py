@@ -54,7 +54,7 @@ while time.time() - t0 < budget:
     shapes = torch.tensor(levels, dtype=torch.int64, device=dev)
     opts = {"value_path": int(rng.choice([0, 2, 3])), "small_ns": int(rng.choice([0, 0, 2, 3])),
             "lds_levels": int(rng.choice([1, 1, 2, 0])), "unit_fwd": int(rng.choice([1, 1, 0, 2])),
-            "lds_planes": int(rng.choice([0, 2, 2, 1])), "linear_slots": int(rng.choice([320, 1, 6, 40])), "touch": int(rng.choice([1, 0, 2]))}
+            "lds_planes": int(rng.choice([0, 2, 2, 1])), "linear_slots": int(rng.choice([320, 1, 6, 40])), "touch": int(rng.choice([1, 0, 2])), "unit_waves": int(rng.choice([1, 2]))}
     desc = dict(seed=seed, kind=kind, B=B, Q=Q, H=H, D=D, levels=levels, P=P, pm=pm, ac=ac, **opts)
     try:
         for k, v in opts.items():
@@ -136,7 +136,7 @@ while time.time() - t0 < budget:
         print("FAIL", json.dumps(desc), "::", str(e).strip().splitlines()[0][:300], flush=True)
     finally:
         for k in opts:
-            _lib.set_option(k, {"lds_levels": 1, "unit_fwd": 1, "linear_slots": 320, "touch": 1}.get(k, 0))
+            _lib.set_option(k, {"lds_levels": 1, "unit_fwd": 1, "linear_slots": 320, "touch": 1, "unit_waves": 1}.get(k, 0))
     n += 1
     seen[kind] = seen.get(kind, 0) + 1
     seed += 1

@@ -52,12 +52,12 @@ def make_case(seed):
             # forward (2: every problem it can serve)
             "lds_levels": int(rng.choice([1, 1, 2, 2, 0])), "unit_fwd": int(rng.choice([1, 1, 0, 2])),
             # ... two planes per LDS-level workgroup (2: whenever H is even), block order (linear from N workgroups per plane)
-            "lds_planes": int(rng.choice([0, 2, 2, 1])), "linear_slots": int(rng.choice([320, 1, 6, 40])), "touch": int(rng.choice([1, 0, 2]))}
+            "lds_planes": int(rng.choice([0, 2, 2, 1])), "linear_slots": int(rng.choice([320, 1, 6, 40])), "touch": int(rng.choice([1, 0, 2])), "unit_waves": int(rng.choice([1, 2]))}
     desc = dict(seed=seed, B=B, Q=Q, H=H, D=D, levels=levels, P=P, range=(lo, hi), pm=pm, ac=ac, f64=f64, **opts)
     return c, pm, ac, td, opts, desc, kind
 
 
-OPTION_DEFAULTS = {"lds_levels": 1, "unit_fwd": 1, "lds_planes": 0, "linear_slots": 320, "touch": 1}
+OPTION_DEFAULTS = {"lds_levels": 1, "unit_fwd": 1, "lds_planes": 0, "linear_slots": 320, "touch": 1, "unit_waves": 1}
 
 
 def run_case(c, pm, ac, td, opts):
