@@ -355,3 +355,22 @@ def test_workspace_size_queries_are_consistent():
     dec = (8, 17821, 8, 32, 900, 4, 4)
     assert lib.msda_bwd_workspace_bytes(*dec, 4, 4, 0, 0) > 0
     assert lib.msda_bwd_workspace_bytes(*dec, 4, 4, 101 * 135, 0) == 0                           # with the bound
+
+
+def test_every_documented_option_exists_with_its_documented_default():
+    """include/msda_hip.h lists the msda_set_option keys as `"key"  <default> (default)`: each must be known to the library
+    and read back that default in a fresh process (no GPU involved), and a key the header does not list must be refused."""
+    import re
+    import subprocess
+    import sys
+    text = open(os.path.join(ROOT, "include", "msda_hip.h")).read()
+    documented = {k: int(v) for k, v in re.findall(r'^ \*   "(\w+)"\s+(-?\d+) \(default\)', text, flags=re.M)}
+    assert {"xcd_map", "lds_levels", "unit_fwd", "unit_waves", "touch", "value_path", "strict", "profile"} <= set(documented), documented
+    code = ("import json; from msda_triton_amd import _lib; "
+            f"print(json.dumps({{k: _lib.get_option(k) for k in {sorted(documented)!r}}}))")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("MSDA_TEST_OPTS", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    import json
+    got = json.loads(out.strip().splitlines()[-1])
+    assert got == documented, {k: (got[k], documented[k]) for k in documented if got[k] != documented[k]}
