@@ -529,14 +529,16 @@ def shard_compute_leg(dev, strong_name, weak_name, ns=(2, 4, 8), steps=5, warmup
         leg["1"] = one
         for nn in ns:
             wl = dataclasses.replace(base, Q=base.Q * nn) if scale else base
-            r = time_shard(wl, nn)  # the forward in the pieces the overlapped exchange uses (default_overlap_chunks)
+            r = time_shard(wl, nn)  # in the pieces the operator itself picks (default_overlap_chunks: one, unless the
+            #                         forward is long enough to hide a piece's exchange)
             r["speedup_ceiling"] = round(one["fwd_bwd_ms"] / r["fwd_bwd_ms"], 3)
             r["fwd_speedup_ceiling"] = round(one["fwd_ms"] / r["fwd_ms"], 3)
             r["ideal"] = 1 if scale else nn
-            r["pieces"] = default_overlap_chunks(wl.B * wl.Q, nn)
-            r1 = time_shard(wl, nn, chunks=1)  # ... and as ONE piece (what the single in-place all-gather runs)
-            r["one_piece"] = {"fwd_ms": r1["fwd_ms"], "fwd_bwd_ms": r1["fwd_bwd_ms"],
-                              "speedup_ceiling": round(one["fwd_bwd_ms"] / r1["fwd_bwd_ms"], 3)}
+            s = wl.elem_size
+            r["pieces"] = default_overlap_chunks(wl.B * wl.Q, nn, 4 * wl.L * wl.P * wl.H * wl.D * s, wl.H * wl.D * s)
+            r4 = time_shard(wl, nn, chunks=4)  # ... and what four overlapped pieces would cost in kernel time
+            r["four_pieces"] = {"fwd_ms": r4["fwd_ms"], "fwd_bwd_ms": r4["fwd_bwd_ms"],
+                                "speedup_ceiling": round(one["fwd_bwd_ms"] / r4["fwd_bwd_ms"], 3)}
             leg[str(nn)] = r
             if on_gpu:
                 torch.cuda.empty_cache()

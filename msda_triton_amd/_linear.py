@@ -86,11 +86,28 @@ class _RowSplitLinear(torch.autograd.Function):
         return gx, gw, gb
 
 
+def _plain_linear(layer) -> bool:
+    """An ordinary ``nn.Linear`` and nothing else: not a subclass or a wrapper whose ``forward`` does more than
+    ``F.linear(x, weight, bias)`` (LoRA / PEFT adapters keep the BASE weight in ``.weight``; quantised and observer
+    layers), and no hooks of any kind that a call bypassing ``layer.__call__`` would skip."""
+    if type(layer) is not torch.nn.Linear:
+        return False
+    if layer._forward_hooks or layer._forward_pre_hooks or layer._backward_hooks or layer._backward_pre_hooks:
+        return False
+    if getattr(layer, "_forward_hooks_with_kwargs", None) or getattr(layer, "_forward_pre_hooks_with_kwargs", None):
+        return False
+    g = torch.nn.modules.module
+    return not (g._global_forward_hooks or g._global_forward_pre_hooks or g._global_backward_hooks
+                or g._global_backward_pre_hooks)
+
+
 def projection(layer: torch.nn.Linear, x: torch.Tensor) -> torch.Tensor:
-    """``layer(x)``; on a GPU with many rows through the row-split weight gradient above."""
+    """``layer(x)``; on a GPU with many rows through the row-split weight gradient above — only for a plain, hook-free
+    ``nn.Linear`` (the reference module always calls the layer itself, frontend.py:253-267: whatever a user hung on it —
+    forward hooks, a LoRA wrapper, a quantised replacement — has to run)."""
     if x.device.type == "cuda" and x.dim() >= 2 and x.numel() // x.shape[-1] >= ROW_SPLIT_MIN_ROWS and \
             torch.is_grad_enabled() and x.is_floating_point() and not torch.compiler.is_compiling() and \
-            (layer.weight.requires_grad or x.requires_grad) and \
+            _plain_linear(layer) and (layer.weight.requires_grad or x.requires_grad) and \
             (torch.is_autocast_enabled("cuda") or x.dtype == layer.weight.dtype):
         return _RowSplitLinear.apply(x, layer.weight, layer.bias)
     return layer(x)

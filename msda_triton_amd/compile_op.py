@@ -99,8 +99,11 @@ def msda_fused_forward(img: torch.Tensor, img_shapes: torch.Tensor, proj: torch.
                        zeros: bool, align_corners: bool, level_cells: int = 0) -> torch.Tensor:
     out = F.msda_hip_fwd_fused(img, img_shapes, proj, reference_points, _PAD[zeros], align_corners)
     if out is None:  # (callers check fused_lp_ok first; kept for safety)
-        pts, att = F.module_sampling_inputs(proj, img_shapes, reference_points)
-        out = F.msda_hip_fwd(img, img_shapes, pts, att, _PAD[zeros], align_corners)
+        # as the eager fallback (_HipFusedModuleCoreFunction): with 16-bit storage next to fp32 reference points the
+        # prologue runs in fp32 over the mixed-storage operator and the result returns to the projection's dtype —
+        # what the fake kernel promises
+        pts, att = F.module_sampling_inputs(proj.to(reference_points.dtype), img_shapes, reference_points)
+        out = F.msda_hip_fwd(img, img_shapes, pts, att, _PAD[zeros], align_corners).to(proj.dtype)
     return out
 
 

@@ -38,6 +38,7 @@ static std::atomic<int> g_lds_planes{0};
 static std::atomic<int> g_linear_slots{320};
 static std::atomic<int> g_touch{1};
 static std::atomic<int> g_unit_waves{1};
+static std::atomic<int> g_value_row_stride{0};  // experiment (round 6): bytes between the pixels' rows of `value` (0: dense)
 static std::atomic<int> g_lds_stagger{0};  // (measured 0 / 4 / 12 / 24 at c2 @ 10k: 0 is fastest — the work counter desynchronises the waves by itself)
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
@@ -123,6 +124,7 @@ int option_linear_slots() { return g_linear_slots.load(std::memory_order_relaxed
 int option_unit_fwd() { return g_unit_fwd.load(std::memory_order_relaxed); }
 int option_touch() { return g_touch.load(std::memory_order_relaxed); }
 int option_unit_waves() { return g_unit_waves.load(std::memory_order_relaxed); }
+int option_value_row_stride() { return g_value_row_stride.load(std::memory_order_relaxed); }
 int option_lds_budget() { return g_lds_budget.load(std::memory_order_relaxed); }  // dev knob: cap on the level bytes (-1: none)
 // CUs of the current device, asked once per device (the LDS-level gather variants size their grid by it)
 int device_cu_count()
@@ -300,6 +302,7 @@ static const OptionEntry kOptions[] = {
     {"linear_slots", &g_linear_slots, 1, 1 << 30, false},
     {"touch", &g_touch, 0, 2, false},
     {"unit_waves", &g_unit_waves, 1, 2, false},
+    {"value_row_stride", &g_value_row_stride, 0, (1 << 24) - 1, true},
 };
 static const OptionEntry *find_option(const char *key)
 {

@@ -36,7 +36,8 @@ import torch
 import torch.distributed as dist
 from torch.autograd.function import Function
 
-from .functional import multiscale_deformable_attention
+from . import _lib
+from .functional import check_backward_supported, multiscale_deformable_attention
 
 
 def shard_bounds(num_queries: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -222,14 +223,28 @@ def _owner_groups(B: int, Q: int, group):
     return out
 
 
-def default_overlap_chunks(rows: int, world: int) -> int:
+# What the piece rule assumes about the machine (one MI355X node, measured where it could be: the gather rate on one GPU;
+# the link rate is the point-to-point xGMI figure a ring / direct exchange sustains in one direction)
+_GATHER_BYTES_PER_S = 30e12   # logical bytes of bilinear rows the forward gathers per second (c2: 41 TB/s, c5: 27)
+_LINK_BYTES_PER_S = 45e9      # one direction of one xGMI link
+
+
+def default_overlap_chunks(rows: int, world: int, gather_bytes_per_row: int = 0, out_bytes_per_row: int = 0) -> int:
     """Pieces a rank's rows are computed and exchanged in (the same number on every rank: it follows the nominal shard
-    size).  Piece k's exchange runs while piece k + 1 computes, so only the LAST piece's exchange is exposed: more
-    pieces hide more of it — as long as a piece stays worth a kernel launch: measured on one GPU (bench.py
-    ``shard_compute_bound``, round 5) c2's 40 000 rows per rank in 8 pieces of 5 000 rows take 0.15 ms of forward
-    against 0.07 ms in one piece (small launches, and the gather kernels' LDS-served levels need a larger grid), so a
-    piece has >= 8 192 rows: c2 weak scaling 4 pieces, c5 strong scaling over 8 ranks (50 000 rows per rank) 6."""
-    if world <= 1:
+    size).  Piece k's exchange runs while piece k + 1 computes, so pieces can hide at most the FORWARD's own time — and
+    they cost kernel time: measured on one GPU (bench.py ``shard_compute_bound``, round 5) c2's 40 000 rows per rank in
+    4 pieces take 0.095 ms of forward against 0.068 ms in one piece, in 8 pieces 0.15 ms.
+
+    So pieces are used only where the forward CAN hide a piece's exchange: its time per row (``gather_bytes_per_row`` =
+    4 * L * P * H * D * element size, at the measured gather rate) is at least half of what the row's result takes over one
+    xGMI link (``out_bytes_per_row`` = H * D * element size).  For this operator that is rare: a row of the result is
+    produced in 2-6 ns and travels for 25 (c2: ratio 0.09, c5: 0.25 — one piece, one in-place all-gather); it takes
+    L * P >= ~170 samples per unit.  Then: pieces of >= 8 192 rows, at most 8.  Without the two sizes (0): one piece."""
+    if world <= 1 or gather_bytes_per_row <= 0 or out_bytes_per_row <= 0:
+        return 1
+    t_compute = gather_bytes_per_row / _GATHER_BYTES_PER_S
+    t_exchange = out_bytes_per_row / _LINK_BYTES_PER_S
+    if t_compute < 0.5 * t_exchange:
         return 1
     return max(1, min(8, -(-rows // world) // 8192))
 
@@ -257,8 +272,19 @@ def _run_pieces(fn, num_queries: int, row0: int, row1: int):
         i += nb
 
 
+def _rows_ext(img: torch.Tensor):
+    """The C++ binding's row-range launchers for GPU tensors (one call per chunk instead of a ctypes call per piece),
+    or None: host tensors, no binding, or bench.py's per-kernel timer (which brackets the ctypes launchers)."""
+    if img.device.type != "cuda":
+        return None
+    from . import _ext
+    from .functional import KernelTimer
+    return _ext.load() if KernelTimer.active is None else None
+
+
 class _RowShardedMSDA(Function):
-    """The whole sharded operator as ONE autograd node.
+    """The sharded operator with its exchange as ONE autograd node (ranks > 1; one rank, or one rank played on one GPU,
+    takes the C++ node ``msda_rows`` of csrc/msda_torch_ext.cpp instead — same launches, no exchange).
 
     forward: this rank's rows are computed in ``chunks`` pieces, each written by the kernel STRAIGHT into its place
     in the full ``[B*Q, H, D]`` result (no local tensor, no padding, no concatenation); as soon as a piece is
@@ -268,22 +294,34 @@ class _RowShardedMSDA(Function):
     backward: this rank's rows of the incoming gradient (replicated consumers) or a reduce-scatter; the local
     backward kernels; grad_value summed as ``grad_value_sync`` says.  Every rank runs every collective, whatever its
     shard holds (an empty shard computes nothing and still takes part).
+
+    ``loopback`` (tests on ONE GPU): a one-rank group runs every collective of the N-rank code against itself — the
+    in-place all-gather, or the pieces sent to and received from its own rank through ``batch_isend_irecv`` into a
+    second buffer that becomes the result; the reduce-scatter and the grad_value sums over the one-rank group — so
+    that the RCCL calls, their views and their stream ordering are exercised where only one GPU is at hand.
     """
 
     @staticmethod
     def forward(ctx, img, img_shapes, pts_rows, att_rows, padding_mode, align_corners, num_queries, group,
-                grad_value_sync, grad_sync, owner_groups, chunks, compute_only_as=None):
+                grad_value_sync, grad_sync, owner_groups, chunks, compute_only_as=None, loopback=False):
         # compute_only_as = (world, rank): this process plays ONE rank of a larger job with every exchange left out
         # (row_sharded_multiscale_deformable_attention: the compute half of the scaling model on one GPU)
         emulated = compute_only_as is not None
         world, rank = compute_only_as if emulated else (dist.get_world_size(group), dist.get_rank(group))
+        loopback = bool(loopback) and world == 1 and not emulated
         B, _, H, D = img.shape
         Q = int(num_queries)
         rows = B * Q
         bounds = [row_shard_bounds(rows, world, r) for r in range(world)]
         r0, r1 = bounds[rank]
         gpu = img.device.type == "cuda"
+        ext = _rows_ext(img)
+        if ext is not None:  # (the launchers take what the kernels take: dense tensors, int64 level sizes)
+            img, pts_rows, att_rows = img.contiguous(), pts_rows.contiguous(), att_rows.contiguous()
+            img_shapes = img_shapes.to(torch.int64).contiguous()
+            pad_code = _lib.PADDING_MODES[padding_mode]
         full = pts_rows.new_empty((rows, H, D))  # the sampling inputs' dtype (fp32 next to a 16-bit pyramid)
+        echo = torch.empty_like(full) if loopback else None  # loopback: where the rows sent to myself arrive
         equal = all(e - b == bounds[0][1] - bounds[0][0] for b, e in bounds)
         chunks = max(1, int(chunks))
         pending = []
@@ -304,8 +342,12 @@ class _RowShardedMSDA(Function):
                         dst.copy_(multiscale_deformable_attention(img[b:b + nb], img_shapes, pts, att, padding_mode,
                                                                   align_corners))
 
-            _run_pieces(piece, Q, r0 + c0, r0 + c1)
-            if world == 1 or emulated:
+            if ext is not None:  # every piece of the chunk in one call
+                ext.rows_forward(img, img_shapes, pts_rows, att_rows, r0, full, r0 + c0, r0 + c1, Q, pad_code,
+                                 bool(align_corners))
+            else:
+                _run_pieces(piece, Q, r0 + c0, r0 + c1)
+            if emulated or (world == 1 and not loopback):
                 continue
             if chunks == 1 and equal:
                 per = r1 - r0
@@ -313,7 +355,7 @@ class _RowShardedMSDA(Function):
                 continue
             ops = []
             for peer in range(world):
-                if peer == rank:
+                if peer == rank and not loopback:
                     continue
                 gpeer = dist.get_global_rank(group, peer) if group is not None else peer
                 if c1 > c0:
@@ -321,14 +363,16 @@ class _RowShardedMSDA(Function):
                 p0, p1 = bounds[peer]
                 pc0, pc1 = _chunk_bounds(p1 - p0, chunks, k)
                 if pc1 > pc0:
-                    ops.append(dist.P2POp(dist.irecv, full[p0 + pc0:p0 + pc1], gpeer, group))
+                    ops.append(dist.P2POp(dist.irecv, (echo if loopback else full)[p0 + pc0:p0 + pc1], gpeer, group))
             if ops:
                 pending.extend(dist.batch_isend_irecv(ops))
         for req in pending:
             req.wait()
+        if loopback and not (chunks == 1 and equal):
+            full = echo  # what came back through the communicator
         ctx.save_for_backward(img, img_shapes, pts_rows, att_rows)
         ctx.meta = (padding_mode, align_corners, Q, group, grad_value_sync, grad_sync, owner_groups, world, rank, r0, r1)
-        ctx.emulated = emulated
+        ctx.emulated, ctx.loopback = emulated, loopback
         return full.view(B, Q, H, D)
 
     @staticmethod
@@ -341,7 +385,8 @@ class _RowShardedMSDA(Function):
         g_rows = grad_full.reshape(rows, H, D)
         if ctx.emulated:
             grad_value_sync, grad_sync = "none", "slice"
-        if grad_sync == "reduce_scatter" and world > 1:
+        comm = (world > 1 or ctx.loopback) and not ctx.emulated
+        if grad_sync == "reduce_scatter" and comm:
             per = -(-rows // world)
             padded = g_rows if rows == world * per else torch.nn.functional.pad(g_rows, (0, 0, 0, 0, 0, world * per - rows))
             mine = torch.empty_like(padded[:per])
@@ -350,56 +395,72 @@ class _RowShardedMSDA(Function):
         else:
             mine = g_rows[r0:r1]
         gpu = img.device.type == "cuda"
-        # Gradient tensors of the shard; the kernels write every piece straight into its slice.  A contiguous row
-        # range meets a batch element in at most one piece, so grad_value needs no accumulation: the batch elements
-        # this rank does not touch are zeroed, the others are written whole.
-        g_img = torch.empty_like(img) if need_img else None
-        g_pts = torch.empty_like(pts_rows) if need_pts else None
-        g_att = torch.empty_like(att_rows) if need_att else None
-        touched = torch.zeros(B, dtype=torch.bool)
-
-        def piece(b, nb, q0, q1, before):
-            n = (q1 - q0) if nb == 1 else nb * Q
-            pts = pts_rows[before:before + n].reshape(nb, n // nb, *pts_rows.shape[1:])
-            att = att_rows[before:before + n].reshape(nb, n // nb, *att_rows.shape[1:])
-            go = mine[before:before + n].reshape(nb, n // nb, H, D)
-            touched[b:b + nb] = True
-            if gpu:
-                from .functional import msda_hip_bwd
-                need_s = need_pts or need_att
-                dst = (g_img[b:b + nb] if need_img else None,
-                       g_pts[before:before + n].view(nb, n // nb, *pts_rows.shape[1:]) if need_pts else None,
-                       g_att[before:before + n].view(nb, n // nb, *att_rows.shape[1:]) if need_att else None)
-                msda_hip_bwd(go, img[b:b + nb], img_shapes, pts, att, padding_mode, align_corners,
-                             (need_img, need_s, need_s), out=dst)
-            else:
-                with torch.enable_grad():
-                    v_ = img[b:b + nb].detach().requires_grad_(need_img)
-                    p_ = pts.detach().requires_grad_(need_pts)
-                    a_ = att.detach().requires_grad_(need_att)
-                    o_ = multiscale_deformable_attention(v_, img_shapes, p_, a_, padding_mode, align_corners)
-                wrt = [t for t, nd in ((v_, need_img), (p_, need_pts), (a_, need_att)) if nd]
-                got = list(torch.autograd.grad(o_, wrt, go)) if wrt else []
-                if need_img:
-                    g_img[b:b + nb] = got.pop(0)
-                if need_pts:
-                    g_pts[before:before + n] = got.pop(0).reshape(n, *pts_rows.shape[1:])
-                if need_att:
-                    g_att[before:before + n] = got.pop(0).reshape(n, *att_rows.shape[1:])
-
-        _run_pieces(piece, Q, r0, r1)
-        if need_img:
-            for b in range(B):
-                if not bool(touched[b]):
-                    g_img[b].zero_()
-        if need_img and world > 1:
+        ext = _rows_ext(img)
+        if ext is not None:
+            g_img, g_pts, g_att = ext.rows_backward(mine, img, img_shapes, pts_rows, att_rows, r0, r1, Q,
+                                                    _lib.PADDING_MODES[padding_mode], bool(align_corners),
+                                                    bool(need_img), bool(need_pts), bool(need_att), 0)
+        else:
+            g_img, g_pts, g_att = _backward_pieces(mine, img, img_shapes, pts_rows, att_rows, padding_mode, align_corners,
+                                                   Q, r0, r1, need_img, need_pts, need_att, gpu)
+        if need_img and comm:
             if grad_value_sync == "all_reduce":
                 dist.all_reduce(g_img, op=dist.ReduceOp.SUM, group=group)
             elif grad_value_sync == "owners":
                 for b, (ranks, pg) in enumerate(owner_groups):  # ascending b on every rank: no cyclic waits
                     if pg is not None and rank in ranks:
                         dist.all_reduce(g_img[b], op=dist.ReduceOp.SUM, group=pg)
-        return (g_img, None, g_pts, g_att) + (None,) * 9
+        return (g_img, None, g_pts, g_att) + (None,) * 10
+
+
+def _backward_pieces(mine, img, img_shapes, pts_rows, att_rows, padding_mode, align_corners, Q, r0, r1, need_img, need_pts,
+                     need_att, gpu):
+    """The backward of rows [r0, r1) piece by piece through the Python launchers (host tensors, installations without
+    the C++ binding, bench.py's per-kernel timer).  Gradient tensors of the shard; the kernels write every piece
+    straight into its slice.  A contiguous row range meets a batch element in at most one piece, so grad_value needs
+    no accumulation: the batch elements this rank does not touch are zeroed, the others are written whole."""
+    B, _, H, D = img.shape
+    g_img = torch.empty_like(img) if need_img else None
+    g_pts = torch.empty_like(pts_rows) if need_pts else None
+    g_att = torch.empty_like(att_rows) if need_att else None
+    touched = [False] * B
+
+    def piece(b, nb, q0, q1, before):
+        n = (q1 - q0) if nb == 1 else nb * Q
+        pts = pts_rows[before:before + n].reshape(nb, n // nb, *pts_rows.shape[1:])
+        att = att_rows[before:before + n].reshape(nb, n // nb, *att_rows.shape[1:])
+        go = mine[before:before + n].reshape(nb, n // nb, H, D)
+        for k in range(b, b + nb):
+            touched[k] = True
+        if gpu:
+            from .functional import msda_hip_bwd
+            need_s = need_pts or need_att
+            dst = (g_img[b:b + nb] if need_img else None,
+                   g_pts[before:before + n].view(nb, n // nb, *pts_rows.shape[1:]) if need_pts else None,
+                   g_att[before:before + n].view(nb, n // nb, *att_rows.shape[1:]) if need_att else None)
+            msda_hip_bwd(go, img[b:b + nb], img_shapes, pts, att, padding_mode, align_corners,
+                         (need_img, need_s, need_s), out=dst)
+        else:
+            with torch.enable_grad():
+                v_ = img[b:b + nb].detach().requires_grad_(need_img)
+                p_ = pts.detach().requires_grad_(need_pts)
+                a_ = att.detach().requires_grad_(need_att)
+                o_ = multiscale_deformable_attention(v_, img_shapes, p_, a_, padding_mode, align_corners)
+            wrt = [t for t, nd in ((v_, need_img), (p_, need_pts), (a_, need_att)) if nd]
+            got = list(torch.autograd.grad(o_, wrt, go)) if wrt else []
+            if need_img:
+                g_img[b:b + nb] = got.pop(0)
+            if need_pts:
+                g_pts[before:before + n] = got.pop(0).reshape(n, *pts_rows.shape[1:])
+            if need_att:
+                g_att[before:before + n] = got.pop(0).reshape(n, *att_rows.shape[1:])
+
+    _run_pieces(piece, Q, r0, r1)
+    if need_img:
+        for b in range(B):
+            if not touched[b]:
+                g_img[b].zero_()
+    return g_img, g_pts, g_att
 
 
 def row_sharded_multiscale_deformable_attention(
@@ -416,16 +477,22 @@ def row_sharded_multiscale_deformable_attention(
     grad_sync: Literal["slice", "reduce_scatter"] = "slice",
     overlap_chunks: Optional[int] = None,
     compute_only_as: Optional[Tuple[int, int]] = None,
+    loopback: bool = False,
 ) -> torch.Tensor:
     """Row-sharded operator; returns the full ``[B, Q, H, D]`` output on every rank.
 
     ``compute_only_as=(world, rank)`` (measurement aid, no process group needed): run exactly what rank ``rank`` of a
     ``world``-rank job computes — its rows, in the same pieces, through the same kernels — and leave every exchange
-    out.  Only that rank's rows of the result (and its share of the gradients) are meaningful.  ``bench.py``'s
+    out: ``grad_value_sync`` and ``grad_sync`` are then overridden to ``"none"`` / ``"slice"`` whatever was passed.  Only
+    that rank's rows of the result (and its share of the gradients) are meaningful.  ``bench.py``'s
     ``shard_compute_bound`` leg times it on one GPU: the speed-up ceiling before any byte crosses xGMI.
 
     ``overlap_chunks``: pieces the local rows are computed and exchanged in (piece k's exchange overlaps piece k+1's
-    kernels); None picks 1 .. 4 by shard size.
+    kernels); None: :func:`default_overlap_chunks` — 1 (one in-place all-gather) unless the forward is long enough to
+    hide a piece's exchange, then up to 8 pieces of at least 8 192 rows.
+
+    ``loopback`` (test aid, one-rank groups only): run the collectives of the N-rank code against the rank itself
+    (see :class:`_RowShardedMSDA`).
 
     ``img`` is ``[B, I, H, D]`` on every rank (a rank only reads the batch elements its rows fall into).
     ``inputs_are_sharded=False``: ``sampling_points [B,Q,H,L,P,2]`` / ``attention_weights [B,Q,H,L,P]`` are
@@ -443,8 +510,12 @@ def row_sharded_multiscale_deformable_attention(
         raise RuntimeError("torch.distributed is not initialised; call init_process_group first")
     if grad_value_sync not in ("all_reduce", "owners", "none"):
         raise ValueError(f"unknown grad_value_sync {grad_value_sync!r}")
+    if grad_sync not in ("slice", "reduce_scatter"):
+        raise ValueError(f"unknown grad_sync {grad_sync!r}")
     if compute_only_as is None:
         world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if loopback and (world != 1 or compute_only_as is not None):
+        raise ValueError("loopback runs a ONE-rank group's collectives against itself (a test aid)")
     B = img.shape[0]
     if inputs_are_sharded:
         if num_queries is None:
@@ -461,6 +532,20 @@ def row_sharded_multiscale_deformable_attention(
     else:
         pts_rows = sampling_points.reshape(rows, *sampling_points.shape[2:])[r0:r1]
         att_rows = attention_weights.reshape(rows, *attention_weights.shape[2:])[r0:r1]
+    if img.device.type == "cuda" and img.requires_grad and torch.is_grad_enabled() and pts_rows.dim() == 5:
+        check_backward_supported(img, pts_rows, Q)  # (at forward time, like the direct operator)
+    if overlap_chunks is None:
+        H, D = img.shape[2], img.shape[3]
+        lp = pts_rows.shape[2] * pts_rows.shape[3] if pts_rows.dim() == 5 else 0
+        overlap_chunks = default_overlap_chunks(rows, world, 4 * lp * H * D * img.element_size(),
+                                                H * D * pts_rows.element_size())
+    if (compute_only_as is not None or (world == 1 and not loopback)) and _rows_node_ok(img, img_shapes, pts_rows, att_rows,
+                                                                                         padding_mode):
+        # nothing to exchange: the whole operator is the C++ node (same launches as _RowShardedMSDA, no Python in the
+        # step — at one rank the sharded operator costs what the direct one does)
+        from . import _ext
+        return _ext.load().msda_rows(img, img_shapes, pts_rows, att_rows, _lib.PADDING_MODES[padding_mode],
+                                     bool(align_corners), Q, r0, r1, max(1, int(overlap_chunks)), 0)
     owners = _owner_groups(B, Q, group) if (grad_value_sync == "owners" and img.requires_grad) else None
     if grad_value_sync == "owners" and img.requires_grad and owners is None:
         grad_value_sync = "all_reduce"  # a caller-supplied sub-group: see _owner_groups
@@ -469,10 +554,25 @@ def row_sharded_multiscale_deformable_attention(
             _WARNED_OWNERS_DOWNGRADE = True
             warnings.warn("grad_value_sync='owners' needs sub-groups of the DEFAULT process group; on a caller-supplied "
                           "group grad_value is all-reduced over that group instead", stacklevel=2)
-    if overlap_chunks is None:
-        overlap_chunks = default_overlap_chunks(rows, world)
+    if loopback and grad_value_sync == "owners" and owners is not None:
+        # a one-rank job has no shared batch element: sum every batch element over the one-rank group instead
+        owners = [([0], group if group is not None else dist.group.WORLD) for _ in range(B)]
     return _RowShardedMSDA.apply(img, img_shapes, pts_rows, att_rows, padding_mode, bool(align_corners), Q, group,
-                                 grad_value_sync, grad_sync, owners, overlap_chunks, compute_only_as)
+                                 grad_value_sync, grad_sync, owners, overlap_chunks, compute_only_as, bool(loopback))
+
+
+def _rows_node_ok(img, img_shapes, pts_rows, att_rows, padding_mode) -> bool:
+    """GPU tensors of a dtype combination the kernels take, the binding built, no autocast / tracing / per-kernel timer:
+    what the C++ row node needs (everything else takes the Python node, whose launchers carry the error messages)."""
+    from .functional import _DTYPE_TRIPLES, _SHAPE_DTYPES, _autocast_on
+    if _rows_ext(img) is None or torch.compiler.is_compiling() or _autocast_on():
+        return False
+    dev = img.device
+    return (img.dim() == 4 and pts_rows.dim() == 5 and att_rows.dim() == 4 and pts_rows.shape[-1] == 2
+            and pts_rows.shape[1] == img.shape[2] and att_rows.shape == pts_rows.shape[:4]
+            and (img.dtype, pts_rows.dtype, att_rows.dtype) in _DTYPE_TRIPLES and padding_mode in _lib.PADDING_MODES
+            and img_shapes.device == dev and pts_rows.device == dev and att_rows.device == dev
+            and img_shapes.dtype in _SHAPE_DTYPES and tuple(img_shapes.shape) == (pts_rows.shape[2], 2))
 
 
 def owners_sum_bytes(B: int, Q: int, world: int, rank: int, plane_bytes: int) -> int:

@@ -109,12 +109,17 @@ def _shapes_i64(img_shapes: torch.Tensor) -> torch.Tensor:
 _BWD_SUPPORTED: dict = {}  # (B, I, H, D, Q, L, P, element size) -> msda_bwd_supported
 
 
-def check_backward_supported(img, sampling_points) -> None:
+def check_backward_supported(img, sampling_points, num_queries: Optional[int] = None) -> None:
     """Raise at FORWARD time when the value pyramid needs a gradient the library cannot produce for these sizes (a plane
     of 2^22 pixels or more, or a head dimension beyond the sorted pipeline's 32-bit slot offsets, on a problem too
-    large for the single-launch kernel) — not from the backward in the middle of a training step."""
+    large for the single-launch kernel) — not from the backward in the middle of a training step.
+    ``num_queries``: ``sampling_points`` is a flat run of rows ``[rows, H, L, P, 2]`` of batch elements with that many
+    queries each (the row-sharded operator)."""
     B, I, H, D = img.shape
-    _, Q, _, L, P = sampling_points.shape[:5]
+    if num_queries is None:
+        _, Q, _, L, P = sampling_points.shape[:5]
+    else:
+        Q, (_, _, L, P) = int(num_queries), sampling_points.shape[:4]
     key = (B, I, H, D, Q, L, P, sampling_points.element_size())
     ok = _BWD_SUPPORTED.get(key)
     if ok is None:

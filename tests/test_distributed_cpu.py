@@ -314,12 +314,22 @@ def test_piece_exchange_is_issued_before_the_next_piece_computes():
 
 
 def test_default_overlap_chunks():
+    """Pieces only where the forward can hide a piece's exchange: never at one rank, never without
+    the row sizes, not for the BASELINE shapes (a row of the result is computed in 2-6 ns and travels for ~25); pieces of
+    at least 8 192 rows, at most 8, for sample counts large enough."""
     from msda_triton_amd.distributed import default_overlap_chunks
-    assert default_overlap_chunks(40000, 1) == 1
-    assert default_overlap_chunks(4 * 10000 * 8, 8) == 4      # c2 weak scaling at 8 ranks: 40 000 rows per rank
-    assert default_overlap_chunks(400000, 8) == 6             # c5 strong scaling: 50 000 rows per rank
-    assert default_overlap_chunks(7200, 8) == 1               # c4: 900 rows per rank, one all-gather
-    assert default_overlap_chunks(400000, 2) == 8
+
+    def sizes(H, D, L, P, s):
+        return 4 * L * P * H * D * s, H * D * s
+
+    assert default_overlap_chunks(40000, 1, *sizes(8, 32, 4, 4, 4)) == 1
+    assert default_overlap_chunks(4 * 10000 * 8, 8) == 1                              # sizes unknown: one piece
+    assert default_overlap_chunks(4 * 10000 * 8, 8, *sizes(8, 32, 4, 4, 4)) == 1      # c2 weak scaling at 8 ranks
+    assert default_overlap_chunks(400000, 8, *sizes(8, 64, 5, 8, 2)) == 1             # c5 strong scaling
+    assert default_overlap_chunks(7200, 8, *sizes(8, 32, 4, 4, 4)) == 1               # c4
+    assert default_overlap_chunks(400000, 8, *sizes(8, 32, 8, 32, 4)) == 6            # L * P = 256: 50 000 rows per rank
+    assert default_overlap_chunks(400000, 2, *sizes(8, 32, 8, 32, 4)) == 8
+    assert default_overlap_chunks(7200, 8, *sizes(8, 32, 8, 32, 4)) == 1              # ... but never pieces below 8 192 rows
 
 
 # ------------------------------------------------------------------------------------------

@@ -77,3 +77,66 @@ def test_module_step_with_row_split_projections_matches_plain_layers(autocast, m
         assert a.dtype == b.dtype and a.shape == b.shape
         scale = b.float().abs().max().clamp_min(1e-6)
         torch.testing.assert_close(a.float() / scale, b.float() / scale, **tol)
+
+
+# ------------------------------------------------------------------------------------------
+# the row-split route calls F.linear on layer.weight / layer.bias itself, so it may only replace a
+# PLAIN nn.Linear without hooks — the reference module always calls the layer (frontend.py:253-267)
+# ------------------------------------------------------------------------------------------
+class _LoraLikeLinear(torch.nn.Linear):
+    """``.weight`` is the base weight; the adapter path lives in ``forward`` (what peft's lora.Linear does)."""
+
+    def __init__(self, i, o):
+        super().__init__(i, o)
+        self.a = torch.nn.Parameter(torch.randn(i, 2) * 0.1)
+        self.b = torch.nn.Parameter(torch.randn(2, o) * 0.1)
+
+    def forward(self, x):
+        return super().forward(x) + (x @ self.a) @ self.b
+
+
+def test_plain_linear_gate():
+    layer = torch.nn.Linear(8, 8)
+    assert _linear._plain_linear(layer)
+    assert not _linear._plain_linear(_LoraLikeLinear(8, 8))
+    for register in ("register_forward_hook", "register_forward_pre_hook", "register_full_backward_hook",
+                     "register_full_backward_pre_hook"):
+        layer = torch.nn.Linear(8, 8)
+        handle = getattr(layer, register)(lambda *a: None)
+        assert not _linear._plain_linear(layer), register
+        handle.remove()
+        assert _linear._plain_linear(layer), register
+    layer = torch.nn.Linear(8, 8)
+    handle = torch.nn.modules.module.register_module_forward_hook(lambda *a: None)
+    try:
+        assert not _linear._plain_linear(layer)
+    finally:
+        handle.remove()
+    assert _linear._plain_linear(layer)
+
+
+@pytest.mark.gpu
+def test_hooks_and_wrapped_layers_run_at_row_split_sizes():
+    """>= 8 192 rows on the GPU with grad enabled — where a plain layer takes the row-split route: a forward hook still
+    fires, and a LoRA-style subclass keeps its adapter path (values and gradients equal the layer called directly)."""
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    x = torch.randn(4, 4096, 32, device=dev, requires_grad=True)
+    assert x.numel() // 32 >= _linear.ROW_SPLIT_MIN_ROWS
+    plain = torch.nn.Linear(32, 48).to(dev)
+    assert "RowSplit" in type(_linear.projection(plain, x).grad_fn).__name__
+    seen = []
+    handle = plain.register_forward_hook(lambda mod, args, out: seen.append(out.shape) or out * 2)
+    y = _linear.projection(plain, x)
+    handle.remove()
+    assert seen == [torch.Size([4, 4096, 48])] and "RowSplit" not in type(y.grad_fn).__name__
+    torch.testing.assert_close(y, 2 * plain(x))
+    lora = _LoraLikeLinear(32, 48).to(dev)
+    y = _linear.projection(lora, x)
+    want = lora(x)
+    torch.testing.assert_close(y, want)
+    g = torch.autograd.grad(y.sum(), [lora.a, lora.b])
+    gw = torch.autograd.grad(want.sum(), [lora.a, lora.b])
+    for p, q in zip(g, gw):
+        torch.testing.assert_close(p, q)
+    assert float(g[0].abs().sum()) > 0  # the adapter path took part
