@@ -46,6 +46,24 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 README_RTX2060_MS = {"fwd": 3.78, "fwd_bwd": 22.78}  # reference README.md:18-19 (Triton, RTX 2060)
 L1_PEAK_GBS = 64 * 256 * 2.4  # vector L1: 64 B/clk/CU x 256 CUs x 2.4 GHz = 39 322 GB/s (guides/MI355X_MICROARCH.md)
+LDS_PEAK_GBS = 256 * 256 * 2.4  # LDS, ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 286 GB/s (same guide, "LDS")
+
+
+def lds_row_fraction(wl, info):
+    """Fraction of the forward's gathered rows that come from LDS: the kernel variant with LDS-served levels
+    (msda_last_launch_info: fwd_variant 1) keeps the longest SUFFIX of the level list whose pixels fit
+    `fwd_lds_level_bytes` (msda_kernels.hpp coarse_levels — restated here); every level has P samples per unit."""
+    if not info or info.get("fwd_variant") != 1:
+        return 0.0
+    cap = info["fwd_lds_level_bytes"] // (wl.D * wl.elem_size)
+    pixels, first = 0, wl.L
+    for lvl in range(wl.L - 1, -1, -1):
+        n = wl.levels[lvl][0] * wl.levels[lvl][1]
+        if n > cap - pixels:
+            break
+        pixels += n
+        first = lvl
+    return (wl.L - first) / wl.L
 
 
 def single_kernel_alg_bytes(wl):
@@ -753,6 +771,18 @@ def main():
             fwd_only()
         return ms, timed(fwd_only, args.steps, collect=False) * 1e3 / args.steps
 
+    def cold_window():
+        """The protocol of rounds 1-4 (and of any caller that times a short burst on an idle GPU): the device idles,
+        W warm-up steps, a collector pause + barrier, then the K timed steps — no spin-up.  Reported NEXT to the
+        steady-state `ms_per_step` so that records from before and after round 5's spin-up change compare."""
+        import gc
+        barrier()
+        time.sleep(0.3)
+        for _ in range(args.warmup):
+            step()
+        gc.collect()
+        return timed(step, args.steps, collect=True) * 1e3 / args.steps
+
     exchange_ms = None
     if use_dist and world > 1:
         # Two ways to exchange the output rows: one in-place all-gather after the kernels, or grouped point-to-point
@@ -770,7 +800,7 @@ def main():
     # ---- the same K steps again with per-launch HIP events (KernelTimer splits the backward into one C-ABI call
     #      per kernel group, so its two halves run back to back here instead of concurrently) ----
     kern = {}
-    peak_mem = None
+    peak_mem = peak_ref = launch_info = None
     if on_gpu:
         for _ in range(args.warmup):
             step()
@@ -794,6 +824,19 @@ def main():
         step()
         torch.cuda.synchronize()
         peak_mem = torch.cuda.max_memory_allocated(dev)
+        # ... and by the reference's recipe (scripts/benchmark.py:158-172; README.md:20 quotes 166.14 MB): the inputs stay
+        # resident, start = memory_allocated(), one fwd+bwd, max_memory_allocated() - start — what a step allocates on top
+        peak_ref, reps = 0.0, 10
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats(dev)
+            start_mem = torch.cuda.memory_allocated(dev)
+            step()
+            torch.cuda.synchronize()
+            peak_ref += (torch.cuda.max_memory_allocated(dev) - start_mem) / 1e6 / reps
+        fwd_only()
+        launch_info = _lib.last_launch_info()
+    ms_cold = cold_window()
 
     if rank == 0:
         kernels = kernel_table(wl, kern, load_traffic(args.workload))
@@ -809,6 +852,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_step,
+            "ms_per_step_cold_window": ms_cold,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -841,6 +885,11 @@ def main():
                                             "fwd_bwd": README_RTX2060_MS["fwd_bwd"] / ms_step},
             "kernels": kernels,
             "peak_mem_MB": round(peak_mem / 1e6, 1) if peak_mem is not None else None,
+            "peak_mem_reference_recipe_MB": round(peak_ref, 1) if peak_ref is not None else None,
+            "peak_mem_note": "peak_mem_MB: max_memory_allocated over a step, inputs included; peak_mem_reference_recipe_MB: "
+                             "the reference's recipe (scripts/benchmark.py:158-172) — what one fwd+bwd allocates ON TOP of "
+                             "its resident inputs (result, rand_like gradient, three gradients, workspace); the reference's "
+                             "README quotes 166.14 MB for it",
         }
         if on_gpu and single:
             salg = single_kernel_alg_bytes(wl)
@@ -868,11 +917,21 @@ def main():
                 # the forward's gather as the hardware sees it: logical row bytes per second, and as a fraction of
                 # the vector L1 rate (64 B/clk/CU x 256 CUs x 2.4 GHz) — "bound by requests, not HBM bytes"
                 "effective_gather_TBs": round(wl.gather_fwd_bytes / (fwd_us * 1e-6) / 1e12, 2) if fwd_us else None,
-                "gather_frac_of_l1_rate": round(wl.gather_fwd_bytes / (fwd_us * 1e-6) / 1e9 / L1_PEAK_GBS, 3) if fwd_us else None,
                 "traffic_caveat": "the 2x FETCH_SIZE correction is calibrated for 16-byte-per-lane streaming reads only: "
                                   "for the scatter / gather kernels `traffic` is an upper-ish bound (profiles/hbm_traffic.json)"}
+            if fwd_us and launch_info:
+                # the forward's gather split by where its rows come from: through the vector L1 (64 B/clk/CU) or out of the
+                # workgroup's LDS copy of the coarse levels (ds_read_b128, 256 B/clk/CU) — two fractions of two different
+                # peaks, each below 1 (rounds 4-5 divided ALL rows by the L1 rate and read 1.015 once half of them had moved)
+                f_lds = lds_row_fraction(wl, launch_info)
+                rows_bytes = wl.gather_fwd_bytes / (fwd_us * 1e-6) / 1e9
+                result["roofline"].update({
+                    "fwd_rows_from_lds_frac": round(f_lds, 3),
+                    "gather_memory_side_frac_of_l1_rate": round(rows_bytes * (1 - f_lds) / L1_PEAK_GBS, 3),
+                    "gather_lds_side_frac_of_lds_rate": round(rows_bytes * f_lds / LDS_PEAK_GBS, 3),
+                    "fwd_launch": launch_info})
         if on_gpu:
-            result["options"] = {k: _lib.get_option(k) for k in ("xcd_map", "value_path", "overlap")}
+            result["options"] = {k: _lib.get_option(k) for k in ("xcd_map", "value_path", "overlap", "ws_passes")}
     else:
         result = None
     guard.result, guard.have_result = result, True

@@ -15,9 +15,16 @@ LIB_NAME = "libmsda_hip.so"
 LIB_PATH = os.path.join(_HERE, LIB_NAME)
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PADDING_MODES = {"border": 0, "zeros": 1}
 WS_RECORDS_IN_GRADS = 1  # msda_bwd_workspace_bytes flag (include/msda_hip.h)
+
+
+def ws_passes(n: int) -> int:
+    """msda_bwd_workspace_bytes flag MSDA_WS_PASSES(n): the size for n passes over the batch (include/msda_hip.h)."""
+    return (int(n) & 0xFF) << 8
+
+
 # one storage type for every tensor, then the mixed ones: value / grad_value in 16 bits, everything else fp32
 DTYPE_SUFFIXES = ("f32", "f16", "bf16", "f64", "f32_vbf16", "f32_vf16")
 # module storage (fused entry points only): value, projection, out and their gradients in 16 bits, reference points fp32
@@ -28,7 +35,8 @@ EXPORTED_SYMBOLS = tuple(
     [f"msda_{d}_{s}" for d in ("fwd", "bwd", "fwd_fused", "bwd_fused") for s in DTYPE_SUFFIXES]
     + [f"msda_{d}_{s}" for d in ("fwd_fused", "bwd_fused") for s in FUSED_STORAGE_SUFFIXES]
     + ["msda_abi_version", "msda_last_error", "msda_set_option", "msda_get_option", "msda_bwd_workspace_bytes",
-       "msda_bwd_fused_workspace_bytes", "msda_bwd_supported", "msda_fused_lp_limit", "msda_profile_read"]
+       "msda_bwd_fused_workspace_bytes", "msda_bwd_supported", "msda_fused_lp_limit", "msda_profile_read",
+       "msda_last_launch_info"]
 )
 
 _lib = None
@@ -72,28 +80,29 @@ def load():
         for suf in DTYPE_SUFFIXES:
             f = getattr(lib, f"msda_fwd_{suf}")
             f.restype = ci
-            f.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, vp]
+            # (..., padding_mode, align_corners, value_row_stride, stream)
+            f.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, i64, vp]
             ff = getattr(lib, f"msda_fwd_fused_{suf}")
             ff.restype = ci
-            ff.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, ci, vp]
-            # the backward: the level-size bound (max_level_cells, 0: unknown) is an argument
+            ff.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, ci, i64, vp]
+            # the backward: (..., max_level_cells, value_row_stride, workspace, workspace_bytes, stream)
             g = getattr(lib, f"msda_bwd_{suf}")
             g.restype = ci
-            g.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, i64, vp, i64, vp]
+            g.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, i64, i64, vp, i64, vp]
             gf = getattr(lib, f"msda_bwd_fused_{suf}")
             gf.restype = ci
-            gf.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, i64, vp, i64, vp]
+            gf.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, i64, i64, vp, i64, vp]
         for suf in FUSED_STORAGE_SUFFIXES:
             ff = getattr(lib, f"msda_fwd_fused_{suf}")
             ff.restype = ci
-            ff.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, ci, vp]
+            ff.argtypes = [vp] * 5 + [i64] * 7 + [ci, ci, ci, i64, vp]
             gf = getattr(lib, f"msda_bwd_fused_{suf}")
             gf.restype = ci
-            gf.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, i64, vp, i64, vp]
+            gf.argtypes = [vp] * 8 + [i64] * 7 + [ci, ci, ci, i64, i64, vp, i64, vp]
         lib.msda_bwd_workspace_bytes.restype = i64
         lib.msda_bwd_workspace_bytes.argtypes = [i64] * 7 + [ci, ci, i64, ci]
         lib.msda_bwd_fused_workspace_bytes.restype = i64
-        lib.msda_bwd_fused_workspace_bytes.argtypes = [i64] * 7 + [ci, ci, i64]
+        lib.msda_bwd_fused_workspace_bytes.argtypes = [i64] * 7 + [ci, ci, i64, ci]
         lib.msda_bwd_supported.restype = ci
         lib.msda_bwd_supported.argtypes = [i64] * 7 + [ci]
         lib.msda_profile_read.restype = ci
@@ -106,6 +115,8 @@ def load():
         lib.msda_set_option.argtypes = [ctypes.c_char_p, ci]
         lib.msda_get_option.restype = ci
         lib.msda_get_option.argtypes = [ctypes.c_char_p]
+        lib.msda_last_launch_info.restype = ci
+        lib.msda_last_launch_info.argtypes = [ctypes.c_char_p]
         got = lib.msda_abi_version()
         if got != ABI_VERSION:
             raise MSDALibraryError(f"{LIB_NAME} has ABI version {got}, this package expects {ABI_VERSION}; rebuild it")
@@ -132,6 +143,16 @@ def set_option(key: str, value: int) -> None:
 
 def get_option(key: str) -> int:
     return int(load().msda_get_option(key.encode()))
+
+
+LAUNCH_INFO_KEYS = ("fwd_variant", "fwd_lds_level_bytes", "fwd_lds_planes", "fwd_workgroups", "sample_variant",
+                    "sample_lds_level_bytes", "value_path", "value_passes")
+
+
+def last_launch_info() -> dict:
+    """Which variants the most recent launches took (measurement only; include/msda_hip.h msda_last_launch_info)."""
+    lib = load()
+    return {k: int(lib.msda_last_launch_info(k.encode())) for k in LAUNCH_INFO_KEYS}
 
 
 def profile_read() -> dict:

@@ -56,9 +56,32 @@ def column_sum(gy: torch.Tensor) -> torch.Tensor:
     return gy.sum(0, dtype=acc)
 
 
+_ZEROS: dict = {}  # (shape, dtype, device) -> zeros (the dead rows of the widened weight / bias)
+
+
+def _zeros(shape, like):
+    key = (tuple(shape), like.dtype, like.device)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros(shape, dtype=like.dtype, device=like.device)
+    return z
+
+
+def _linear_into_padded_rows(xc, wc, bc, pad_elems: int):
+    """``F.linear(xc, wc, bc)`` with its output rows ``out_features + pad_elems`` elements apart, as the product with a
+    WIDENED weight — ``pad_elems`` zero rows behind ``wc`` — whose dense ``[N, out + pad]`` result is that layout; returns
+    the ``[..., out_features]`` view.  (Measured on MI355X, N = 21 760 rows, 256 -> 256, tools/linear_pad_bench.py: the
+    dense GEMM 41 us in fp32 / 18 in bf16; the widened one 36 / 20; the same GEMM with ``out=`` a strided view 55 / 23 —
+    the library takes a slower path for a leading dimension that is not the row length; dense + strided copy 51 / 25.)"""
+    o = wc.shape[0]
+    wp = torch.cat([wc, _zeros((pad_elems, wc.shape[1]), wc)])
+    bp = None if bc is None else torch.cat([bc, _zeros((pad_elems,), bc)])
+    return F.linear(xc, wp, bp)[..., :o]
+
+
 class _RowSplitLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, pad_elems=0):
         # autocast: what F.linear would do to its arguments, done once so that the 16-bit copies can be saved
         if torch.is_autocast_enabled("cuda"):
             dt = torch.get_autocast_dtype("cuda")
@@ -68,6 +91,8 @@ class _RowSplitLinear(torch.autograd.Function):
         ctx.save_for_backward(xc, wc)
         ctx.dtypes = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
         with torch.autocast("cuda", enabled=False):
+            if pad_elems:
+                return _linear_into_padded_rows(xc, wc, bc, pad_elems)
             return F.linear(xc, wc, bc)
 
     @staticmethod
@@ -83,7 +108,7 @@ class _RowSplitLinear(torch.autograd.Function):
                 gw = row_split_weight_grad(gy2, xc.reshape(-1, xc.shape[-1])).to(wdt)
             if bdt is not None and ctx.needs_input_grad[2]:
                 gb = column_sum(gy2).to(bdt)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 def _plain_linear(layer) -> bool:
@@ -101,13 +126,36 @@ def _plain_linear(layer) -> bool:
                 or g._global_backward_pre_hooks)
 
 
-def projection(layer: torch.nn.Linear, x: torch.Tensor) -> torch.Tensor:
+def projection(layer: torch.nn.Linear, x: torch.Tensor, pad_rows: bool = False) -> torch.Tensor:
     """``layer(x)``; on a GPU with many rows through the row-split weight gradient above — only for a plain, hook-free
     ``nn.Linear`` (the reference module always calls the layer itself, frontend.py:253-267: whatever a user hung on it —
-    forward hooks, a LoRA wrapper, a quantised replacement — has to run)."""
-    if x.device.type == "cuda" and x.dim() >= 2 and x.numel() // x.shape[-1] >= ROW_SPLIT_MIN_ROWS and \
-            torch.is_grad_enabled() and x.is_floating_point() and not torch.compiler.is_compiling() and \
-            _plain_linear(layer) and (layer.weight.requires_grad or x.requires_grad) and \
-            (torch.is_autocast_enabled("cuda") or x.dtype == layer.weight.dtype):
-        return _RowSplitLinear.apply(x, layer.weight, layer.bias)
+    forward hooks, a LoRA wrapper, a quantised replacement — has to run).
+
+    ``pad_rows`` (the value projection): where this function runs the GEMM itself (same conditions, and plain no-grad
+    inference calls), the output rows are written ``functional.value_row_pad`` bytes apart — a ``[..., out_features]``
+    view of a wider buffer the attention kernels read in place."""
+    gpu_plain = x.device.type == "cuda" and x.dim() >= 2 and x.is_floating_point() and \
+        not torch.compiler.is_compiling() and _plain_linear(layer) and \
+        (torch.is_autocast_enabled("cuda") or x.dtype == layer.weight.dtype)
+    pad = 0
+    if pad_rows and gpu_plain:
+        from .functional import value_row_pad
+        es = (torch.empty((), dtype=torch.get_autocast_dtype("cuda")) if torch.is_autocast_enabled("cuda") else x).element_size()
+        # fp32 values only: measured at the c2 module shape (tools/module_pad_ab.py, profiles/r06_module_pad_ab.txt) the
+        # fused kernels over fp32 rows gain (sample gradients 149 -> 127 us, forward 75.6 -> 73.7 at 10 000 queries; 42.7 ->
+        # 39.7 / 32 -> 28.4 at 2 500) while the 16-bit storage kernels do not move (76 / 120 us either way)
+        pad = value_row_pad(layer.out_features * es) // es if es == 4 else 0
+    if gpu_plain and x.numel() // x.shape[-1] >= ROW_SPLIT_MIN_ROWS and torch.is_grad_enabled() and \
+            (layer.weight.requires_grad or x.requires_grad):
+        return _RowSplitLinear.apply(x, layer.weight, layer.bias, pad)
+    if pad and gpu_plain and not (torch.is_grad_enabled() and (layer.weight.requires_grad or x.requires_grad or
+                                                                (layer.bias is not None and layer.bias.requires_grad))):
+        # nothing to differentiate (inference): the same GEMM straight into the padded rows
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            xc, wc, bc = x.to(dt), layer.weight.to(dt), None if layer.bias is None else layer.bias.to(dt)
+        else:
+            xc, wc, bc = x, layer.weight, layer.bias
+        with torch.autocast("cuda", enabled=False):
+            return _linear_into_padded_rows(xc.detach(), wc.detach(), None if bc is None else bc.detach(), pad)
     return layer(x)

@@ -38,7 +38,7 @@ static std::atomic<int> g_lds_planes{0};
 static std::atomic<int> g_linear_slots{320};
 static std::atomic<int> g_touch{1};
 static std::atomic<int> g_unit_waves{1};
-static std::atomic<int> g_value_row_stride{0};  // experiment (round 6): bytes between the pixels' rows of `value` (0: dense)
+static std::atomic<int> g_ws_passes{1};
 static std::atomic<int> g_lds_stagger{0};  // (measured 0 / 4 / 12 / 24 at c2 @ 10k: 0 is fastest — the work counter desynchronises the waves by itself)
 
 // One side stream + two events per (host thread, device), created on first use and kept for the life of the thread.
@@ -124,7 +124,7 @@ int option_linear_slots() { return g_linear_slots.load(std::memory_order_relaxed
 int option_unit_fwd() { return g_unit_fwd.load(std::memory_order_relaxed); }
 int option_touch() { return g_touch.load(std::memory_order_relaxed); }
 int option_unit_waves() { return g_unit_waves.load(std::memory_order_relaxed); }
-int option_value_row_stride() { return g_value_row_stride.load(std::memory_order_relaxed); }
+int option_ws_passes() { return g_ws_passes.load(std::memory_order_relaxed); }
 int option_lds_budget() { return g_lds_budget.load(std::memory_order_relaxed); }  // dev knob: cap on the level bytes (-1: none)
 // CUs of the current device, asked once per device (the LDS-level gather variants size their grid by it)
 int device_cu_count()
@@ -184,6 +184,14 @@ void profile_end(void *token, hipStream_t stream)
     r->ended = true;
 }
 
+// ---- measurement only: what the last launches were (msda_last_launch_info) — process-wide, like the profile records:
+//      autograd issues the backward from its own thread ----
+static std::atomic<int> g_info[8];
+void note_launch(int slot, int value)
+{
+    if (slot >= 0 && slot < 8) g_info[slot].store(value, std::memory_order_relaxed);
+}
+
 void set_error(const char *fmt, ...)
 {
     va_list ap;
@@ -197,7 +205,7 @@ void set_error(const char *fmt, ...)
 extern "C" int msda_abi_version(void) { return MSDA_ABI_VERSION; }
 
 // the layout lives in a device header (msda_value_sorted.hpp); msda_f32.hip exposes its size formula
-extern "C" int64_t msda_bwd_workspace_bytes_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, int64_t);
+extern "C" int64_t msda_bwd_workspace_bytes_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, int64_t, int);
 
 extern "C" int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
                                             int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells,
@@ -205,18 +213,21 @@ extern "C" int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int
 {
     if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0) return 0;
     return msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, (flags & MSDA_WS_RECORDS_IN_GRADS) ? 1 : 0,
-                                         value_elem_size > 0 ? value_elem_size : elem_size, max_level_cells);
+                                         value_elem_size > 0 ? value_elem_size : elem_size, max_level_cells,
+                                         ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) : msda::option_ws_passes());
 }
 
 extern "C" int64_t msda_bwd_fused_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
-                                                  int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells)
+                                                  int64_t P, int elem_size, int value_elem_size, int64_t max_level_cells,
+                                                  int flags)
 {
     if (B < 0 || I < 0 || H < 0 || D < 0 || Q < 0 || L < 0 || P < 0 || elem_size <= 0) return 0;
     // the derived sampling points + attention weights (3 elements per sample, rounded up to 256 bytes), then
     // the sorted pipeline's own workspace (msda_launch.hpp: fused_mat_bytes)
     (void)value_elem_size;
     const int64_t mat = (B * Q * H * L * P * 3 * (int64_t)elem_size + 255) / 256 * 256;
-    return mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0, 0, max_level_cells);
+    return mat + msda_bwd_workspace_bytes_impl(B, I, H, D, Q, L, P, elem_size, 0, 0, max_level_cells,
+                                               ((flags >> 8) & 0xff) ? ((flags >> 8) & 0xff) : msda::option_ws_passes());
 }
 
 extern "C" int msda_bwd_supported_impl(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int);
@@ -232,6 +243,16 @@ extern "C" int64_t msda_fused_lp_limit_impl(int64_t, int);
 extern "C" int64_t msda_fused_lp_limit(int64_t D, int elem_size) { return msda_fused_lp_limit_impl(D, elem_size); }
 
 extern "C" const char *msda_last_error(void) { return msda::g_err; }
+
+extern "C" int msda_last_launch_info(const char *key)
+{
+    static const char *const kKeys[8] = {"fwd_variant", "fwd_lds_level_bytes", "fwd_lds_planes", "fwd_workgroups",
+                                         "sample_variant", "sample_lds_level_bytes", "value_path", "value_passes"};
+    for (int i = 0; key != nullptr && i < 8; ++i)
+        if (strcmp(key, kKeys[i]) == 0) return msda::g_info[i].load(std::memory_order_relaxed);
+    msda::set_error("unknown launch-info key '%s'", key ? key : "(null)");
+    return MSDA_ERR_BAD_ARG;
+}
 
 // "name launches total_us\n" per kernel launched on this thread since the last read while option "profile" was 1;
 // (any thread: the records are process-wide) waits for the recorded events, then forgets them.  Returns the number of characters written (without the NUL).
@@ -302,7 +323,7 @@ static const OptionEntry kOptions[] = {
     {"linear_slots", &g_linear_slots, 1, 1 << 30, false},
     {"touch", &g_touch, 0, 2, false},
     {"unit_waves", &g_unit_waves, 1, 2, false},
-    {"value_row_stride", &g_value_row_stride, 0, (1 << 24) - 1, true},
+    {"ws_passes", &g_ws_passes, 1, 128, false},
 };
 static const OptionEntry *find_option(const char *key)
 {

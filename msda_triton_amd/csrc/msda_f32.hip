@@ -6,13 +6,15 @@ MSDA_DEFINE_ENTRY_POINTS(f32, float)
 // size of the backward workspace (shared by every dtype: the accumulate type decides the record sizes)
 extern "C" __attribute__((visibility("hidden"))) int64_t msda_bwd_workspace_bytes_impl(
     int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L, int64_t P, int elem_size, int records_in_grads,
-    int value_elem_size, int64_t max_level_cells)
+    int value_elem_size, int64_t max_level_cells, int passes)
 {
     // problems the single-launch kernel takes need no workspace at all
     const msda::Dims d{B, I, H, D, Q, L, P, max_level_cells > 0 ? max_level_cells : 0};
     const bool small = elem_size == 8 ? msda::small_path_chosen<double>(d) : msda::small_path_chosen<float>(d);
     const size_t acc = elem_size == 8 ? 8 : 4;
     if (small) return 0;
+    // passes over the batch (MSDA_WS_PASSES): the workspace of ceil(B / passes) batch elements, used once per group
+    if (passes > 1 && B > 1) B = (B + passes - 1) / passes;
     // the larger of the 16-byte-vector and the scalar layout: which one a call takes depends on the alignment of its
     // grad_out / grad_value pointers (a slice of a shard's buffers can be misaligned), and a workspace that is too
     // small would be rejected (MSDA_ERR_BAD_ARG)

@@ -13,8 +13,9 @@
 //   sample, park {4 row offsets, 4 weights} in the wave's LDS slice.  Loads are coalesced along (l, p).
 // Phase 2 (per unit, G lanes): broadcast-read the parked record, fetch the four rows with range-checked
 //   16-byte buffer loads, FMA into per-lane accumulators.  No block barrier: a wave reads only its own records.
-// (Serving the coarsest pyramid levels from an LDS copy was measured twice — 1024-thread groups in round 1, 256-thread
-//  groups with 9 / 15 / 41 KiB in round 2 — and removed: -7 % on c2 @ 10k only, slower on c1 / c3 / c5)
+// LDSL variants (1024-thread workgroups, one per CU): the coarsest pyramid levels are served from ONE LDS copy shared by
+//   16 waves, whose waves take their query slices from a counter in LDS (round 5; rounds 1-2 had tried it with static
+//   slices / 256-thread workgroups and dropped it).  msda_fwd_unit_kernel: one wave per unit for decoder-sized calls.
 #pragma once
 
 #include <type_traits>
@@ -81,7 +82,7 @@ struct Params {
     int touch;          // forward kernels: the workgroups request every row of their plane once at the start (touch_rows)
     int small_cells;    // single-launch small-problem kernel: capacity of its LDS cell table
     int small_ns;       // ... workgroups per (plane, level)
-    int small_hinted;   // ... small_cells is the caller's promise (msda_hint_level_cells), not the bound from I
+    int small_hinted;   // ... small_cells is the caller's bound (max_level_cells argument / option "level_cells"), not the bound from I
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char msda_smem[];
@@ -325,8 +326,15 @@ __device__ __forceinline__ void request_all_arguments(const Params &p)
 //  loads each: msda_fwd_unit_kernel below.)
 // TS (module kernels, FUSED): storage type of the projection and of `out` when it differs from the arithmetic type T —
 // 16-bit projections / results next to fp32 reference points and fp32 arithmetic (msda_*_fused_f32_sbf16 / _sf16)
+// Occupancy target of the 256-thread forward: five waves per SIMD (102 VGPRs) — except the variants that do not fit it
+// without scratch: 16-bit operators with the prologue fused in or with 8-byte pieces (VEC 4), and double accumulation
+// (1-18 VGPR spills under the cap, round 5 / 6; tests/test_host_api.py reads every kernel's spill count from the library)
+template <typename T, int VEC, bool FUSED> constexpr int fwd_waves_per_eu()
+{
+    return (sizeof(T) == 2 && (FUSED || VEC * sizeof(T) < 16)) || sizeof(typename Traits<T>::acc) == 8 ? 4 : 5;
+}
 template <typename T, int VEC, int G, bool FUSED, typename TV = T, int BLK = kBlock, bool LDSL = false, typename TS = T>
-__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlock ? 5 : 4))) void msda_fwd_kernel(const Params p)
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == kBlock ? fwd_waves_per_eu<T, VEC, FUSED>() : 4))) void msda_fwd_kernel(const Params p)
 {
     using SR = Traits<TS>;
     static_assert(FUSED || sizeof(TS) == sizeof(T), "a separate storage type exists for the module kernels only");

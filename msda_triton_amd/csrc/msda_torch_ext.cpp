@@ -14,24 +14,26 @@
 
 #include <algorithm>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "../../include/msda_hip.h"
 
 namespace {
 
+// (ABI 11: value_row_stride in front of the stream / the workspace)
 using FwdFn = int (*)(const void *, const int64_t *, const void *, const void *, void *, int64_t, int64_t, int64_t,
-                      int64_t, int64_t, int64_t, int64_t, int, int, void *);
+                      int64_t, int64_t, int64_t, int64_t, int, int, int64_t, void *);
 // (the level-size bound travels as an argument: include/msda_hip.h, max_level_cells)
 using BwdFn = int (*)(const void *, const void *, const int64_t *, const void *, const void *, void *, void *, void *,
-                      int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int64_t, void *, int64_t,
-                      void *);
+                      int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int64_t, int64_t, void *,
+                      int64_t, void *);
 
 using FwdFusedFn = int (*)(const void *, const int64_t *, const void *, const void *, void *, int64_t, int64_t, int64_t,
-                           int64_t, int64_t, int64_t, int64_t, int, int, int, void *);
+                           int64_t, int64_t, int64_t, int64_t, int, int, int, int64_t, void *);
 using BwdFusedFn = int (*)(const void *, const void *, const int64_t *, const void *, const void *, void *, void *, void *,
-                           int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, int64_t, void *,
-                           int64_t, void *);
+                           int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int, int, int, int64_t, int64_t,
+                           void *, int64_t, void *);
 
 struct Fns {
     FwdFn fwd;
@@ -87,13 +89,35 @@ torch::autograd::variable_list once_differentiable(const torch::autograd::variab
 
 void *current_stream(const at::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
+// The value pyramid as the kernels can address it, and its value_row_stride in bytes (0: dense).  A [B, I, H, D] view whose
+// pixels sit a constant number of bytes apart with a pixel's H * D channels contiguous (functional.padded_value_rows) is read
+// in place; any other layout is copied dense (functional._value_rows is the same rule).
+std::pair<at::Tensor, int64_t> value_rows(const at::Tensor &img)
+{
+    if (img.is_contiguous()) return {img, 0};
+    if (img.dim() == 4) {
+        const int64_t B = img.size(0), I = img.size(1), H = img.size(2), D = img.size(3), es = (int64_t)img.element_size();
+        const auto st = img.strides();
+        if (D > 0 && H > 0 && I > 0 && st[3] == 1 && st[2] == D && st[1] >= H * D && (B == 1 || st[0] == I * st[1]) &&
+            (st[1] * es) % 16 == 0 && I * st[1] * es < ((int64_t)1 << 31))
+            return {img, st[1] * es};
+    }
+    return {img.contiguous(), 0};
+}
+// bytes from one batch element of `img` (as returned by value_rows) to the next
+int64_t value_batch_bytes(const at::Tensor &img, int64_t vrow)
+{
+    return vrow > 0 ? img.size(1) * vrow : img.size(1) * img.size(2) * img.size(3) * (int64_t)img.element_size();
+}
+
 class MSDAFunction : public torch::autograd::Function<MSDAFunction> {
 public:
     static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &img_, const at::Tensor &shapes_,
                               const at::Tensor &pts_, const at::Tensor &att_, int64_t padding_mode, bool align_corners,
                               int64_t level_cells)
     {
-        const at::Tensor img = img_.contiguous(), pts = pts_.contiguous(), att = att_.contiguous();
+        const auto [img, vrow] = value_rows(img_);
+        const at::Tensor pts = pts_.contiguous(), att = att_.contiguous();
         const at::Tensor shapes = shapes_.to(at::kLong).contiguous();  // stays on the device
         const int64_t B = img.size(0), I = img.size(1), H = img.size(2), D = img.size(3);
         const int64_t Q = pts.size(1), L = pts.size(3), P = pts.size(4);
@@ -101,12 +125,13 @@ public:
         const c10::DeviceGuard guard(img.device());
         check_rc(fns_for(img.scalar_type(), pts.scalar_type())
                      .fwd(img.data_ptr(), shapes.data_ptr<int64_t>(), pts.data_ptr(), att.data_ptr(), out.data_ptr(), B, I,
-                          H, D, Q, L, P, (int)padding_mode, align_corners ? 1 : 0, current_stream(img)),
+                          H, D, Q, L, P, (int)padding_mode, align_corners ? 1 : 0, vrow, current_stream(img)),
                  "msda_fwd");
         ctx->save_for_backward({img, shapes, pts, att});
         ctx->saved_data["padding_mode"] = padding_mode;
         ctx->saved_data["align_corners"] = align_corners;
         ctx->saved_data["level_cells"] = level_cells;
+        ctx->saved_data["vrow"] = vrow;
         return out;
     }
 
@@ -115,6 +140,7 @@ public:
     {
         const auto saved = ctx->get_saved_variables();
         const at::Tensor &img = saved[0], &shapes = saved[1], &pts = saved[2], &att = saved[3];
+        const int64_t vrow = ctx->saved_data["vrow"].toInt();
         const int padding_mode = (int)ctx->saved_data["padding_mode"].toInt();
         const bool align_corners = ctx->saved_data["align_corners"].toBool();
         const int64_t level_cells = ctx->saved_data["level_cells"].toInt();  // bound on the largest level's cells (0: unknown)
@@ -131,7 +157,7 @@ public:
             g_att = at::empty_like(att);
         }
         if (want_value) {
-            g_img = at::empty_like(img);
+            g_img = at::empty(img.sizes(), img.options());  // (dense, whatever the pyramid's row stride)
             // all three gradients in one call: the sorted records may use the gradient buffers themselves (the library's
             // own conditions: 16-byte aligned buffers, no forced side-stream fork)
             const bool in_grads = want_sample && reinterpret_cast<uintptr_t>(g_pts.data_ptr()) % 16 == 0 &&
@@ -147,7 +173,7 @@ public:
                          .bwd(gout.data_ptr(), img.data_ptr(), shapes.data_ptr<int64_t>(), pts.data_ptr(), att.data_ptr(),
                               want_value ? g_img.data_ptr() : nullptr, want_sample ? g_pts.data_ptr() : nullptr,
                               want_sample ? g_att.data_ptr() : nullptr, B, I, H, D, Q, L, P, padding_mode,
-                              align_corners ? 1 : 0, level_cells, ws.defined() ? ws.data_ptr() : nullptr, ws_bytes,
+                              align_corners ? 1 : 0, level_cells, vrow, ws.defined() ? ws.data_ptr() : nullptr, ws_bytes,
                               current_stream(img)),
                      "msda_bwd");
         }
@@ -165,7 +191,8 @@ public:
                               const at::Tensor &proj_, const at::Tensor &ref_, int64_t padding_mode, bool align_corners,
                               int64_t level_cells)
     {
-        const at::Tensor img = img_.contiguous(), proj = proj_.contiguous(), ref = ref_.contiguous();
+        const auto [img, vrow] = value_rows(img_);
+        const at::Tensor proj = proj_.contiguous(), ref = ref_.contiguous();
         const at::Tensor shapes = shapes_.to(at::kLong).contiguous();
         const int64_t B = img.size(0), I = img.size(1), H = img.size(2), D = img.size(3);
         const int64_t Q = proj.size(1), L = proj.size(3), P = proj.size(4);
@@ -173,13 +200,14 @@ public:
         const c10::DeviceGuard guard(img.device());
         check_rc(fns_for(img.scalar_type(), proj.scalar_type())
                      .fwd_fused(img.data_ptr(), shapes.data_ptr<int64_t>(), proj.data_ptr(), ref.data_ptr(), out.data_ptr(),
-                                B, I, H, D, Q, L, P, (int)ref.size(-1), (int)padding_mode, align_corners ? 1 : 0,
+                                B, I, H, D, Q, L, P, (int)ref.size(-1), (int)padding_mode, align_corners ? 1 : 0, vrow,
                                 current_stream(img)),
                  "msda_fwd_fused");
         ctx->save_for_backward({img, shapes, proj, ref});
         ctx->saved_data["padding_mode"] = padding_mode;
         ctx->saved_data["align_corners"] = align_corners;
         ctx->saved_data["level_cells"] = level_cells;
+        ctx->saved_data["vrow"] = vrow;
         return out;
     }
 
@@ -191,6 +219,7 @@ public:
         const int padding_mode = (int)ctx->saved_data["padding_mode"].toInt();
         const bool align_corners = ctx->saved_data["align_corners"].toBool();
         const int64_t level_cells = ctx->saved_data["level_cells"].toInt();
+        const int64_t vrow = ctx->saved_data["vrow"].toInt();
         at::Tensor gout = grads[0].contiguous();
         if (gout.scalar_type() != proj.scalar_type()) gout = gout.to(proj.scalar_type());
         const bool want_value = ctx->needs_input_grad(0);
@@ -201,9 +230,9 @@ public:
         at::Tensor g_proj = at::empty_like(proj), g_ref_part = at::empty({B, Q, H, ref_dim}, proj.options());
         int64_t ws_bytes = 0;
         if (want_value) {
-            g_img = at::empty_like(img);
+            g_img = at::empty(img.sizes(), img.options());
             ws_bytes = msda_bwd_fused_workspace_bytes(B, I, H, D, Q, L, P, (int)proj.element_size(),
-                                                      (int)img.element_size(), level_cells);
+                                                      (int)img.element_size(), level_cells, 0);
             ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));
         }
         {
@@ -212,8 +241,8 @@ public:
                          .bwd_fused(gout.data_ptr(), img.data_ptr(), shapes.data_ptr<int64_t>(), proj.data_ptr(),
                                     ref.data_ptr(), want_value ? g_img.data_ptr() : nullptr, g_proj.data_ptr(),
                                     g_ref_part.data_ptr(), B, I, H, D, Q, L, P, (int)ref_dim, padding_mode,
-                                    align_corners ? 1 : 0, level_cells, ws.defined() ? ws.data_ptr() : nullptr, ws_bytes,
-                                    current_stream(img)),
+                                    align_corners ? 1 : 0, level_cells, vrow, ws.defined() ? ws.data_ptr() : nullptr,
+                                    ws_bytes, current_stream(img)),
                      "msda_bwd_fused");
         }
         return once_differentiable(grads, {g_img, at::Tensor(), ctx->needs_input_grad(2) ? g_proj : at::Tensor(),
@@ -265,12 +294,13 @@ template <typename F> void for_pieces(int64_t Q, int64_t row0, int64_t row1, F f
 }
 
 // forward of rows [row0, row1) into full[row0:row1]; pts_rows / att_rows hold the rows from `in_row0` on
-void rows_forward(const at::Tensor &img, const at::Tensor &shapes, const at::Tensor &pts_rows, const at::Tensor &att_rows,
+void rows_forward(const at::Tensor &img_, const at::Tensor &shapes, const at::Tensor &pts_rows, const at::Tensor &att_rows,
                   int64_t in_row0, const at::Tensor &full, int64_t row0, int64_t row1, int64_t Q, int64_t padding_mode,
                   bool align_corners)
 {
-    const RowDims d = row_dims(img, pts_rows, att_rows, Q);
-    TORCH_CHECK_VALUE(img.is_contiguous() && pts_rows.is_contiguous() && att_rows.is_contiguous() && full.is_contiguous(),
+    const RowDims d = row_dims(img_, pts_rows, att_rows, Q);
+    const auto [img, vrow] = value_rows(img_);
+    TORCH_CHECK_VALUE(pts_rows.is_contiguous() && att_rows.is_contiguous() && full.is_contiguous(),
                       "rows_forward takes contiguous tensors");
     TORCH_CHECK_VALUE(shapes.scalar_type() == at::kLong && shapes.is_contiguous(), "img_shapes: contiguous int64");
     TORCH_CHECK_VALUE(0 <= in_row0 && in_row0 <= row0 && row0 <= row1 && row1 <= d.B * d.Q &&
@@ -284,27 +314,27 @@ void rows_forward(const at::Tensor &img, const at::Tensor &shapes, const at::Ten
     const char *v = static_cast<const char *>(img.data_ptr());
     const char *p = static_cast<const char *>(pts_rows.data_ptr()), *a = static_cast<const char *>(att_rows.data_ptr());
     char *o = static_cast<char *>(full.data_ptr());
-    const int64_t unit = d.H * d.L * d.P;
+    const int64_t unit = d.H * d.L * d.P, vbatch = value_batch_bytes(img, vrow);
     for_pieces(d.Q, row0, row1, [&](int64_t b, int64_t nb, int64_t before, int64_t n) {
         const int64_t in_at = row0 + before - in_row0, out_at = row0 + before;
-        check_rc(fns.fwd(v + b * d.I * d.H * d.D * d.vs, shapes.data_ptr<int64_t>(), p + in_at * unit * 2 * d.es,
+        check_rc(fns.fwd(v + b * vbatch, shapes.data_ptr<int64_t>(), p + in_at * unit * 2 * d.es,
                          a + in_at * unit * d.es, o + out_at * d.H * d.D * d.es, nb, d.I, d.H, d.D, n / nb, d.L, d.P,
-                         (int)padding_mode, align_corners ? 1 : 0, stream),
+                         (int)padding_mode, align_corners ? 1 : 0, vrow, stream),
                  "msda_fwd (row range)");
     });
 }
 
 // backward of rows [r0, r1): grad_rows / pts_rows / att_rows hold exactly those rows.  Returns (grad_img [B,I,H,D] with
 // the batch elements the rows do not touch zeroed, grad_pts_rows, grad_att_rows); undefined tensors for what is not needed.
-std::tuple<at::Tensor, at::Tensor, at::Tensor> rows_backward(const at::Tensor &grad_rows_, const at::Tensor &img,
+std::tuple<at::Tensor, at::Tensor, at::Tensor> rows_backward(const at::Tensor &grad_rows_, const at::Tensor &img_,
                                                              const at::Tensor &shapes, const at::Tensor &pts_rows,
                                                              const at::Tensor &att_rows, int64_t r0, int64_t r1, int64_t Q,
                                                              int64_t padding_mode, bool align_corners, bool need_img,
                                                              bool need_pts, bool need_att, int64_t level_cells)
 {
-    const RowDims d = row_dims(img, pts_rows, att_rows, Q);
-    TORCH_CHECK_VALUE(img.is_contiguous() && pts_rows.is_contiguous() && att_rows.is_contiguous(),
-                      "rows_backward takes contiguous tensors");
+    const RowDims d = row_dims(img_, pts_rows, att_rows, Q);
+    const auto [img, vrow] = value_rows(img_);
+    TORCH_CHECK_VALUE(pts_rows.is_contiguous() && att_rows.is_contiguous(), "rows_backward takes contiguous tensors");
     TORCH_CHECK_VALUE(shapes.scalar_type() == at::kLong && shapes.is_contiguous(), "img_shapes: contiguous int64");
     TORCH_CHECK_VALUE(0 <= r0 && r0 <= r1 && r1 <= d.B * d.Q && pts_rows.size(0) == r1 - r0 &&
                           grad_rows_.numel() == (r1 - r0) * d.H * d.D,
@@ -313,7 +343,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rows_backward(const at::Tensor &g
     if (grad_rows.scalar_type() != pts_rows.scalar_type()) grad_rows = grad_rows.to(pts_rows.scalar_type());
     const bool want_sample = need_pts || need_att;
     at::Tensor g_img, g_pts, g_att;
-    if (need_img) g_img = at::empty_like(img);
+    if (need_img) g_img = at::empty(img.sizes(), img.options());  // (dense)
     if (want_sample) {
         g_pts = at::empty_like(pts_rows);
         g_att = at::empty_like(att_rows);
@@ -329,7 +359,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rows_backward(const at::Tensor &g
         char *gv = need_img ? static_cast<char *>(g_img.data_ptr()) : nullptr;
         char *gp = want_sample ? static_cast<char *>(g_pts.data_ptr()) : nullptr;
         char *ga = want_sample ? static_cast<char *>(g_att.data_ptr()) : nullptr;
-        const int64_t unit = d.H * d.L * d.P, plane = d.I * d.H * d.D;
+        const int64_t unit = d.H * d.L * d.P, plane = d.I * d.H * d.D, vbatch = value_batch_bytes(img, vrow);
         const bool overlap_forced = msda_get_option("overlap") == 1;
         for_pieces(d.Q, r0, r1, [&](int64_t b, int64_t nb, int64_t before, int64_t n) {
             for (int64_t k = 0; k < nb; ++k) touched[(size_t)(b + k)] = true;
@@ -346,9 +376,9 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rows_backward(const at::Tensor &g
                                                     in_grads ? MSDA_WS_RECORDS_IN_GRADS : 0);
                 ws = at::empty({ws_bytes}, img.options().dtype(at::kByte));
             }
-            check_rc(fns.bwd(go + before * d.H * d.D * d.es, v + b * plane * d.vs, shapes.data_ptr<int64_t>(),
+            check_rc(fns.bwd(go + before * d.H * d.D * d.es, v + b * vbatch, shapes.data_ptr<int64_t>(),
                              p + before * unit * 2 * d.es, a + before * unit * d.es, pv, pp, pa, nb, d.I, d.H, d.D, n / nb,
-                             d.L, d.P, (int)padding_mode, align_corners ? 1 : 0, level_cells,
+                             d.L, d.P, (int)padding_mode, align_corners ? 1 : 0, level_cells, vrow,
                              ws.defined() ? ws.data_ptr() : nullptr, ws_bytes, stream),
                      "msda_bwd (row range)");
         });
@@ -374,7 +404,7 @@ public:
                               const at::Tensor &pts_, const at::Tensor &att_, int64_t padding_mode, bool align_corners,
                               int64_t Q, int64_t r0, int64_t r1, int64_t chunks, int64_t level_cells)
     {
-        const at::Tensor img = img_.contiguous(), pts = pts_.contiguous(), att = att_.contiguous();
+        const at::Tensor img = value_rows(img_).first, pts = pts_.contiguous(), att = att_.contiguous();
         const at::Tensor shapes = shapes_.to(at::kLong).contiguous();
         const int64_t B = img.size(0), H = img.size(2), D = img.size(3);
         at::Tensor full = at::empty({B, Q, H, D}, pts.options());

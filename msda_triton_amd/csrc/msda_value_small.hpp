@@ -51,7 +51,9 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     using TR = Traits<T>;
     using TVR = Traits<TV>;
     constexpr int NG = kSmallBlock / G;  // lane groups per workgroup
-    constexpr int UB = G < 8 ? G : 8;    // row loads in flight per lane
+    // row loads in flight per lane: 8 — 4 for rows of eight 16-bit channels per lane, whose widened copies (8 floats each) next
+    // to the four accumulator rows do not fit the 128 VGPRs of a 1024-thread workgroup (6-26 spilled registers otherwise)
+    constexpr int UB = G < 8 ? G : (VEC >= 8 ? 4 : 8);
     // p.small_ns workgroups per (plane, level): each builds the level's sorted records for itself (cheap) and takes
     // every small_ns-th 2 x 2-pixel block of the gather, so few planes still fill the chip
     int pair, slot;

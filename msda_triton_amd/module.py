@@ -90,7 +90,9 @@ class MultiscaleDeformableAttention(nn.Module):
         # one projection holds (x offset, y offset, attention logit) per (head, level, point); on the GPU the softmax
         # and the offset -> sampling-point math run inside the attention kernel's prologue
         proj = projection(self.query_input_proj, queries).reshape(B, N, H, L, P, 3)
-        value = projection(self.img_input_proj, img).reshape(B, I, H, self.hidden_dim // H)
+        # (the value pyramid is this module's own tensor: on the GPU its pixels' rows are written one 128-byte line apart
+        #  where that takes them off the vector L1's tag-RAM skew — functional.value_row_pad; the kernels read it in place)
+        value = projection(self.img_input_proj, img, pad_rows=True).reshape(B, I, H, self.hidden_dim // H)
         if value.device.type == "cuda" and proj.dtype in (torch.bfloat16, torch.float16) and \
                 self.value_dtype in (None, proj.dtype) and value.dtype == proj.dtype:
             # 16-bit projections (autocast's GEMMs, or 16-bit parameters) with fp32 reference points: the kernels read

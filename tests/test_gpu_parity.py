@@ -657,7 +657,7 @@ def test_grad_value_without_workspace(oracle):
     _, Q, _, L, P, _ = l.shape
     st = torch.cuda.current_stream().cuda_stream
     rc = lib.msda_bwd_f32(g.data_ptr(), v.data_ptr(), s.data_ptr(), l.data_ptr(), a.data_ptr(),
-                          gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, I, H, D, Q, L, P, 1, 0, 0, None, 0, st)
+                          gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, I, H, D, Q, L, P, 1, 0, 0, 0, None, 0, st)
     assert rc == 0
     torch.cuda.synchronize()
     r_gv, r_gl, r_ga = oracle.backward(c["grad_out"], c["value"], c["shapes"], c["loc"], c["attn"], "zeros", False)
@@ -672,7 +672,7 @@ def test_grad_value_without_workspace(oracle):
     need = lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, 4, 4, 0, 0)
     assert need > 0
     args = (g.data_ptr(), v.data_ptr(), s.data_ptr(), l.data_ptr(), a.data_ptr())
-    dims = (B, I, H, D, Q, L, P, 1, 0, 0)  # (..., padding_mode, align_corners, max_level_cells)
+    dims = (B, I, H, D, Q, L, P, 1, 0, 0, 0)  # (..., padding_mode, align_corners, max_level_cells, value_row_stride)
     assert lib.msda_bwd_f32(*args, gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), *dims, None, 0, st) == -1
     assert str(need) in lib.msda_last_error().decode()
     small_ws = torch.empty(need // 8, dtype=torch.uint8, device=DEV)
@@ -702,7 +702,7 @@ def test_grad_value_without_workspace(oracle):
     gvb = torch.empty(v.numel() + 4, device=DEV)
     gv, gl, ga = gvb[:v.numel()].view_as(v), torch.empty_like(l), torch.empty_like(a)
     args = (g.data_ptr(), v.data_ptr(), s.data_ptr(), l.data_ptr(), a.data_ptr())
-    dims = (B, I, H, D, Q, L, P, 1, 0, 0)  # (..., padding_mode, align_corners, max_level_cells)
+    dims = (B, I, H, D, Q, L, P, 1, 0, 0, 0)  # (..., padding_mode, align_corners, max_level_cells, value_row_stride)
     full = lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, 4, 4, 0, 0)
     lean = lib.msda_bwd_workspace_bytes(B, I, H, D, Q, L, P, 4, 4, 0, _lib.WS_RECORDS_IN_GRADS)
     assert 0 < lean <= full - 2 * Q * L * P * 16  # both planes' records are gone from it
@@ -735,11 +735,13 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     x = torch.zeros(64, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     p = x.data_ptr()
-    assert lib.msda_fwd_f32(p, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 7, 0, st) == -1          # unknown padding mode
-    assert lib.msda_fwd_f32(p, p, p, p, p, 1, 33, 1, 4, 1, 33, 1, 0, 0, st) == -2        # too many levels
-    assert lib.msda_fwd_f32(p, p, p, p, p, 1, 1 << 28, 8, 64, 1, 1, 1, 0, 0, st) == -3    # plane offsets overflow
-    assert lib.msda_fwd_f32(p + 2, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, st) == -4      # misaligned
-    assert lib.msda_fwd_f32(None, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, st) == -1       # null buffer
+    assert lib.msda_fwd_f32(p, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 7, 0, 0, st) == -1          # unknown padding mode
+    assert lib.msda_fwd_f32(p, p, p, p, p, 1, 33, 1, 4, 1, 33, 1, 0, 0, 0, st) == -2        # too many levels
+    assert lib.msda_fwd_f32(p, p, p, p, p, 1, 1 << 28, 8, 64, 1, 1, 1, 0, 0, 0, st) == -3    # plane offsets overflow
+    assert lib.msda_fwd_f32(p + 2, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, 0, st) == -4      # misaligned
+    assert lib.msda_fwd_f32(None, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, 0, st) == -1    # null buffer
+    assert lib.msda_fwd_f32(p, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, 8, st) == -1       # value_row_stride below H*D*sizeof
+    assert lib.msda_fwd_f32(p, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, 18, st) == -1      # ... not a multiple of the element size
     assert lib.msda_bwd_workspace_bytes(4, 5440, 8, 32, 10000, 4, 4, 4, 4, 0, 0) > 0
 
 

@@ -374,3 +374,36 @@ def test_every_documented_option_exists_with_its_documented_default():
     import json
     got = json.loads(out.strip().splitlines()[-1])
     assert got == documented, {k: (got[k], documented[k]) for k in documented if got[k] != documented[k]}
+
+
+def test_no_kernel_spills_vector_registers_or_uses_scratch(tmp_path):
+    """every kernel of every translation unit of the shipped library has .vgpr_spill_count 0 and no
+    private (scratch) segment — read from the code objects' metadata notes (no GPU needed).  A gather kernel that spills in
+    its hot loop pays a scratch round trip per trip; round 5 shipped 1-26 spilled VGPRs in the fp16 fused forward, the fp64
+    scalar forward, the 16-bit forward with 8-byte pieces and the 16-bit single-launch grad_value kernel.  (SGPR spills go
+    to VGPR lanes, not to memory, and are not counted.)"""
+    import glob
+    import re
+    import shutil
+    import subprocess
+    from msda_triton_amd import _lib
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objdump, readelf = os.path.join(llvm, "llvm-objdump"), os.path.join(llvm, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf of the ROCm toolchain not found")
+    lib = tmp_path / "lib.so"
+    shutil.copy(_lib.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)  # writes one file per bundle next to the copy
+    objects = glob.glob(str(tmp_path / "lib.so.*gfx950"))
+    assert len(objects) >= 8, objects  # one code object per dtype translation unit
+    kernels, bad = 0, []
+    pat = re.compile(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", re.S)
+    for obj in objects:
+        notes = subprocess.run([readelf, "--notes", obj], capture_output=True, text=True, check=True).stdout
+        for m in pat.finditer(notes):
+            kernels += 1
+            if int(m.group(2)) or int(m.group(3)):
+                bad.append((m.group(1), "scratch bytes", int(m.group(2)), "vgpr spills", int(m.group(3))))
+    assert kernels >= 500, kernels
+    assert not bad, bad
