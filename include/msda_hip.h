@@ -196,8 +196,11 @@ MSDA_DECLARE_FUSED_STORAGE(f32_sf16)
  * does hold ceil(B / 2), ceil(B / 4) ... batch elements runs the pipeline once per such group in the same memory
  * (the workspace it is GIVEN decides: the fewest passes that fit).  c2 @ 10k fp32 with MSDA_WS_RECORDS_IN_GRADS:
  * 107 MB in one pass, 54 MB in two, 27 MB in four — the step's peak memory by the reference's recipe
- * (scripts/benchmark.py:158-172) 273 -> 220 -> 193 MB, for +1 ... +4 % of the step.  Results are
- * bit-identical whatever the number of passes (a plane's gradient is computed by the same kernels from the same records).
+ * (scripts/benchmark.py:158-172) 277 -> 229 -> 205 MB — for +16 % / +48 % of the step (0.307 -> 0.358 / 0.456 ms: the
+ * pipeline's five kernels run at 68 % / 50 % of their rate on half / a quarter of the planes), which is why one pass is
+ * the default.  grad_loc / grad_attn do not depend on the passes; grad_value is bitwise reproducible for a given number
+ * of passes, and between two numbers of passes equal up to the rounding of the last bit (a group of fewer planes is cut
+ * into more query slices, so a cell's records can sit in another order).
  */
 #define MSDA_WS_PASSES(n) (((n) & 0xff) << 8)
 MSDA_API int64_t msda_bwd_workspace_bytes(int64_t B, int64_t I, int64_t H, int64_t D, int64_t Q, int64_t L,
@@ -274,7 +277,7 @@ MSDA_API const char *msda_last_error(void);
  *   "level_cells" 0 (default): unknown;  n: process-wide form of the max_level_cells argument (an argument wins)
  *   "ws_passes"  1 (default): passes over the batch the workspace queries size for when their flags carry no MSDA_WS_PASSES(n)
  *                   (n: smaller workspace, the sorted pipeline runs once per group of ceil(B / n) batch elements — callers that
- *                   simply allocate what the query returns follow it without a change; results bit-identical)
+ *                   simply allocate what the query returns follow it without a change; see MSDA_WS_PASSES for the price)
  * Builds with -DMSDA_DEV (development only; the shipped library rejects these keys) add the experiment knobs
  * "cell_slices", "gather_win", "wg_target", "lds_budget", "lds_stagger", "lds_over" and the ablation / phase-clock mask "debug":
  * see msda_triton_amd/csrc/msda_launch.hpp, msda_value_sorted.hpp and tools/phase_clock.py.

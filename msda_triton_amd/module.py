@@ -90,9 +90,12 @@ class MultiscaleDeformableAttention(nn.Module):
         # one projection holds (x offset, y offset, attention logit) per (head, level, point); on the GPU the softmax
         # and the offset -> sampling-point math run inside the attention kernel's prologue
         proj = projection(self.query_input_proj, queries).reshape(B, N, H, L, P, 3)
-        # (the value pyramid is this module's own tensor: on the GPU its pixels' rows are written one 128-byte line apart
-        #  where that takes them off the vector L1's tag-RAM skew — functional.value_row_pad; the kernels read it in place)
-        value = projection(self.img_input_proj, img, pad_rows=True).reshape(B, I, H, self.hidden_dim // H)
+        # (the value pyramid is this module's own tensor: for large fp32 calls its pixels' rows are written one 128-byte line
+        #  apart, which takes them off the vector L1's tag-RAM skew — functional.value_row_pad; the kernels read that layout
+        #  in place.  Measured at the c2 module shape, fp32, tools/module_pad_ab.py: step 1.05 -> 1.02 ms at 10 000 queries,
+        #  no gain at 2 500, and a LOSS at 900 — a host-bound step that the two extra small launches lengthen — so only
+        #  from 32 768 (b, q) rows on)
+        value = projection(self.img_input_proj, img, pad_rows=B * N >= 32768).reshape(B, I, H, self.hidden_dim // H)
         if value.device.type == "cuda" and proj.dtype in (torch.bfloat16, torch.float16) and \
                 self.value_dtype in (None, proj.dtype) and value.dtype == proj.dtype:
             # 16-bit projections (autocast's GEMMs, or 16-bit parameters) with fp32 reference points: the kernels read

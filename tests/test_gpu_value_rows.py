@@ -143,7 +143,7 @@ def test_module_writes_its_value_projection_padded(monkeypatch):
     torch.manual_seed(3)
     levels = [(48, 48), (24, 24), (12, 12), (6, 6)]
     I = sum(h * w for h, w in levels)  # noqa: E741
-    B, Q, E = 4, 900, 256
+    B, Q, E = 4, 8192, 256  # (>= 32 768 rows: the size from which the module pads)
     m = MultiscaleDeformableAttention(E, E, 4, 8, 4, "border", True).to(DEV)
     img = torch.randn(B, I, E, device=DEV, requires_grad=True)
     q = torch.randn(B, Q, E, device=DEV, requires_grad=True)
@@ -210,8 +210,9 @@ def test_workspace_shrinks_with_the_passes():
 def test_passes_over_the_batch_are_bit_identical(dtype, B, passes, need_sample):
     """ws_passes = n: the size queries return the n-pass workspace, the backward given it runs the sorted pipeline once per
     group of ceil(B / n) batch elements (B = 3 in 2 passes: groups of 2 + 1; B = 5 asked for 8: one element per pass) —
-    every gradient bit-identical to the one-pass run, with the records in the gradient buffers (all three gradients) and
-    in the workspace (grad_value alone)."""
+    grad_loc / grad_attn bit-identical to the one-pass run and grad_value too wherever the groups keep the slice count
+    (else equal to the last bit's rounding), with the records in the gradient buffers (all three gradients) and in the
+    workspace (grad_value alone)."""
     value, shapes, loc, attn, go = _case(B, 1700, 4, 32, 4, dtype, seed=B * 31 + passes)
 
     def run():
@@ -230,8 +231,16 @@ def test_passes_over_the_batch_are_bit_identical(dtype, B, passes, need_sample):
         got = run()
         info = _lib.last_launch_info()
         assert info["value_passes"] == -(-B // -(-B // min(passes, B))), info
-        for a, b in zip(got, one):
+        # grad_loc / grad_attn: the same kernel on the same inputs — bit-exact.  grad_value: each pass count is bitwise
+        # reproducible by itself, but a group of fewer planes is cut into more query slices (sorted_ws_layout: enough
+        # workgroups to fill the chip), a cell's records then sit in another order and its fp32 sum may round differently
+        # in the last bit (B = 5: 13 slices per plane in one pass, 14 with one batch element per pass)
+        for a, b in zip(got[1:], one[1:]):
             assert torch.equal(a, b)
+        if not torch.equal(got[0], one[0]):
+            assert (B, passes) == (5, 8), "these shapes keep their slice count: grad_value must be bit-identical"
+            tol = dict(rtol=2e-6, atol=2e-6 * float(one[0].abs().max())) if dtype == torch.float32 else dict(rtol=8e-3, atol=1e-2)
+            torch.testing.assert_close(got[0], one[0], **tol)
     finally:
         _lib.set_option("ws_passes", keep)
 
