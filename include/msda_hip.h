@@ -195,7 +195,7 @@ MSDA_DECLARE_FUSED_STORAGE(f32_sf16)
  * rows are per (batch, head) plane of the call; msda_bwd_<dtype> given a workspace that does not hold the whole batch but
  * does hold ceil(B / 2), ceil(B / 4) ... batch elements runs the pipeline once per such group in the same memory
  * (the workspace it is GIVEN decides: the fewest passes that fit).  c2 @ 10k fp32 with MSDA_WS_RECORDS_IN_GRADS:
- * 107 MB in one pass, 54 MB in two, 27 MB in four — the step's peak memory by the reference's recipe
+ * 107 MB in one pass, 59 MB in two, 35 MB in four — the step's peak memory by the reference's recipe
  * (scripts/benchmark.py:158-172) 277 -> 229 -> 205 MB — for +16 % / +48 % of the step (0.307 -> 0.358 / 0.456 ms: the
  * pipeline's five kernels run at 68 % / 50 % of their rate on half / a quarter of the planes), which is why one pass is
  * the default.  grad_loc / grad_attn do not depend on the passes; grad_value is bitwise reproducible for a given number

@@ -2,11 +2,16 @@
 # dev tool: per-XCC (and per-instance) values of a few texture-path / L2 counters for the forward kernel — does the XCD that
 # serves the slow head differ in tag conflicts, pending stalls or L2 channel load?
 #   [OPTS="--opt lds_levels=0"] [INSTANCES=1] bash tools/pmc_xcc.sh "TCP_TAGRAM0_REQ TCP_TAGRAM1_REQ TCP_TAGRAM2_REQ TCP_TAGRAM3_REQ" [kernel substring]
+#   PROG="python tools/row_stride_ab.py --pads 128 --rounds 1 --reps 3 --no-spin": profile that program instead of bench.py
 # (the TA_BUFFER_* counters hang the profiler on this image: do not ask for them)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 C="$1"; K=${2:-msda_fwd_kernel}
 rm -rf gpurun_out/pmc_xcc
-timeout -k 10 120 rocprofv3 --pmc $C --output-format json -d gpurun_out/pmc_xcc -- python bench.py --workload ${W:-c2_q10k} --steps 2 --warmup 1 --spin-up-ms 0 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton $OPTS > gpurun_out/pmc_xcc.log 2>&1
+if [ -n "$PROG" ]; then
+  timeout -k 10 120 rocprofv3 --pmc $C --output-format json -d gpurun_out/pmc_xcc -- $PROG > gpurun_out/pmc_xcc.log 2>&1
+else
+  timeout -k 10 120 rocprofv3 --pmc $C --output-format json -d gpurun_out/pmc_xcc -- python bench.py --workload ${W:-c2_q10k} --steps 2 --warmup 1 --spin-up-ms 0 --no-cpu-baseline --no-strong-c5 --no-shard-compute --no-configs --no-do-bench --no-triton $OPTS > gpurun_out/pmc_xcc.log 2>&1
+fi
 python - "$K" <<'PY'
 import collections, glob, json, os, sys
 want = sys.argv[1]

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT")
+    ap.add_argument("--no-spin", action="store_true", help="no spin-up, no profile option (runs under rocprofv3 --pmc)")
     args = ap.parse_args()
 
     import torch
@@ -79,6 +80,12 @@ def main():
         same = all(torch.equal(a[pad], a[pads[0]]) for a in (out, g_loc, g_att))
         print(f"pad {pad}: bit-identical to pad {pads[0]}: {same}")
         assert same
+    if args.no_spin:
+        for _ in range(args.reps):
+            for pad in pads:
+                run(pad)
+        torch.cuda.synchronize()
+        return
     # spin-up
     for _ in range(300):
         run(pads[0])
