@@ -207,7 +207,7 @@ __device__ __forceinline__ void load_level_table(LevelTab *tab, const int64_t *s
     // together — and the exclusive sums come from a shuffle scan over those lanes.  (Until round 5 thread t looped
     // over the levels below it: the compiler made that a waterfall of scalar loads, one dependent miss per level and
     // a vector load of the thread's own level behind them — on a cold cache four round trips in front of the first
-    // sample, which is most of a decoder-sized launch: DESIGN.md 9, small-Q forward.)
+    // sample, which is most of a decoder-sized launch: HISTORY.md 9, small-Q forward.)
     const int t = threadIdx.x;
     if (t < kWave) {
         int lh = 0, lw = 0;

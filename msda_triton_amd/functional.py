@@ -158,7 +158,7 @@ def value_row_pad(dense_row_bytes: int) -> int:
     """Bytes to put behind every pixel's rows of a value pyramid this package allocates itself.  The gather kernels are
     bound by the vector L1, which picks one of four tag RAMs from the low bits of a row's 128-byte line index: with the
     pixels' rows an EVEN number of lines apart (1 024 bytes: 8 heads x 32 channels x fp32; 512: the same in 16 bits) the
-    rows of one head keep hitting the same tag RAMs, and that head's plane gathers up to 20 % slower.  One
+    rows of one head keep hitting the same tag RAMs, and that head's plane gathers up to 20 % slower (HISTORY.md 4 item 5).  One
     extra line makes the distance odd: every head cycles through all eight residues.  Measured (round 6,
     profiles/r06_row_stride_ab.txt): forward -4 ... -8 %, sample gradients -9 ... -10 % at 900 ... 5 000 queries per batch
     element; c3's bf16 forward -7.5 %; nothing at 10 000 queries, where two-plane workgroups already level it."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev tool: per-XCC (and per-instance) values of a few texture-path / L2 counters for the forward kernel — does the XCD that
-# serves the slow head differ in tag conflicts, pending stalls or L2 channel load?
+# serves the slow head (HISTORY §4 item 5) differ in tag conflicts, pending stalls or L2 channel load?
 #   [OPTS="--opt lds_levels=0"] [INSTANCES=1] bash tools/pmc_xcc.sh "TCP_TAGRAM0_REQ TCP_TAGRAM1_REQ TCP_TAGRAM2_REQ TCP_TAGRAM3_REQ" [kernel substring]
 #   PROG="python tools/row_stride_ab.py --pads 128 --rounds 1 --reps 3 --no-spin": profile that program instead of bench.py
 # (the TA_BUFFER_* counters hang the profiler on this image: do not ask for them)

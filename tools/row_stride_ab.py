@@ -1,7 +1,7 @@
 """dev tool (GPU box): do PADDED value rows pay?  
 
 The vector L1 picks one of its four tag RAMs from the low bits of the 128-byte line index; with H * D * sizeof = 1 024 the
-rows of head 3 are the lines 8 p + 3 and use two of the four.  Rows 1 152 bytes apart (one extra line per
+rows of head 3 are the lines 8 p + 3 and use two of the four (HISTORY.md 4 item 5).  Rows 1 152 bytes apart (one extra line per
 pixel) make every head's rows cycle through all residues mod 8.  The C ABI's `value_row_stride` argument (ABI 11) tells the
 forward and sample-gradient kernels that the pixels' rows of `value` are that many bytes apart; this tool feeds them a
 padded copy and alternates dense / padded inside one process, per-kernel device times from the library's own event pairs.

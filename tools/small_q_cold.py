@@ -2,7 +2,7 @@
 for option strings alternated INSIDE one process (boxes and even runs differ by more than the effects looked for):
     python tools/small_q_cold.py [--triton] [--floor] [--warm] [--reps N] [--flush MiB] [--spin ms] Q [Q ...] -- opt=val[,opt=val] [opt=val ...]
 ("-" = defaults).  --triton: the comparator takes its turn in every round; --flush 1024: the Infinity Cache is flushed too
-(256, the recipe's figure, leaves an undefined share of the pyramid there: DESIGN 9); --reps: rounds of the option list."""
+(256, the recipe's figure, leaves an undefined share of the pyramid there: HISTORY.md 9); --reps: rounds of the option list."""
 import importlib.util
 import os
 import sys
