@@ -7,6 +7,8 @@ bar (1e-4 fp32 vs the native CPU fallback) is what the fp32 forward checks use.
 """
 import zlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -29,7 +31,14 @@ def run_hip(value, shapes, loc, attn, grad_out, pm, ac, dtype=None, needs_grad=T
     """numpy in -> numpy out through the public API (autograd -> ctypes -> C ABI -> HIP)."""
     ops = _ops()
     td = dtype or torch.from_numpy(np.asarray(value)).dtype
-    v = torch.from_numpy(np.asarray(value)).to(DEV, td).requires_grad_(needs_grad)
+    v = torch.from_numpy(np.asarray(value)).to(DEV, td)
+    pad = int(os.environ.get("MSDA_TEST_VALUE_PAD", "0"))  # (tools/fuzz_parity.py: the same cases over padded value rows)
+    if pad:
+        from msda_triton_amd.functional import padded_value_rows
+        vp = padded_value_rows(*v.shape, v.dtype, v.device, pad_bytes=pad * v.element_size())
+        vp.copy_(v)
+        v = vp
+    v.requires_grad_(needs_grad)
     l = torch.from_numpy(np.asarray(loc)).to(DEV, td).requires_grad_(needs_grad)
     a = torch.from_numpy(np.asarray(attn)).to(DEV, td).requires_grad_(needs_grad)
     s = torch.from_numpy(np.asarray(shapes)).to(DEV)

@@ -52,22 +52,32 @@ def make_case(seed):
             # forward (2: every problem it can serve)
             "lds_levels": int(rng.choice([1, 1, 2, 2, 0])), "unit_fwd": int(rng.choice([1, 1, 0, 2])),
             # ... two planes per LDS-level workgroup (2: whenever H is even), block order (linear from N workgroups per plane)
-            "lds_planes": int(rng.choice([0, 2, 2, 1])), "linear_slots": int(rng.choice([320, 1, 6, 40])), "touch": int(rng.choice([1, 0, 2])), "unit_waves": int(rng.choice([1, 2]))}
+            "lds_planes": int(rng.choice([0, 2, 2, 1])), "linear_slots": int(rng.choice([320, 1, 6, 40])), "touch": int(rng.choice([1, 0, 2])), "unit_waves": int(rng.choice([1, 2])),
+            # round 6: passes over the batch (the workspace queries size for n passes; the backward follows the workspace)
+            "ws_passes": int(rng.choice([1, 1, 2, 3])),
+            # ... and padded value rows: elements behind every pixel's H * D channels (0: dense; values whose byte stride is not
+            # a multiple of 16 take the dense-copy route of functional._value_rows — also a path worth fuzzing)
+            "value_pad": int(rng.choice([0, 0, 4, 8, 32, 5]))}
     desc = dict(seed=seed, B=B, Q=Q, H=H, D=D, levels=levels, P=P, range=(lo, hi), pm=pm, ac=ac, f64=f64, **opts)
     return c, pm, ac, td, opts, desc, kind
 
 
-OPTION_DEFAULTS = {"lds_levels": 1, "unit_fwd": 1, "lds_planes": 0, "linear_slots": 320, "touch": 1, "unit_waves": 1}
+OPTION_DEFAULTS = {"lds_levels": 1, "unit_fwd": 1, "lds_planes": 0, "linear_slots": 320, "touch": 1, "unit_waves": 1, "ws_passes": 1}
 
 
 def run_case(c, pm, ac, td, opts):
     try:
         for k, v in opts.items():
-            _lib.set_option(k, v)
+            if k == "value_pad":  # not a library option: the layout of the tensor the test hands over (tests/test_gpu_parity.run_hip)
+                os.environ["MSDA_TEST_VALUE_PAD"] = str(v)
+            else:
+                _lib.set_option(k, v)
         tp.check_against_oracle(msda_oracle, c, pm, ac, tp.FWD_TOL[td], tp.BWD_TOL[td])
     finally:
+        os.environ.pop("MSDA_TEST_VALUE_PAD", None)
         for k in opts:
-            _lib.set_option(k, OPTION_DEFAULTS.get(k, 0))
+            if k != "value_pad":
+                _lib.set_option(k, OPTION_DEFAULTS.get(k, 0))
 
 
 msda_oracle.build()
