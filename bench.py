@@ -682,7 +682,7 @@ def main():
     pts, attn = d["loc"].requires_grad_(True), d["attn"].requires_grad_(True)
     d.pop("grad_out", None)  # (the step draws its own, as the reference's benchmark does)
 
-    exchange = {"chunks": None}  # None: automatic (pieces overlapped with compute); 1: one in-place all-gather
+    exchange = {"chunks": None}  # None: the operator's default (one piece for these shapes); 1: one in-place all-gather; 4: pieces
 
     def op():
         if not use_dist:
@@ -954,7 +954,9 @@ def main():
     pieces_failed = False
     if exchange_ms is not None:
         guard.arm(240, "piece-wise exchange (weak-scaling leg)")
-        exchange["chunks"] = None
+        # (four pieces, forced: the operator's own default is ONE piece for these shapes — default_overlap_chunks: the
+        #  forward cannot hide a piece's exchange — so this leg is what says whether that rule holds on real links)
+        exchange["chunks"] = 4
         try:
             ms2, fwd2 = measure()
             exchange_ms["pieces"] = {"fwd_bwd_ms": ms2, "fwd_ms": fwd2}
