@@ -933,13 +933,6 @@ template <typename T, typename TV> inline int64_t value_batch_per_pass(const Par
     return 0;
 }
 
-// would run_value find a route with this workspace?  (the single-launch kernel, or the sorted pipeline with enough room)
-template <typename T, typename TV = T> inline bool value_ws_ok(const Params &p, const Dims &d, const void *workspace, int64_t workspace_bytes)
-{
-    const bool sorted = sorted_fits<T>(d) && value_batch_per_pass<T, TV>(p, d, workspace, workspace_bytes) > 0;
-    return sorted || small_path_chosen<T>(d) || (option_value_path() != 2 && small_fits<T>(d));
-}
-
 template <typename T, typename TV = T, typename TS = T>
 inline int run_value(Params &p, const Dims &d, void *workspace, int64_t workspace_bytes, hipStream_t stream)
 {
