@@ -772,7 +772,7 @@ int run_fwd(const void *value, const int64_t *shapes, const void *loc, const voi
     p.vrow_bytes = (int)(d.D * (int64_t)sizeof(TV));
     if ((rc = set_value_rows<TV>(p, d, value_row_stride)) != 0) return rc;
     p.touch = touch_plan(d);
-    const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
+    const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16) && p.v_row % 16 == 0;  // (rows that start on 16-byte boundaries)
     rc = dispatch_gather<T, 0, TV>(p, vec_ok, stream);
     if (rc > 0) set_error("forward launch failed: %s", hipGetErrorString((hipError_t)rc));  // negative: message already set
     return rc;
@@ -821,7 +821,7 @@ int run_fwd_fused(const void *value, const int64_t *shapes, const void *proj, co
     if ((rc = set_value_rows<TV>(p, d, value_row_stride)) != 0) return rc;
     p.ref = ref;
     p.ref_dim = ref_dim;
-    const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16);
+    const bool vec_ok = aligned_to(value, 16) && aligned_to(out, 16) && p.v_row % 16 == 0;  // (rows that start on 16-byte boundaries)
     rc = dispatch_gather<T, 2, TV, TS>(p, vec_ok, stream);
     if (rc > 0) set_error("fused forward launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
@@ -1048,7 +1048,7 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
         p.ent_alt1 = grad_attn;
         p.ent_alt2 = grad_value;
     }
-    const bool vec_sample = aligned_to(value, 16) && aligned_to(grad_out, 16);
+    const bool vec_sample = aligned_to(value, 16) && aligned_to(grad_out, 16) && p.v_row % 16 == 0;
     // The two halves of the backward are independent: when both are wanted, grad_loc/grad_attn run on a
     // forked side stream next to the grad_value pipeline (fork/join with events: still graph-capturable).
     hipStream_t sample_stream = stream;
@@ -1167,7 +1167,7 @@ int run_bwd_fused(const void *grad_out, const void *value, const int64_t *shapes
         p.mat_loc = ws;
         p.mat_attn = ws + ns * 2 * sizeof(T);
     }
-    const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16);
+    const bool vec_ok = aligned_to(value, 16) && aligned_to(grad_out, 16) && p.v_row % 16 == 0;
     rc = dispatch_gather<T, 3, TV, TS>(p, vec_ok, stream);
     if (rc) {
         if (rc > 0) set_error("fused backward launch failed: %s", hipGetErrorString((hipError_t)rc));

@@ -264,6 +264,9 @@ struct RowDims {
 
 RowDims row_dims(const at::Tensor &img, const at::Tensor &pts_rows, const at::Tensor &att_rows, int64_t Q)
 {
+    // (pointers of another device — or of the host — must never reach the kernels)
+    TORCH_CHECK_VALUE(img.is_cuda() && pts_rows.device() == img.device() && att_rows.device() == img.device(),
+                      "expected all tensors on one gpu, got ", img.device(), ", ", pts_rows.device(), ", ", att_rows.device());
     TORCH_CHECK_VALUE(img.dim() == 4 && pts_rows.dim() == 5 && att_rows.dim() == 4 && pts_rows.size(4) == 2,
                       "expected img [B,I,H,D], sampling_points [rows,H,L,P,2], attention_weights [rows,H,L,P]");
     TORCH_CHECK_VALUE(pts_rows.size(1) == img.size(2) && att_rows.sizes() == pts_rows.sizes().slice(0, 4),
@@ -302,7 +305,8 @@ void rows_forward(const at::Tensor &img_, const at::Tensor &shapes, const at::Te
     const auto [img, vrow] = value_rows(img_);
     TORCH_CHECK_VALUE(pts_rows.is_contiguous() && att_rows.is_contiguous() && full.is_contiguous(),
                       "rows_forward takes contiguous tensors");
-    TORCH_CHECK_VALUE(shapes.scalar_type() == at::kLong && shapes.is_contiguous(), "img_shapes: contiguous int64");
+    TORCH_CHECK_VALUE(shapes.scalar_type() == at::kLong && shapes.is_contiguous() && shapes.device() == img.device() &&
+                          full.device() == img.device(), "img_shapes: contiguous int64 on the tensors' device; result on it too");
     TORCH_CHECK_VALUE(0 <= in_row0 && in_row0 <= row0 && row0 <= row1 && row1 <= d.B * d.Q &&
                           row1 - in_row0 <= pts_rows.size(0) && full.numel() == d.B * d.Q * d.H * d.D &&
                           full.scalar_type() == pts_rows.scalar_type(),
@@ -335,7 +339,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> rows_backward(const at::Tensor &g
     const RowDims d = row_dims(img_, pts_rows, att_rows, Q);
     const auto [img, vrow] = value_rows(img_);
     TORCH_CHECK_VALUE(pts_rows.is_contiguous() && att_rows.is_contiguous(), "rows_backward takes contiguous tensors");
-    TORCH_CHECK_VALUE(shapes.scalar_type() == at::kLong && shapes.is_contiguous(), "img_shapes: contiguous int64");
+    TORCH_CHECK_VALUE(shapes.scalar_type() == at::kLong && shapes.is_contiguous() && shapes.device() == img.device() &&
+                          grad_rows_.device() == img.device(), "img_shapes: contiguous int64 on the tensors' device; grad_out on it too");
     TORCH_CHECK_VALUE(0 <= r0 && r0 <= r1 && r1 <= d.B * d.Q && pts_rows.size(0) == r1 - r0 &&
                           grad_rows_.numel() == (r1 - r0) * d.H * d.D,
                       "rows_backward: row range / buffer sizes do not match");

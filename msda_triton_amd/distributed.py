@@ -315,8 +315,10 @@ class _RowShardedMSDA(Function):
         bounds = [row_shard_bounds(rows, world, r) for r in range(world)]
         r0, r1 = bounds[rank]
         gpu = img.device.type == "cuda"
-        ext = _rows_ext(img)
-        if ext is not None:  # (the launchers take what the kernels take: dense tensors, int64 level sizes)
+        # (the C++ launchers only for arguments the kernels take — one GPU, a supported dtype combination; anything else
+        #  goes through the Python launchers, whose checks carry the error messages)
+        ext = _rows_ext(img) if _rows_node_ok(img, img_shapes, pts_rows, att_rows, padding_mode) else None
+        if ext is not None:  # (dense tensors, int64 level sizes)
             img, pts_rows, att_rows = img.contiguous(), pts_rows.contiguous(), att_rows.contiguous()
             img_shapes = img_shapes.to(torch.int64).contiguous()
             pad_code = _lib.PADDING_MODES[padding_mode]
@@ -395,7 +397,8 @@ class _RowShardedMSDA(Function):
         else:
             mine = g_rows[r0:r1]
         gpu = img.device.type == "cuda"
-        ext = _rows_ext(img)
+        ext = _rows_ext(img) if _rows_node_ok(img, img_shapes, pts_rows, att_rows, padding_mode) and \
+            grad_full.device == img.device else None
         if ext is not None:
             g_img, g_pts, g_att = ext.rows_backward(mine, img, img_shapes, pts_rows, att_rows, r0, r1, Q,
                                                     _lib.PADDING_MODES[padding_mode], bool(align_corners),

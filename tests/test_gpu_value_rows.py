@@ -97,6 +97,38 @@ def test_padded_rows_with_lds_levels_two_planes_and_touch():
             _lib.set_option(k, v)
 
 
+def test_c_abi_takes_any_element_multiple_as_the_stride(oracle):
+    """Straight through the C ABI: a stride that is a multiple of the element size but not of 16 bytes (the scalar kernels
+    then run: rows no longer start on 16-byte boundaries) — forward and sample gradients against the oracle."""
+    value, shapes, loc, attn, go = _case(2, 150, 4, 32, 3, torch.float32, seed=12)
+    B, I, H, D = value.shape  # noqa: E741
+    Q, L, P = 150, len(LEVELS), 3
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    host = [t.cpu().numpy() for t in (value, shapes, loc, attn)]
+    want = oracle.forward(*host, "border", False)
+    _, want_gl, want_ga = oracle.backward(go.cpu().numpy(), *host, "border", False)
+    for pad_elems in (1, 3, 4, 33):
+        buf = torch.zeros(B, I, H * D + pad_elems, device=DEV)
+        buf[:, :, :H * D] = value.reshape(B, I, H * D)
+        out, gl, ga = torch.empty(B, Q, H, D, device=DEV), torch.empty_like(loc), torch.empty_like(attn)
+        stride = (H * D + pad_elems) * 4
+        assert lib.msda_fwd_f32(buf.data_ptr(), shapes.data_ptr(), loc.data_ptr(), attn.data_ptr(), out.data_ptr(),
+                                B, I, H, D, Q, L, P, 0, 0, stride, st) == 0
+        assert lib.msda_bwd_f32(go.data_ptr(), buf.data_ptr(), shapes.data_ptr(), loc.data_ptr(), attn.data_ptr(), None,
+                                gl.data_ptr(), ga.data_ptr(), B, I, H, D, Q, L, P, 0, 0, 0, stride, None, 0, st) == 0
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ga.cpu().numpy(), want_ga, rtol=1e-3, atol=1e-4)
+        keep = ~_kinks(host[2], host[1])
+        np.testing.assert_allclose(np.where(keep, gl.cpu().numpy(), 0), np.where(keep, want_gl, 0), rtol=1e-3, atol=1e-4)
+
+
+def _kinks(loc, shapes):
+    from conftest import kink_mask
+    return kink_mask(loc, shapes, False)
+
+
 def test_padded_rows_against_the_oracle(oracle):
     value, shapes, loc, attn, go = _case(2, 300, 4, 32, 3, torch.float32, seed=5)
     out, gv, gl, ga = _run(multiscale_deformable_attention, _padded(value), shapes, loc, attn, go, "zeros", False)
