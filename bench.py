@@ -311,6 +311,58 @@ def bench_config(name, dev, steps=20, warmup=5):
             "peak_mem_MB": round(peak / 1e6, 1), "inputs_MB": round(base / 1e6, 1), "kernels": kernels}
 
 
+def padded_rows_leg(wl_name, dev, steps=50, warmup=10, rounds=3):
+    """NOT the headline: the same step with `img` handed over in PADDED rows (every pixel's H * D channels one 128-byte line
+    apart: functional.padded_value_rows, C ABI value_row_stride) next to the dense layout the reference's callers produce,
+    alternated in this process.  What a caller that owns the layout of its value projection gets."""
+    import torch
+    from msda_triton_amd import _lib, synth
+    from msda_triton_amd.functional import multiscale_deformable_attention, padded_value_rows
+
+    wl = synth.WORKLOADS[wl_name]
+    d = synth.make_inputs_torch(wl, dev, seed=0)
+    dense = d["value"]
+    padded = padded_value_rows(*dense.shape, dense.dtype, dense.device)
+    padded.copy_(dense)
+    shapes, pts, attn = d["shapes"], d["loc"].requires_grad_(True), d["attn"].requires_grad_(True)
+    pm, ac = wl.padding_mode, wl.align_corners
+    out = {"what": "the headline step with `img` in padded rows (a caller that owns the layout) against the dense layout; "
+                   "NOT the headline — the reference's callers hand over dense tensors",
+           "value_row_stride": padded.stride(1) * padded.element_size()}
+    res = {"dense": [], "padded": []}
+    kern = {}
+    for _ in range(rounds):
+        for name, img in (("dense", dense), ("padded", padded)):
+            img = img.detach().requires_grad_(True)
+
+            def step():
+                o = multiscale_deformable_attention(img, shapes, pts, attn, pm, ac)
+                o.backward(torch.rand_like(o))
+                img.grad = pts.grad = attn.grad = None
+
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(dev)
+            res[name].append(round((time.perf_counter() - t0) * 1e3 / steps, 4))
+            _lib.set_option("profile", 1)
+            try:
+                _lib.profile_read()
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize(dev)
+                kern[name] = {k: round(v[1], 1) for k, v in _lib.profile_read().items() if "fwd" in k or "bwd_sample" in k}
+            finally:
+                _lib.set_option("profile", 0)
+    out["fwd_bwd_ms"] = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
+    out["fwd_bwd_ms_rounds"] = res
+    out["kernel_us"] = kern
+    return out
+
+
 def real_pyramid_leg(dev, steps=50, warmup=10):
     """Not a BASELINE config: the c4 decoder call (B=8, Q=900) over the pyramid of an 800 x 1066 image (c3's levels)
     instead of 64 x 64 ... 8 x 8 — what a Grounding-DINO / Deformable-DETR decoder layer sees at COCO size — without
@@ -1027,6 +1079,7 @@ def main():
             return out
         optional("configs", leg_configs, False)
         optional("decoder_real_pyramid", lambda: real_pyramid_leg(dev), False)
+        optional("padded_value_rows", lambda: padded_rows_leg(args.workload, dev), False)
     if world == 1 and on_gpu and rank == 0 and not args.no_triton and args.workload == "c2_q10k":
         result["triton_comparator"] = triton_comparator_leg(args.workload, dev)
     if rank == 0:
