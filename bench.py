@@ -329,13 +329,19 @@ def padded_rows_leg(wl_name, dev, steps=50, warmup=10, rounds=3):
     out = {"what": "the headline step with `img` in padded rows (a caller that owns the layout) against the dense layout; "
                    "NOT the headline — the reference's callers hand over dense tensors",
            "value_row_stride": padded.stride(1) * padded.element_size()}
-    res = {"dense": [], "padded": []}
+    res = {"dense": [], "padded": [], "padded_copy_per_step": []}
     kern = {}
     for _ in range(rounds):
-        for name, img in (("dense", dense), ("padded", padded)):
+        # padded_copy_per_step: the ONE-COPY variant for callers with a dense tensor — the step first copies `img` into
+        # padded rows (what a forward that made the copy itself would pay: 22 MB read, 25 MB written at the c2 shape)
+        for name, img in (("dense", dense), ("padded", padded), ("padded_copy_per_step", padded)):
             img = img.detach().requires_grad_(True)
+            copy = name == "padded_copy_per_step"
 
             def step():
+                if copy:
+                    with torch.no_grad():
+                        img.copy_(dense)
                 o = multiscale_deformable_attention(img, shapes, pts, attn, pm, ac)
                 o.backward(torch.rand_like(o))
                 img.grad = pts.grad = attn.grad = None
