@@ -407,3 +407,51 @@ def test_no_kernel_spills_vector_registers_or_uses_scratch(tmp_path):
                 bad.append((m.group(1), "scratch bytes", int(m.group(2)), "vgpr spills", int(m.group(3))))
     assert kernels >= 500, kernels
     assert not bad, bad
+
+
+def test_header_is_plain_c_and_a_c_caller_links(tmp_path):
+    """include/msda_hip.h is the boundary a C / cgo / JNI caller binds: it must compile as plain C (no C++, no HIP or torch
+    types), and a C translation unit calling one entry point of every family with the documented argument lists must
+    compile against it and link against libmsda_hip.so (a prototype that drifts from the library is a link-time or
+    compile-time failure here; nothing is run: no GPU needed)."""
+    import shutil
+    import subprocess
+    from msda_triton_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include <stddef.h>
+#include "msda_hip.h"
+int main(int argc, char **argv)
+{
+    if (msda_abi_version() != MSDA_ABI_VERSION) return 2;   /* the first thing every caller does */
+    if (argc < 1000) return 0;                              /* never reached in the test: the calls below are link checks */
+    void *p = argv; const int64_t *s = (const int64_t *)argv; void *st = NULL;
+    int64_t ws = msda_bwd_workspace_bytes(1, 4, 1, 4, 1, 1, 1, 4, 4, 0, MSDA_WS_RECORDS_IN_GRADS | MSDA_WS_PASSES(2));
+    ws += msda_bwd_fused_workspace_bytes(1, 4, 1, 4, 1, 1, 1, 4, 4, 0, 0);
+    int rc = msda_fwd_f32(p, s, p, p, p, 1, 4, 1, 4, 1, 1, 1, MSDA_PADDING_ZEROS, 0, /*value_row_stride*/ 0, st);
+    rc |= msda_bwd_bf16(p, p, s, p, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, MSDA_PADDING_BORDER, 1, /*max_level_cells*/ 0,
+                        /*value_row_stride*/ 0, p, ws, st);
+    rc |= msda_fwd_fused_f16(p, s, p, p, p, 1, 4, 1, 4, 1, 1, 1, /*ref_dim*/ 2, 0, 0, 0, st);
+    rc |= msda_bwd_fused_f32_sbf16(p, p, s, p, p, p, p, p, 1, 4, 1, 4, 1, 1, 1, 4, 0, 0, 0, 0, p, ws, st);
+    rc |= msda_fwd_f32_vbf16(p, s, p, p, p, 1, 4, 1, 4, 1, 1, 1, 0, 0, 0, st);
+    rc |= msda_bwd_supported(1, 4, 1, 4, 1, 1, 1, 4) | (int)msda_fused_lp_limit(32, 4) | msda_set_option("xcd_map", 1) |
+          msda_get_option("xcd_map") | msda_last_launch_info("fwd_variant") | msda_profile_read((char *)p, 0);
+    return rc + (msda_last_error()[0] != 0);
+}
+''')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-x", "c", os.path.join(inc, "msda_hip.h")],
+                   check=True)
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    res = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", f"-I{inc}", str(src), "-o", str(exe), f"-L{libdir}", "-lmsda_hip",
+                          f"-Wl,-rpath,{libdir}", "-Wl,--unresolved-symbols=ignore-in-shared-libs"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout
+    run = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert run.returncode == 0, (run.returncode, run.stdout)  # the ABI check passed; nothing touched a device
