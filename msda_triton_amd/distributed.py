@@ -11,7 +11,11 @@ The reference has no multi-device code; every (b, q, h) of the operator is indep
             batch element (nothing to do while the ranks divide B), or all-reduced.
 
 With 8 GPUs on one node a rank sends ``B*Q*H*D*s/8`` bytes to every peer over its own point-to-point xGMI link
-(c4 0.9 MB, c5 51 MB per rank); the collectives are issued on whole tensors or on up to four pieces.
+(c4 0.9 MB, c5 51 MB per rank); the exchange is ONE in-place all-gather by default (pieces overlapped with compute only where
+the forward is long enough to hide a piece's exchange: :func:`default_overlap_chunks`).  The launches of a rank's row range
+go through the C++ binding (``csrc/msda_torch_ext.cpp``: ``rows_forward`` / ``rows_backward``; the whole operator is the
+C++ autograd node ``msda_rows`` when there is nothing to exchange), the collectives stay in Python.  Every collective runs
+over RCCL in ``tests/test_gpu_nccl.py`` (an in-process one-rank ``nccl`` group; ``loopback=True``).
 
 Two partitions are offered:
 
