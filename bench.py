@@ -711,6 +711,9 @@ def main():
         dev = torch.device("cpu")
     use_dist = world > 1 or args.force_dist
     if use_dist:
+        # (this pool's host driver only supports dmabuf IPC: without it RCCL's buffer exchange between the ranks' processes
+        #  fails with hipIpcGetMemHandle: invalid argument; the boxes export it already — belt and braces)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if on_gpu:
