@@ -42,6 +42,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# This pool's host driver only supports dmabuf IPC: without it RCCL's buffer exchange between the ranks' processes fails with
+# hipIpcGetMemHandle: invalid argument.  The boxes export it already; set before anything initialises the runtime.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 README_RTX2060_MS = {"fwd": 3.78, "fwd_bwd": 22.78}  # reference README.md:18-19 (Triton, RTX 2060)
@@ -711,9 +714,6 @@ def main():
         dev = torch.device("cpu")
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        # (this pool's host driver only supports dmabuf IPC: without it RCCL's buffer exchange between the ranks' processes
-        #  fails with hipIpcGetMemHandle: invalid argument; the boxes export it already — belt and braces)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if on_gpu:
