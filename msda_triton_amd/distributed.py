@@ -507,6 +507,10 @@ def row_sharded_multiscale_deformable_attention(
     ``inputs_are_sharded=True``: they hold only this rank's rows, flattened: ``[rows, H, L, P, 2]`` /
     ``[rows, H, L, P]`` (``num_queries`` = Q per batch element is then required).
     """
+    if grad_value_sync not in ("all_reduce", "owners", "none"):
+        raise ValueError(f"unknown grad_value_sync {grad_value_sync!r}")
+    if grad_sync not in ("slice", "reduce_scatter"):
+        raise ValueError(f"unknown grad_sync {grad_sync!r}")
     if compute_only_as is not None:
         world, rank = (int(v) for v in compute_only_as)
         if not 0 <= rank < world:
@@ -515,10 +519,6 @@ def row_sharded_multiscale_deformable_attention(
         grad_value_sync = "none"
     elif not (dist.is_available() and dist.is_initialized()):
         raise RuntimeError("torch.distributed is not initialised; call init_process_group first")
-    if grad_value_sync not in ("all_reduce", "owners", "none"):
-        raise ValueError(f"unknown grad_value_sync {grad_value_sync!r}")
-    if grad_sync not in ("slice", "reduce_scatter"):
-        raise ValueError(f"unknown grad_sync {grad_sync!r}")
     if compute_only_as is None:
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     if loopback and (world != 1 or compute_only_as is not None):

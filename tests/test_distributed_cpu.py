@@ -386,3 +386,25 @@ def test_bench_dry_run_world1_carries_the_shard_compute_leg():
         assert leg[key]["2"]["ideal"] == (2 if key.startswith("strong") else 1)
     assert leg["strong_dryrun_strong"]["8"]["rows"] * 8 == leg["strong_dryrun_strong"]["1"]["rows"]
     assert leg["weak_dryrun"]["8"]["rows"] == leg["weak_dryrun"]["1"]["rows"]
+
+
+def test_argument_errors_of_the_row_sharded_operator():
+    """Rejected before anything is computed or exchanged: unknown sync modes, loopback outside a one-rank group (it is a
+    test aid for ONE rank), a compute_only_as rank outside its world, missing num_queries for sharded inputs."""
+    from msda_triton_amd import synth
+    from msda_triton_amd.distributed import row_sharded_multiscale_deformable_attention as op
+    wl = synth.WORKLOADS["dryrun"]
+    d = synth.make_inputs_torch(wl, "cpu", seed=1)
+    args = (d["value"], d["shapes"], d["loc"], d["attn"], wl.padding_mode, wl.align_corners)
+    with pytest.raises(RuntimeError, match="not initialised"):
+        op(*args)
+    with pytest.raises(ValueError, match="grad_value_sync"):
+        op(*args, compute_only_as=(2, 0), grad_value_sync="sometimes")
+    with pytest.raises(ValueError, match="grad_sync"):
+        op(*args, compute_only_as=(2, 0), grad_sync="gather")
+    with pytest.raises(ValueError, match="0 <= rank < world"):
+        op(*args, compute_only_as=(2, 2))
+    with pytest.raises(ValueError, match="loopback"):
+        op(*args, compute_only_as=(1, 0), loopback=True)
+    with pytest.raises(ValueError, match="num_queries"):
+        op(*args, compute_only_as=(2, 0), inputs_are_sharded=True)
