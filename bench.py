@@ -625,6 +625,28 @@ def shard_compute_leg(dev, strong_name, weak_name, ns=(2, 4, 8), steps=5, warmup
     return out
 
 
+_REAL_STDOUT = None  # file descriptor of the process's stdout once library output has been sent to stderr
+
+
+def _library_output_to_stderr():
+    """RCCL prints a version block ("RCCL version : ...", "Librccl path : ...") on STDOUT when its first communicator comes
+    up.  Rank 0's stdout must carry ONE JSON line and nothing else, so in runs that initialise RCCL the process's fd 1 is
+    pointed at stderr for everything — C libraries included — and the line is written to the saved descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
 class _StallGuard:
     """N>1 only.  A step that exchanges over RCCL is armed with a deadline; if it stalls, rank 0 prints the result
     measured so far (with config.stalled naming the step) and every rank leaves the process, so a wedged exchange
@@ -650,7 +672,7 @@ class _StallGuard:
     def _fire(self):
         if self.rank == 0 and self.result is not None:
             self.result["config"]["stalled"] = self.what
-            print(json.dumps(self.result), flush=True)
+            emit(json.dumps(self.result))
         sys.stderr.write(f"bench.py: rank {self.rank}: {self.what} stalled; leaving\n")
         sys.stderr.flush()
         os._exit(0 if self.have_result else 3)
@@ -717,6 +739,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if on_gpu:
+            _library_output_to_stderr()
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -1094,7 +1117,7 @@ def main():
     if rank == 0:
         if failed_legs:
             result["failed_legs"] = failed_legs
-        print(json.dumps(result), flush=True)
+        emit(json.dumps(result))
     if use_dist:
         try:
             dist.barrier()
