@@ -455,3 +455,34 @@ int main(int argc, char **argv)
     assert res.returncode == 0, res.stdout
     run = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert run.returncode == 0, (run.returncode, run.stdout)  # the ABI check passed; nothing touched a device
+
+
+def test_padded_value_rows_layout_rule_on_the_host():
+    """functional.padded_value_rows / _value_rows (no GPU needed): which layouts the launchers hand to the kernels in place —
+    dense, or a [B, I, H, D] view whose pixels sit a constant, 16-byte-multiple number of bytes apart — and which they copy
+    dense first (everything else: the reference's `.contiguous()`, kernels.py:367-370)."""
+    from msda_triton_amd import functional as F
+    assert F.value_row_pad(1024) == 128 and F.value_row_pad(512) == 128 and F.value_row_pad(1152) == 0 and F.value_row_pad(96) == 0
+    dense = torch.randn(2, 5, 8, 32)
+    t, row = F._value_rows(dense)
+    assert t is dense and row == 0
+    p = F.padded_value_rows(2, 5, 8, 32, torch.float32, "cpu")
+    assert tuple(p.shape) == (2, 5, 8, 32) and p.stride() == (5 * 288, 288, 32, 1)
+    t, row = F._value_rows(p)
+    assert t is p and row == 1152
+    p16 = F.padded_value_rows(1, 5, 8, 32, torch.bfloat16, "cpu")          # 512-byte rows: one more line
+    assert F._value_rows(p16)[1] == 640
+    odd = F.padded_value_rows(2, 5, 8, 32, torch.float32, "cpu", pad_bytes=20)  # not a multiple of 16 bytes: copied dense
+    t, row = F._value_rows(odd)
+    assert t.is_contiguous() and row == 0
+    for other in (dense.transpose(1, 2).contiguous().transpose(1, 2), dense[:, ::2], dense.permute(0, 1, 3, 2)):
+        t, row = F._value_rows(other)
+        assert t.is_contiguous() and row == 0 and torch.equal(t, other)
+    with pytest.raises(ValueError, match="multiple of the element size"):
+        F.padded_value_rows(1, 2, 2, 4, torch.float32, "cpu", pad_bytes=6)
+    # the host path takes a padded pyramid like any other strided tensor
+    shapes = torch.tensor([[1, 5]])
+    pts, att = torch.rand(2, 3, 8, 1, 2, 2), torch.rand(2, 3, 8, 1, 2)
+    p.copy_(dense)
+    torch.testing.assert_close(F.multiscale_deformable_attention(p, shapes, pts, att, "zeros", False),
+                               F.multiscale_deformable_attention(dense, shapes, pts, att, "zeros", False))

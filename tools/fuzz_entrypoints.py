@@ -18,7 +18,18 @@ import numpy as np
 import torch
 
 from msda_triton_amd import _lib
-from msda_triton_amd.functional import (fused_module_core, module_sampling_inputs, multiscale_deformable_attention)
+from msda_triton_amd.functional import (fused_module_core, module_sampling_inputs, multiscale_deformable_attention,
+                                        padded_value_rows)
+
+
+def rows(t, pad_bytes):
+    """`t` [B, I, H, D] handed over in padded rows (round 6: value_row_stride) — or as it is (pad_bytes 0)"""
+    if not pad_bytes:
+        return t
+    p = padded_value_rows(*t.shape, t.dtype, t.device, pad_bytes)
+    p.copy_(t)
+    return p
+
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -54,8 +65,10 @@ while time.time() - t0 < budget:
     shapes = torch.tensor(levels, dtype=torch.int64, device=dev)
     opts = {"value_path": int(rng.choice([0, 2, 3])), "small_ns": int(rng.choice([0, 0, 2, 3])),
             "lds_levels": int(rng.choice([1, 1, 2, 0])), "unit_fwd": int(rng.choice([1, 1, 0, 2])),
-            "lds_planes": int(rng.choice([0, 2, 2, 1])), "linear_slots": int(rng.choice([320, 1, 6, 40])), "touch": int(rng.choice([1, 0, 2])), "unit_waves": int(rng.choice([1, 2]))}
-    desc = dict(seed=seed, kind=kind, B=B, Q=Q, H=H, D=D, levels=levels, P=P, pm=pm, ac=ac, **opts)
+            "lds_planes": int(rng.choice([0, 2, 2, 1])), "linear_slots": int(rng.choice([320, 1, 6, 40])), "touch": int(rng.choice([1, 0, 2])), "unit_waves": int(rng.choice([1, 2])),
+            "ws_passes": int(rng.choice([1, 1, 2, 3]))}
+    pad = int(rng.choice([0, 0, 64, 128, 48]))  # bytes behind every pixel's rows of the TESTED route's value pyramid
+    desc = dict(seed=seed, kind=kind, B=B, Q=Q, H=H, D=D, levels=levels, P=P, pm=pm, ac=ac, value_pad=pad, **opts)
     try:
         for k, v in opts.items():
             _lib.set_option(k, v)
@@ -69,7 +82,9 @@ while time.time() - t0 < budget:
             desc.update(dtype=str(dt), coords=coords)
             res = []
             for fused in (True, False):
-                v, pr, rf = (t.clone().to(dev).requires_grad_(True) for t in (value, proj, ref))
+                v, pr, rf = (t.clone().to(dev) for t in (value, proj, ref))
+                v = rows(v, pad if fused else 0)
+                v.requires_grad_(True), pr.requires_grad_(True), rf.requires_grad_(True)
                 if fused:
                     out = fused_module_core(v, shapes, pr, rf, pm, ac)
                 else:
@@ -93,6 +108,7 @@ while time.time() - t0 < budget:
             res = []
             for low in (True, False):
                 v, pr, go = ((t if low else t.float()).clone().to(dev) for t in (value, proj, gout))
+                v = rows(v, pad if low else 0)
                 v.requires_grad_(True), pr.requires_grad_(True)
                 rf = ref.clone().to(dev).requires_grad_(True)
                 out = fused_module_core(v, shapes, pr, rf, pm, ac)
@@ -118,7 +134,7 @@ while time.time() - t0 < budget:
                 loc, attn, gout = loc.to(sdt), attn.to(sdt), gout.to(sdt)
             res = []
             for low in (True, False):
-                v = (value if low else value.float()).clone().to(dev).requires_grad_(True)
+                v = rows((value if low else value.float()).clone().to(dev), pad if low else 0).requires_grad_(True)
                 lo = (loc if low else loc.float()).clone().to(dev).requires_grad_(True)
                 at = (attn if low else attn.float()).clone().to(dev).requires_grad_(True)
                 out = multiscale_deformable_attention(v, shapes, lo, at, pm, ac)
@@ -136,7 +152,7 @@ while time.time() - t0 < budget:
         print("FAIL", json.dumps(desc), "::", str(e).strip().splitlines()[0][:300], flush=True)
     finally:
         for k in opts:
-            _lib.set_option(k, {"lds_levels": 1, "unit_fwd": 1, "linear_slots": 320, "touch": 1, "unit_waves": 1}.get(k, 0))
+            _lib.set_option(k, {"lds_levels": 1, "unit_fwd": 1, "linear_slots": 320, "touch": 1, "unit_waves": 1, "ws_passes": 1}.get(k, 0))
     n += 1
     seen[kind] = seen.get(kind, 0) + 1
     seed += 1
