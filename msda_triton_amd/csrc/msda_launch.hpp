@@ -1039,7 +1039,7 @@ int run_bwd(const void *grad_out, const void *value, const int64_t *shapes, cons
     // grad_attn are written only by the sample-gradient kernel, so that kernel goes LAST and the records of as many
     // planes as fit live in those two buffers (three quarters of them in fp32: 61 of 82 MB at c2 @ 10k); the rest go
     // into grad_value itself, which only the finish kernel writes, behind the gather (single-round problems).  The
-    // workspace layout shrinks accordingly (msda_bwd_workspace_bytes_ex with MSDA_WS_RECORDS_IN_GRADS); a caller that
+    // workspace layout shrinks accordingly (msda_bwd_workspace_bytes with MSDA_WS_RECORDS_IN_GRADS); a caller that
     // passes the full size loses nothing.
     const bool records_in_grads = want_sample && want_value && option_records_in_grads() != 0 && option_overlap() != 1 &&
                                   aligned_to(grad_loc, 16) && aligned_to(grad_attn, 16) && aligned_to(grad_value, 16);

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kSmallBlock) void msda_value_small_kernel(const Par
     const int npix = lw * lh;
     const int pstart = tab->start[lvl];
     if (p.small_hinted && ncl_true > p.small_cells) {
-        // The caller promised smaller levels than this one (msda_hint_level_cells) and the table was sized on that
+        // The caller promised smaller levels than this one (max_level_cells) and the table was sized on that
         // promise: there is no way to report it from here, so the level's rows come back as NaN instead of wrong.
         if (share == 0) {
             const A nan = (A)__builtin_nanf("");
