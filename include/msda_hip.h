@@ -108,9 +108,9 @@ extern "C" {
  * would pad: the gather kernels are bound by the vector L1, which picks one of its four tag RAMs from the low bits of a
  * row's 128-byte line index; rows exactly 1 024 bytes apart (H * D * sizeof = 1 KB: 8 heads x 32 channels x fp32) put
  * every row of one head on half of them, and that head's plane gathers ~20 % slower.  One extra 128-byte line per pixel
- * (1 152) makes every head cycle through all residues: forward -3.5 ... -8 %, sample gradients -10 % at 900 ... 10 000
- * queries per batch element (profiles/r06_row_stride_ab.txt; the whole training step -2.5 ... -5 %,
- * r06_padded_step_ab.txt; nothing at 1 000 queries and below).  A caller that OWNS the layout — a module that writes the value projection itself — can do
+ * (1 152) makes every head cycle through all residues: forward -3.5 ... -8 %, sample gradients -10 % at B = 4 with 5 000
+ * / 10 000 queries and at B = 8 with 900 (profiles/r06_row_stride_ab.txt; the whole training step -2.5 ... -5 %,
+ * r06_padded_step_ab.txt; nothing at B = 4 with 1 000).  A caller that OWNS the layout — a module that writes the value projection itself — can do
  * that for free (GEMM output with a leading dimension of H * D + 32 floats); grad_value is always dense.  Results are
  * bit-identical to the dense layout.
  *
